@@ -1,0 +1,142 @@
+"""ctypes binding of libadaptive_stereo_hip.so (C ABI: include/adaptive_stereo_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback for the
+operators it provides.  If it is missing (not built, wrong path) every operator
+raises, loudly, with the build command.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadaptive_stereo_hip.so")
+BUILD_HINT = "build it with: make -C %s" % os.path.join(os.path.dirname(_HERE), "csrc")
+
+c_int, c_float, c_i64, c_vp = ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_void_p
+
+
+class Pcl(ctypes.Structure):
+  """as_pcl: geometry of a padded channel-last tensor [B][D+2pd][H+2ph][W+2pw][32]."""
+  _fields_ = [(n, ctypes.c_int32) for n in ("B", "D", "H", "W", "pd", "ph", "pw")]
+
+  def numel(self):
+    return self.B * (self.D + 2 * self.pd) * (self.H + 2 * self.ph) * (self.W + 2 * self.pw) * 32
+
+  def voxels(self):
+    return self.B * self.D * self.H * self.W
+
+  def key(self):
+    return (self.B, self.D, self.H, self.W, self.pd, self.ph, self.pw)
+
+
+class ConvShape(ctypes.Structure):
+  """as_conv_shape."""
+  _fields_ = [(n, ctypes.c_int32) for n in ("kd", "kh", "kw", "pad_d", "pad_h", "pad_w", "dil", "stride")]
+
+  def taps(self):
+    return self.kd * self.kh * self.kw
+
+
+_P = ctypes.POINTER
+_SIGNATURES = {
+  # name: (restype, [argtypes])
+  "as_last_error": (ctypes.c_char_p, []),
+  "as_version": (c_int, []),
+  "as_pcl_numel": (c_i64, [_P(Pcl)]),
+  "as_cost_volume_fwd": (c_int, [c_vp, c_vp, c_vp, _P(Pcl), c_vp]),
+  "as_cost_volume_bwd": (c_int, [c_vp, c_vp, c_vp, _P(Pcl), c_vp]),
+  "as_conv32_pack_weights": (c_int, [c_vp, c_vp, _P(ConvShape), c_int, c_vp]),
+  "as_conv32_num_blocks": (c_int, [_P(Pcl)]),
+  "as_conv32_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_float,
+                            c_vp, c_vp, c_vp, c_vp]),
+  "as_conv32_wgrad_workspace": (c_i64, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
+  "as_conv32_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp]),
+  "as_bn_finalize": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp,
+                             c_vp, c_vp]),
+  "as_bn_eval_affine": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  "as_bn_act_fwd": (c_int, [c_vp, c_vp, c_vp, c_float, c_vp, c_vp, _P(Pcl), c_vp]),
+  "as_bn_bwd_workspace": (c_i64, [_P(Pcl)]),
+  "as_bn_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_vp,
+                            _P(Pcl), c_vp]),
+  "as_conv3d_out_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp]),
+  "as_conv3d_out_bwd_workspace": (c_i64, [_P(Pcl)]),
+  "as_conv3d_out_bwd": (c_int, [c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  "as_softargmax_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+  "as_softargmax_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+  "as_upsample_bilinear_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),
+  "as_upsample_bilinear_bwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),
+  "as_warp_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+  "as_warp_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+  "as_monodepth_workspace": (c_i64, [c_int, c_int, c_int]),
+  "as_monodepth_loss_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                    c_vp]),
+  "as_monodepth_loss_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp,
+                                    c_vp, c_vp, c_vp]),
+  "as_masked_sum_workspace": (c_i64, [c_i64]),
+  "as_masked_sum": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+  "as_sumsq_workspace": (c_i64, [c_i64]),
+  "as_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+  "as_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_float, c_float, c_float, c_float, c_int, c_vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib = None
+
+
+def load():
+  """Returns the loaded library; raises RuntimeError if it cannot be loaded."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise RuntimeError("adaptive_stereo: HIP library %s is missing; %s" % (LIB_PATH, BUILD_HINT))
+    try:
+      lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+      raise RuntimeError("adaptive_stereo: cannot load %s (%s); %s" % (LIB_PATH, e, BUILD_HINT))
+    for name, (res, args) in _SIGNATURES.items():
+      fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+      fn.restype = res
+      fn.argtypes = args
+    _lib = lib
+  return _lib
+
+
+def call(name, *args):
+  """Invokes an int-returning entry point and raises on a non-zero status."""
+  lib = load()
+  rc = getattr(lib, name)(*args)
+  if rc != 0:
+    raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.as_last_error().decode()))
+
+
+def ptr(t):
+  """Device pointer of a tensor (None -> NULL)."""
+  if t is None:
+    return None
+  return c_vp(t.data_ptr())
+
+
+def stream():
+  return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+  for t in tensors:
+    if t is None:
+      continue
+    if not t.is_cuda:
+      raise RuntimeError("adaptive_stereo: tensors must live on the GPU (got %s); there is no CPU path" % t.device)
+    if t.dtype not in (torch.float32, torch.uint8, torch.int32, torch.bool):
+      raise RuntimeError("adaptive_stereo: unsupported dtype %s" % t.dtype)
+
+
+def f32c(t):
+  """fp32 contiguous view/copy of a GPU tensor."""
+  if t is None:
+    return None
+  require_gpu(t)
+  if t.dtype != torch.float32:
+    t = t.float()
+  return t.contiguous()

@@ -1,0 +1,166 @@
+"""StereoNet / FeatureExtractorNetwork with the reference's public contract, computed on MI355X.
+
+Drop-in surface (reference: adaptive_stereo/models/stereo_net.py):
+  FeatureExtractorNetwork(k)(rgb[B,3,H,W]) -> [B,32,Hc,Wc]                       (:54-85)
+  StereoNet(k, r, input_scale, maxdisp=192)(left_img, left_features, right_features,
+            side, output_cost_volume=False) -> {"cost_volume_{side}/{s+k}",      (:137-207)
+            "pred_disp_{side}/{s+k}", "pred_disp_{side}/{s}"}
+  identical ``state_dict`` keys and shapes, including the never-executed
+  ``BasicBlock.conv2`` tensors (:40) — checkpoints interchange with the reference.
+
+The modules below are parameter containers: their nested ModuleLists exist to reproduce
+the reference's key names.  ``forward`` never calls an nn.Conv3d/BatchNorm3d: the cost
+volume, the 3-D aggregation, the soft-argmax, the up-sampling and their backward passes
+run as hand-written HIP kernels behind ``libadaptive_stereo_hip.so`` (hip_ops.py).  The
+2-D convolutions of the feature extractor and of the edge-aware refinement are issued
+through MIOpen in this revision ("MIOpen first").
+There is no CPU path: tensors must be on the GPU and the HIP library must be built.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _native as nat
+from .. import hip_ops
+
+LEAKY_SLOPE = hip_ops.LEAKY_SLOPE
+REFINE_DILATIONS = (1, 2, 4, 8, 1, 1)
+
+
+class _ConvBN(nn.ModuleList):
+  """[conv, batchnorm] pair; children are named "0" and "1" like the reference's nn.Sequential."""
+
+  def __init__(self, dims, cin, cout, ksize, dilation=1):
+    conv_t, bn_t = (nn.Conv3d, nn.BatchNorm3d) if dims == 3 else (nn.Conv2d, nn.BatchNorm2d)
+    pad = dilation if dilation > 1 else 1
+    super().__init__([conv_t(cin, cout, ksize, stride=1, padding=pad, dilation=dilation), bn_t(cout)])
+
+  @property
+  def conv(self):
+    return self[0]
+
+  @property
+  def bn(self):
+    return self[1]
+
+
+class _ResidualBlock2d(nn.Module):
+  """x + LeakyReLU(BN(Conv3x3_dilated(x))).  ``conv2`` holds parameters the reference
+  allocates but never uses (stereo_net.py:40, 44-51); they receive no gradient."""
+
+  def __init__(self, dilation):
+    super().__init__()
+    self.dilation = dilation
+    self.conv1 = nn.ModuleList([_ConvBN(2, 32, 32, 3, dilation)])
+    self.conv2 = _ConvBN(2, 32, 32, 3, dilation)
+
+  def forward(self, x):
+    cb = self.conv1[0]
+    y = F.conv2d(x, cb.conv.weight, cb.conv.bias, 1, cb.conv.padding, cb.conv.dilation)
+    y = F.batch_norm(y, cb.bn.running_mean, cb.bn.running_var, cb.bn.weight, cb.bn.bias,
+                     self.training, cb.bn.momentum, cb.bn.eps)
+    if self.training:
+      cb.bn.num_batches_tracked += 1
+    return x + F.leaky_relu(y, LEAKY_SLOPE)
+
+
+class FeatureExtractorNetwork(nn.Module):
+  def __init__(self, k):
+    super().__init__()
+    self.k = k
+    self.downsample = nn.ModuleList(
+        [nn.Conv2d(3 if i == 0 else 32, 32, kernel_size=5, stride=2, padding=2) for i in range(k)])
+    self.residual_blocks = nn.ModuleList([_ResidualBlock2d(1) for _ in range(6)])
+    self.conv_alone = nn.Conv2d(32, 32, kernel_size=3, stride=1, padding=1)
+
+  def forward(self, rgb_img):
+    nat.require_gpu(rgb_img)
+    x = rgb_img
+    for conv in self.downsample:          # no activation between the strided convs (:81-82)
+      x = conv(x)
+    for block in self.residual_blocks:
+      x = block(x)
+    return self.conv_alone(x)
+
+
+class EdgeAwareRefinement(nn.Module):
+  def __init__(self, in_channels):
+    super().__init__()
+    self.conv2d_feature = nn.ModuleList([_ConvBN(2, in_channels, 32, 3, 1)])
+    self.residual_astrous_blocks = nn.ModuleList([_ResidualBlock2d(d) for d in REFINE_DILATIONS])
+    self.conv2d_out = nn.Conv2d(32, 1, kernel_size=3, stride=1, padding=1)
+
+  def forward(self, coarse_disparity, guidance_rgb):
+    H, W = guidance_rgb.shape[-2:]
+    gain = W / coarse_disparity.shape[-1]          # float ratio, e.g. 1242/78 (:113)
+    up = hip_ops.UpsampleBilinearFn.apply(coarse_disparity, H, W, gain)
+    cb = self.conv2d_feature[0]
+    x = F.conv2d(torch.cat([up, guidance_rgb], dim=1), cb.conv.weight, cb.conv.bias, 1, 1)
+    x = F.batch_norm(x, cb.bn.running_mean, cb.bn.running_var, cb.bn.weight, cb.bn.bias,
+                     self.training, cb.bn.momentum, cb.bn.eps)
+    if self.training:
+      cb.bn.num_batches_tracked += 1
+    x = F.leaky_relu(x, LEAKY_SLOPE)
+    for block in self.residual_astrous_blocks:
+      x = block(x)
+    return F.relu(up + self.conv2d_out(x))
+
+
+class DisparityRegression(nn.Module):
+  """sum_d d * x[:, d] (stereo_net.py:124-134).  Exported only because callers import the name
+  (evaluation/ood_analysis.py:13); it is NOT on the hot path — StereoNet.forward uses the fused
+  soft-argmax kernel (as_softargmax_fwd), which never materialises the probabilities."""
+
+  def __init__(self, maxdisp):
+    super().__init__()
+    self.maxdisp = maxdisp
+
+  def forward(self, x):
+    nat.require_gpu(x)
+    idx = torch.arange(self.maxdisp, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+    return (x * idx).sum(dim=1)
+
+
+class StereoNet(nn.Module):
+  def __init__(self, k, r, input_scale, maxdisp=192):
+    super().__init__()
+    self.maxdisp = maxdisp
+    self.k = k
+    self.r = r
+    self.input_scale = input_scale
+    self.filter = nn.ModuleList([nn.ModuleList([_ConvBN(3, 32, 32, 3)]) for _ in range(4)])
+    self.conv3d_alone = nn.Conv3d(32, 1, kernel_size=3, stride=1, padding=1)
+    self.edge_aware_refinements = nn.ModuleList([EdgeAwareRefinement(4)])
+
+  def coarse_max_disp(self):
+    return (self.maxdisp + 1) // (2 ** (self.input_scale + self.k))
+
+  def forward(self, left_img, left_features, right_features, side, output_cost_volume=False):
+    nat.require_gpu(left_img, left_features, right_features)
+    params, buffers = [], []
+    for f in self.filter:
+      cb = f[0]
+      params += [cb.conv.weight, cb.conv.bias, cb.bn.weight, cb.bn.bias]
+      buffers.append((cb.bn.running_mean, cb.bn.running_var))
+    params += [self.conv3d_alone.weight, self.conv3d_alone.bias]
+
+    logits, pred, argmax, fcs = hip_ops.CostAggregationFn.apply(
+        left_features, right_features, self.coarse_max_disp(), self.training, buffers, *params)
+    if self.training:
+      for f in self.filter:
+        f[0].bn.num_batches_tracked += 1
+
+    # By-products of the fused soft-argmax kernel; feature_contrast_mean() picks the FCS up
+    # from the logits tensor instead of sorting the volume again.
+    logits._as_fcs = fcs
+    logits._as_argmax = argmax
+
+    coarse_scale = self.input_scale + self.k
+    outputs = {}
+    if output_cost_volume:
+      outputs["cost_volume_{}/{}".format(side, coarse_scale)] = logits
+    H, W = left_img.shape[-2:]
+    outputs["pred_disp_{}/{}".format(side, coarse_scale)] = hip_ops.UpsampleBilinearFn.apply(
+        pred, H, W, float(2 ** self.k))
+    outputs["pred_disp_{}/{}".format(side, self.input_scale)] = self.edge_aware_refinements[0](pred, left_img)
+    return outputs

@@ -1,0 +1,25 @@
+"""Feature-contrast score (OOD score) — reference adaptive_stereo/utils/feature_contrast.py:12-23.
+
+The reference sorts the whole [B,Dc,Hc,Wc] volume along Dc to take ``max - mean(sorted[2:])``.
+Only the two largest values and the sum are needed: fcs = m1 - (sum - m1 - m2)/(Dc-2), which the
+soft-argmax kernel already produces in the same pass over the logits.  StereoNet.forward attaches
+that by-product to the logits tensor; a volume that did not come from StereoNet is scored by
+running the kernel on it.
+"""
+import torch
+
+from .. import _native as nat
+
+
+def feature_contrast_mean(cost_volume):
+  nat.require_gpu(cost_volume)
+  cached = getattr(cost_volume, "_as_fcs", None)
+  if cached is not None:
+    return cached
+  with torch.no_grad():
+    logits = nat.f32c(cost_volume.detach())
+    B, D, H, W = logits.shape
+    pred = torch.empty(B, H, W, dtype=torch.float32, device=logits.device)
+    fcs = torch.empty_like(pred)
+    nat.call("as_softargmax_fwd", nat.ptr(logits), B, D, H, W, nat.ptr(pred), None, nat.ptr(fcs), nat.stream())
+    return fcs

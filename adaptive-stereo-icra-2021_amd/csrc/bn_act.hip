@@ -1,0 +1,272 @@
+// BatchNorm (train / eval) + LeakyReLU(0.2) (+ BasicBlock skip) around conv32.
+// Reference semantics: nn.BatchNorm3d/2d defaults (eps 1e-5, momentum 0.1, affine,
+// running stats) + nn.LeakyReLU(0.2, inplace) — adaptive_stereo/models/stereo_net.py
+// :17,29,39,94,159; train-mode batch statistics during adaptation (adapt.py:309-314).
+//
+// Statistics are exact-merge (Chan) in fp64 of the per-workgroup (mean, M2) pairs the
+// convolution epilogue emitted from its register tile, mirroring ATen's CPU kernel,
+// which accumulates BatchNorm moments in double for float inputs.
+// All element-wise passes are HBM-bound: float4 per lane over the PCL interior.
+#include "as_common.h"
+
+// ---- finalize: one workgroup, 256 threads = 8 slices x 32 channels -----------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ stat_mean, const float* __restrict__ stat_m2, int nblocks, long count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
+    float momentum, float eps, float* save_mean, float* save_invstd, float* scale, float* shift) {
+  __shared__ double sn[8][32], smean[8][32], sm2[8][32];
+  const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int i = sl; i < nblocks; i += 8) {
+    const long first = (long)i * 128;
+    const double nb = (double)((count - first) < 128 ? (count - first) : 128);
+    const double mb = (double)stat_mean[i * 32 + c], qb = (double)stat_m2[i * 32 + c];
+    const double tot = n + nb, delta = mb - mean;
+    mean += delta * (nb / tot);
+    m2 += qb + delta * delta * (n * nb / tot);
+    n = tot;
+  }
+  sn[sl][c] = n; smean[sl][c] = mean; sm2[sl][c] = m2;
+  __syncthreads();
+  if (sl == 0) {
+    for (int j = 1; j < 8; ++j) {
+      const double nb = sn[j][c];
+      if (nb == 0.0) continue;
+      const double tot = n + nb, delta = smean[j][c] - mean;
+      mean += delta * (nb / tot);
+      m2 += sm2[j][c] + delta * delta * (n * nb / tot);
+      n = tot;
+    }
+    const double var_b = m2 / n;
+    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+    const float meanf = (float)mean;
+    save_mean[c] = meanf;
+    save_invstd[c] = invstd;
+    const float sc = invstd * gamma[c];
+    scale[c] = sc;
+    shift[c] = beta[c] - meanf * sc;
+    if (running_mean) {
+      const double var_u = n > 1.0 ? m2 / (n - 1.0) : var_b;
+      running_mean[c] = (float)((double)momentum * mean + (1.0 - (double)momentum) * (double)running_mean[c]);
+      running_var[c] = (float)((double)momentum * var_u + (1.0 - (double)momentum) * (double)running_var[c]);
+    }
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* save_mean, float* save_invstd, float* scale, float* shift) {
+  const int c = threadIdx.x;
+  if (c >= 32) return;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = invstd * gamma[c];
+  save_mean[c] = rm[c];
+  save_invstd[c] = invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---- a = lrelu(z*scale + shift) (+ residual), interior only -------------------------
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope,
+                                                          const float* __restrict__ residual, float* __restrict__ a,
+                                                          PclDev g, long M) {
+  const int c4 = threadIdx.x & 7;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+  const long stride = (long)gridDim.x * 32;
+  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < M; v += stride) {
+    long t = v;
+    const int x = t % g.W; t /= g.W;
+    const int y = t % g.H; t /= g.H;
+    const int d = t % g.D;
+    const int b = t / g.D;
+    const long off = g.vox(b, d, y, x) * 32 + c4 * 4;
+    f32x4 q = *reinterpret_cast<const f32x4*>(z + off);
+    q = q * sc + sh;
+    q.x = q.x > 0.f ? q.x : q.x * slope;
+    q.y = q.y > 0.f ? q.y : q.y * slope;
+    q.z = q.z > 0.f ? q.z : q.z * slope;
+    q.w = q.w > 0.f ? q.w : q.w * slope;
+    if (residual) q += *reinterpret_cast<const f32x4*>(residual + off);
+    *reinterpret_cast<f32x4*>(a + off) = q;
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------
+// stage 1: per-workgroup partial sums of g_y and g_y*(z-mean) per channel (fp64 slabs).
+#define BNB_BLOCKS 1024
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g_a, const float* __restrict__ z,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, float slope,
+                                                             double* __restrict__ partial, PclDev g, long M) {
+  __shared__ double red[2][32][33];
+  const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+  f32x4 s_dy = {0.f, 0.f, 0.f, 0.f}, s_dx = {0.f, 0.f, 0.f, 0.f};
+  const long stride = (long)gridDim.x * 32;
+  for (long v = (long)blockIdx.x * 32 + vl; v < M; v += stride) {
+    long t = v;
+    const int x = t % g.W; t /= g.W;
+    const int y = t % g.H; t /= g.H;
+    const int d = t % g.D;
+    const int b = t / g.D;
+    const long off = g.vox(b, d, y, x) * 32 + c4 * 4;
+    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + off);
+    f32x4 gy = *reinterpret_cast<const f32x4*>(g_a + off);
+    const f32x4 yy = zz * sc + sh;
+    gy.x = yy.x > 0.f ? gy.x : gy.x * slope;
+    gy.y = yy.y > 0.f ? gy.y : gy.y * slope;
+    gy.z = yy.z > 0.f ? gy.z : gy.z * slope;
+    gy.w = yy.w > 0.f ? gy.w : gy.w * slope;
+    s_dy += gy;
+    s_dx += gy * (zz - mu);
+  }
+  for (int i = 0; i < 4; ++i) {
+    red[0][vl][c4 * 4 + i] = (double)s_dy[i];
+    red[1][vl][c4 * 4 + i] = (double)s_dx[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+    double s = 0.0;
+    for (int j = 0; j < 32; ++j) s += red[which][j][c];
+    partial[(long)blockIdx.x * 64 + which * 32 + c] = s;
+  }
+}
+
+// stage 2: fixed-order sum of the slabs; emits g_gamma, g_beta and the per-channel
+// coefficients of stage 3:  g_z = (g_y - k1 - (z-mean)*k2) * k3.
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long count,
+                                       const float* __restrict__ invstd, const float* __restrict__ gamma, int train,
+                                       float* g_gamma, float* g_beta, float* coef) {
+  const int c = threadIdx.x;
+  if (c >= 32) return;
+  double sdy = 0.0, sdx = 0.0;
+  for (int i = 0; i < nblocks; ++i) {
+    sdy += partial[(long)i * 64 + c];
+    sdx += partial[(long)i * 64 + 32 + c];
+  }
+  const double is = (double)invstd[c];
+  g_gamma[c] = (float)(sdx * is);
+  g_beta[c] = (float)sdy;
+  coef[c] = train ? (float)(sdy / (double)count) : 0.f;
+  coef[32 + c] = train ? (float)(sdx * is * is / (double)count) : 0.f;
+  coef[64 + c] = invstd[c] * gamma[c];
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g_a, const float* __restrict__ z,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ coef,
+                                                            float slope, float* __restrict__ g_z, PclDev g, long M) {
+  const int c4 = threadIdx.x & 7;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+  const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
+  const f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + 32 + c4 * 4);
+  const f32x4 k3 = *reinterpret_cast<const f32x4*>(coef + 64 + c4 * 4);
+  const long stride = (long)gridDim.x * 32;
+  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < M; v += stride) {
+    long t = v;
+    const int x = t % g.W; t /= g.W;
+    const int y = t % g.H; t /= g.H;
+    const int d = t % g.D;
+    const int b = t / g.D;
+    const long off = g.vox(b, d, y, x) * 32 + c4 * 4;
+    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + off);
+    f32x4 gy = *reinterpret_cast<const f32x4*>(g_a + off);
+    const f32x4 yy = zz * sc + sh;
+    gy.x = yy.x > 0.f ? gy.x : gy.x * slope;
+    gy.y = yy.y > 0.f ? gy.y : gy.y * slope;
+    gy.z = yy.z > 0.f ? gy.z : gy.z * slope;
+    gy.w = yy.w > 0.f ? gy.w : gy.w * slope;
+    const f32x4 dx = (zz - mu) * k2;
+    *reinterpret_cast<f32x4*>(g_z + off) = (gy - k1 - dx) * k3;
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------
+static inline int elementwise_blocks(long M) {
+  long nb = (M + 31) / 32;
+  if (nb > 4096) nb = 4096;   // grid-stride beyond ~16 workgroups per CU
+  return (int)nb;
+}
+
+extern "C" int as_bn_finalize(const float* stat_mean, const float* stat_m2, int nblocks, int64_t count,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* save_mean, float* save_invstd,
+                              float* scale, float* shift, void* stream) {
+  AS_CHECK_ARG(stat_mean && stat_m2 && gamma && beta && save_mean && save_invstd && scale && shift,
+               "as_bn_finalize: null pointer");
+  AS_CHECK_ARG(nblocks >= 1 && count >= 1 && (int64_t)nblocks == (count + 127) / 128,
+               "as_bn_finalize: nblocks=%d inconsistent with count=%lld", nblocks, (long long)count);
+  AS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "as_bn_finalize: running stats must pair");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stat_mean, stat_m2, nblocks,
+                     (long)count, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                     scale, shift);
+  AS_CHECK_LAUNCH("as_bn_finalize");
+  return AS_OK;
+}
+
+extern "C" int as_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, float* save_mean, float* save_invstd,
+                                 float* scale, float* shift, void* stream) {
+  AS_CHECK_ARG(gamma && beta && running_mean && running_var && save_mean && save_invstd && scale && shift,
+               "as_bn_eval_affine: null pointer");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, eps, save_mean, save_invstd, scale, shift);
+  AS_CHECK_LAUNCH("as_bn_eval_affine");
+  return AS_OK;
+}
+
+extern "C" int as_bn_act_fwd(const float* z, const float* scale, const float* shift, float slope,
+                             const float* residual, float* a, const as_pcl* g, void* stream) {
+  AS_CHECK_ARG(as_pcl_ok(g), "as_bn_act_fwd: bad geometry");
+  AS_CHECK_ARG(z && scale && shift && a, "as_bn_act_fwd: null pointer");
+  const long M = (long)g->B * g->D * g->H * g->W;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(elementwise_blocks(M)), dim3(256), 0, (hipStream_t)stream, z, scale,
+                     shift, slope, residual, a, as_make_dev(g), M);
+  AS_CHECK_LAUNCH("as_bn_act_fwd");
+  return AS_OK;
+}
+
+static int bnb_blocks(long M) {
+  long nb = (M + 2047) / 2048;      // ~64 voxels per thread-row
+  if (nb > BNB_BLOCKS) nb = BNB_BLOCKS;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+extern "C" int64_t as_bn_bwd_workspace(const as_pcl* g) {
+  if (!as_pcl_ok(g)) return -1;
+  // fp64 slabs [blocks][64] (= 128 floats each) + 96 coefficient floats
+  return (int64_t)BNB_BLOCKS * 128 + 96 + 32;
+}
+
+extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const float* shift,
+                             const float* save_mean, const float* save_invstd, const float* gamma,
+                             float slope, int train, float* g_z, float* g_gamma, float* g_beta,
+                             float* workspace, const as_pcl* g, void* stream) {
+  AS_CHECK_ARG(as_pcl_ok(g), "as_bn_act_bwd: bad geometry");
+  AS_CHECK_ARG(g_a && z && scale && shift && save_mean && save_invstd && gamma && g_z && g_gamma && g_beta && workspace,
+               "as_bn_act_bwd: null pointer");
+  AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_bn_act_bwd: workspace must be 8-byte aligned");
+  const long M = (long)g->B * g->D * g->H * g->W;
+  const int nb = bnb_blocks(M);
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* coef = workspace + (int64_t)BNB_BLOCKS * 128;
+  hipStream_t st = (hipStream_t)stream;
+  const PclDev gd = as_make_dev(g);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g_a, z, scale, shift, save_mean, slope,
+                     partial, gd, M);
+  AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nb, M, save_invstd, gamma, train,
+                     g_gamma, g_beta, coef);
+  AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(M)), dim3(256), 0, st, g_a, z, scale, shift,
+                     save_mean, coef, slope, g_z, gd, M);
+  AS_CHECK_LAUNCH("as_bn_act_bwd(apply)");
+  return AS_OK;
+}

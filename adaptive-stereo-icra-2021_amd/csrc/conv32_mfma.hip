@@ -1,0 +1,434 @@
+// a3 (+ the 32->32 2-D convolutions of a1/a7): fp32 implicit-GEMM convolution on
+// the CDNA4 matrix cores, forward / data-gradient / weight-gradient.
+//
+// Reference semantics: nn.Conv3d(32,32,3,padding=1) inside convbn_3d
+// (adaptive_stereo/models/stereo_net.py:21-30, applied :185-186) and the
+// nn.Conv2d(32,32,3,dilation=d,padding=d) of convbn (stereo_net.py:10-18).
+//
+// Why fp32 MFMA: parity with the reference's fp32 CPU path (disparity EPE <= 1e-3,
+// arg-max indices equal) rules out bf16 inputs; gfx950 has no xf32.  The f32-input
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain at the fp32 vector peak
+// (157 TFLOP/s), so this kernel is MFMA-issue bound: 64 cycles per MFMA leave ample
+// issue slots, and operands come straight from L1/L2 with 16-byte loads — there is
+// no LDS staging because every operand float feeds exactly one MFMA lane and the
+// PCL layout already makes each lane's 16 K-values one contiguous 64-byte run.
+//
+// GEMM view (forward):  Z[v][co] = sum_{tap} sum_{ci} X[v + off(tap)][ci] * W[tap][ci][co]
+//   M = voxels (32 per wave tile, lane&31), N = 32 output channels, K = taps*32.
+//   K is ordered (tap, s, h) with ci = 16*h + s, h = lane>>5: the lane-half h of an
+//   MFMA holds k = h, so per tap a lane loads ci = 16h..16h+15 of its voxel: 4 x
+//   dwordx4.  Weights are pre-packed to [tap][h][co][s] so the B operand is likewise
+//   4 x dwordx4 per tap per lane (coalesced 4 KiB per wave, L1/L2 resident: 110 KB
+//   for 27 taps).  The zero halo of PCL supplies the padding: no predicates.
+//
+// The data gradient is the same kernel run on mirrored/transposed weights.
+// The weight gradient is a second kernel: M = ci, N = co, K = voxels.
+#include "as_common.h"
+
+struct ConvArgs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* z;
+  const float* ep_scale;
+  const float* ep_shift;
+  const float* residual;
+  float* stat_mean;
+  float* stat_m2;
+  PclDev gin, gout;
+  int M;          // B*D*H*W output voxels
+  int stride;
+  int ntaps;
+  int epilogue;
+  float slope;
+  int tap_off[AS_MAX_TAPS];   // voxel offsets in the INPUT geometry
+};
+
+__device__ inline void load16(f32x4 (&r)[4], const float* p) {
+  const f32x4* q = reinterpret_cast<const f32x4*>(p);
+  r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+}
+
+__device__ inline void mfma16(f32x16& acc, const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+  }
+}
+
+// One wave = one 32-voxel x 32-channel output tile; 4 waves per workgroup.
+__global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
+  __shared__ float red[4][32];
+  __shared__ float bmean[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, li = lane & 31;
+  const int tile = blockIdx.x * 4 + wave;
+  const int v = tile * 32 + li;
+  const bool valid = v < p.M;
+  const int vc = valid ? v : p.M - 1;
+
+  const int W = p.gout.W, H = p.gout.H, D = p.gout.D;
+  int t = vc;
+  const int x = t % W; t /= W;
+  const int y = t % H; t /= H;
+  const int d = t % D;
+  const int b = t / D;
+  const int in_vox = (int)p.gin.vox(b, d, y * p.stride, x * p.stride);
+  const int out_vox = (int)p.gout.vox(b, d, y, x);
+
+  const float* xa = p.x + (long)in_vox * 32 + h * 16;
+  const float* wb = p.wp + lane * 16;
+
+  f32x16 acc;
+  {
+    const float bv = p.bias ? p.bias[li] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+  }
+
+  f32x4 a0[4], b0[4], a1[4], b1[4];
+  const int nt = p.ntaps;
+  load16(a0, xa + (long)p.tap_off[0] * 32);
+  load16(b0, wb);
+  for (int tp = 0; tp < nt; tp += 2) {
+    const bool has1 = tp + 1 < nt;
+    if (has1) {
+      load16(a1, xa + (long)p.tap_off[tp + 1] * 32);
+      load16(b1, wb + (tp + 1) * 1024);
+    }
+    mfma16(acc, a0, b0);
+    if (has1) {
+      if (tp + 2 < nt) {
+        load16(a0, xa + (long)p.tap_off[tp + 2] * 32);
+        load16(b0, wb + (tp + 2) * 1024);
+      }
+      mfma16(acc, a1, b1);
+    }
+  }
+
+  // ---- epilogue: acc[r] = Z[voxel row(r,h)][channel li] -------------------------
+  if (p.epilogue == 1) {
+    const float sc = p.ep_scale[li], sh = p.ep_shift[li];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ov = __shfl(out_vox, row, 64);
+      const int rv = __shfl((int)valid, row, 64);
+      float yv = acc[r] * sc + sh;
+      yv = yv > 0.f ? yv : yv * p.slope;
+      if (rv) {
+        if (p.residual) yv += p.residual[(long)ov * 32 + li];
+        p.z[(long)ov * 32 + li] = yv;
+      }
+    }
+    return;
+  }
+
+  float s1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int ov = __shfl(out_vox, row, 64);
+    const int rv = __shfl((int)valid, row, 64);
+    if (rv) {
+      p.z[(long)ov * 32 + li] = acc[r];
+      s1 += acc[r];
+    }
+  }
+  if (p.stat_mean == nullptr) return;
+
+  // Per-workgroup (mean, M2) over its valid voxels, per channel: exact two-pass on
+  // the register-resident tile; merged across workgroups by as_bn_finalize (Chan).
+  const int first = blockIdx.x * 128;
+  const int nvalid = min(128, p.M - first);
+  s1 += __shfl_xor(s1, 32, 64);
+  if (h == 0) red[wave][li] = s1;
+  __syncthreads();
+  if (threadIdx.x < 32)
+    bmean[li] = (red[0][li] + red[1][li] + red[2][li] + red[3][li]) / (float)nvalid;
+  __syncthreads();
+  const float mu = bmean[li];
+  float s2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int rv = __shfl((int)valid, row, 64);
+    const float dv = acc[r] - mu;
+    if (rv) s2 += dv * dv;
+  }
+  s2 += __shfl_xor(s2, 32, 64);
+  __syncthreads();
+  if (h == 0) red[wave][li] = s2;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    p.stat_mean[blockIdx.x * 32 + li] = mu;
+    p.stat_m2[blockIdx.x * 32 + li] = red[0][li] + red[1][li] + red[2][li] + red[3][li];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Weight packing: PyTorch [O][I][taps] -> MFMA B-operand order [tap][h][j][s].
+//   forward : packed[t][h][j][s] = w[o=j][i=16h+s][t]
+//   dgrad   : packed[t][h][j][s] = w[o=16h+s][i=j][T-1-t]
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int T, int flip) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * 1024) return;
+  const int s = idx & 15, j = (idx >> 4) & 31, h = (idx >> 9) & 1, t = idx >> 10;
+  const int k = 16 * h + s;
+  float v;
+  if (!flip) v = w[((long)j * 32 + k) * T + t];
+  else       v = w[((long)k * 32 + j) * T + (T - 1 - t)];
+  packed[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------
+// Weight gradient: dW[tap][ci][co] = sum_v X[v + off(tap)][ci] * G[v][co].
+//   MFMA: i = ci (lane&31 of A), j = co (lane&31 of B), k = voxel (lane>>5 selects the
+//   even/odd voxel of a pair).  Both operands are one coalesced 256-byte wave load per
+//   MFMA.  A workgroup owns (tap group, chunk of image rows); its 4 waves take rows
+//   round-robin, reduce through LDS and write one partial slab; a second kernel sums
+//   the slabs in a fixed order (deterministic — no float atomics).
+template <int TG>
+struct WgradAcc { f32x16 a[TG]; };
+
+struct WgradArgs {
+  const float* x;
+  const float* gz;
+  float* partial;     // [nchunks][ntaps][32][32]
+  float* partial_db;  // [nchunks][32]
+  PclDev gin, gout;
+  int rows;           // B*D*H
+  int rows_per_chunk;
+  int ntaps;
+  int tap_off[AS_MAX_TAPS];
+};
+
+template <int TG>
+__global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [3 waves][TG*16 regs][64 lanes] + db
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, li = lane & 31;
+  const int group = blockIdx.x, chunk = blockIdx.y;
+  const int W = p.gout.W, H = p.gout.H, D = p.gout.D;
+  const int r0 = chunk * p.rows_per_chunk;
+  const int r1 = min(p.rows, r0 + p.rows_per_chunk);
+
+  f32x16 acc[TG];
+#pragma unroll
+  for (int g = 0; g < TG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  float bsum = 0.f;
+
+  int toff[TG];
+#pragma unroll
+  for (int g = 0; g < TG; ++g) toff[g] = p.tap_off[group * TG + g] * 32;
+
+  const int nsteps = (W + 1) >> 1;
+  for (int row = r0 + wave; row < r1; row += 4) {
+    int t = row;
+    const int y = t % H; t /= H;
+    const int d = t % D;
+    const int b = t / D;
+    const float* xr = p.x + p.gin.vox(b, d, y, 0) * 32 + li;
+    const float* gr = p.gz + p.gout.vox(b, d, y, 0) * 32 + li;
+#pragma unroll 4
+    for (int s = 0; s < nsteps; ++s) {
+      const int xc = 2 * s + h;
+      const bool ok = xc < W;
+      const int xcl = ok ? xc : W - 1;
+      float bv = gr[xcl * 32];
+      bv = ok ? bv : 0.f;
+      bsum += bv;
+      float av[TG];
+#pragma unroll
+      for (int g = 0; g < TG; ++g) av[g] = xr[xcl * 32 + toff[g]];
+#pragma unroll
+      for (int g = 0; g < TG; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g], bv, acc[g], 0, 0, 0);
+    }
+  }
+
+  // Reduce the 4 waves' accumulators through LDS (fixed order: w0 + w1 + w2 + w3).
+  float* slab = lds;                       // [3][TG*16][64]
+  float* dbs = lds + 3 * TG * 16 * 64;     // [4][32]
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) dbs[wave * 32 + li] = bsum;
+  if (wave > 0) {
+#pragma unroll
+    for (int g = 0; g < TG; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[((wave - 1) * TG * 16 + g * 16 + r) * 64 + lane] = acc[g][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {
+      const int tap = group * TG + g;
+      float* out = p.partial + ((long)chunk * p.ntaps + tap) * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[g][r];
+        v += slab[(0 * TG * 16 + g * 16 + r) * 64 + lane];
+        v += slab[(1 * TG * 16 + g * 16 + r) * 64 + lane];
+        v += slab[(2 * TG * 16 + g * 16 + r) * 64 + lane];
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[ci * 32 + li] = v;
+      }
+    }
+    if (group == 0 && h == 0)
+      p.partial_db[chunk * 32 + li] = dbs[li] + dbs[32 + li] + dbs[64 + li] + dbs[96 + li];
+  }
+}
+
+// dW[o][i][t] = sum_chunks partial[chunk][t][i][o];  db[o] = sum_chunks partial_db[chunk][o].
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
+                                    int nchunks, int T, float* __restrict__ dW, float* __restrict__ db) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = T * 1024;
+  if (idx < total) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(long)c * total + idx];
+    const int o = idx & 31, i = (idx >> 5) & 31, t = idx >> 10;
+    dW[((long)o * 32 + i) * T + t] = s;
+  } else if (db != nullptr && idx < total + 32) {
+    const int o = idx - total;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial_db[c * 32 + o];
+    db[o] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Host side
+static int fill_taps(const as_pcl* gin, const as_conv_shape* s, int* tap_off, const char* who) {
+  const int T = s->kd * s->kh * s->kw;
+  AS_CHECK_ARG(T >= 1 && T <= AS_MAX_TAPS, "%s: %d taps unsupported", who, T);
+  AS_CHECK_ARG(s->dil >= 1 && s->stride >= 1, "%s: bad dilation/stride", who);
+  const int Hp = gin->H + 2 * gin->ph, Wp = gin->W + 2 * gin->pw;
+  int n = 0;
+  for (int i = 0; i < s->kd; ++i)
+    for (int j = 0; j < s->kh; ++j)
+      for (int l = 0; l < s->kw; ++l) {
+        const int od = (s->kd > 1 ? i * s->dil : 0) - s->pad_d;
+        const int oh = j * s->dil - s->pad_h;
+        const int ow = l * s->dil - s->pad_w;
+        tap_off[n++] = (od * Hp + oh) * Wp + ow;
+      }
+  return AS_OK;
+}
+
+static int check_conv(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s, const char* who) {
+  AS_CHECK_ARG(as_pcl_ok(gin) && as_pcl_ok(gout) && s, "%s: bad geometry", who);
+  AS_CHECK_ARG(gin->B == gout->B && gin->D == gout->D, "%s: batch/depth mismatch", who);
+  // output extent of the convolution
+  const int eh = (gin->H + 2 * s->pad_h - s->dil * (s->kh - 1) - 1) / s->stride + 1;
+  const int ew = (gin->W + 2 * s->pad_w - s->dil * (s->kw - 1) - 1) / s->stride + 1;
+  AS_CHECK_ARG(eh == gout->H && ew == gout->W, "%s: output extent %dx%d != conv result %dx%d", who,
+               gout->H, gout->W, eh, ew);
+  if (s->kd > 1)
+    AS_CHECK_ARG(gin->D + 2 * s->pad_d - s->dil * (s->kd - 1) == gout->D, "%s: depth extent mismatch", who);
+  // every tap of every output must land inside the input's halo
+  const int reach_h_lo = s->pad_h, reach_w_lo = s->pad_w;
+  const int reach_h_hi = (gout->H - 1) * s->stride + s->dil * (s->kh - 1) - s->pad_h - (gin->H - 1);
+  const int reach_w_hi = (gout->W - 1) * s->stride + s->dil * (s->kw - 1) - s->pad_w - (gin->W - 1);
+  AS_CHECK_ARG(reach_h_lo <= gin->ph && reach_w_lo <= gin->pw && reach_h_hi <= gin->ph && reach_w_hi <= gin->pw,
+               "%s: input halo (%d,%d) too small for padding", who, gin->ph, gin->pw);
+  if (s->kd > 1) AS_CHECK_ARG(s->pad_d <= gin->pd && s->dil * (s->kd - 1) - s->pad_d <= gin->pd,
+                              "%s: input depth halo too small", who);
+  return AS_OK;
+}
+
+extern "C" int as_conv32_pack_weights(const float* w, float* packed, const as_conv_shape* s,
+                                      int transpose_flip, void* stream) {
+  AS_CHECK_ARG(w && packed && s, "as_conv32_pack_weights: null pointer");
+  const int T = s->kd * s->kh * s->kw;
+  AS_CHECK_ARG(T >= 1 && T <= AS_MAX_TAPS, "as_conv32_pack_weights: %d taps unsupported", T);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(as_div_up(T * 1024, 256)), dim3(256), 0, (hipStream_t)stream,
+                     w, packed, T, transpose_flip);
+  AS_CHECK_LAUNCH("as_conv32_pack_weights");
+  return AS_OK;
+}
+
+extern "C" int as_conv32_num_blocks(const as_pcl* gout) {
+  if (!as_pcl_ok(gout)) return AS_ERR_ARG;
+  const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;
+  return as_div_up(M, 128);
+}
+
+extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, const float* bias,
+                             float* z, const as_pcl* gout, const as_conv_shape* s,
+                             int epilogue, const float* ep_scale, const float* ep_shift, float slope,
+                             const float* residual, float* stat_mean, float* stat_m2, void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_fwd")) return e;
+  AS_CHECK_ARG(x && packed_w && z, "as_conv32_fwd: null pointer");
+  AS_CHECK_ARG(epilogue == 0 || (epilogue == 1 && ep_scale && ep_shift), "as_conv32_fwd: bad epilogue");
+  AS_CHECK_ARG((stat_mean == nullptr) == (stat_m2 == nullptr), "as_conv32_fwd: stat pointers must come in pairs");
+  ConvArgs a;
+  a.x = x; a.wp = packed_w; a.bias = bias; a.z = z;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual;
+  a.stat_mean = epilogue == 0 ? stat_mean : nullptr; a.stat_m2 = epilogue == 0 ? stat_m2 : nullptr;
+  a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
+  const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;
+  a.M = (int)M; a.stride = s->stride; a.ntaps = s->kd * s->kh * s->kw;
+  a.epilogue = epilogue; a.slope = slope;
+  if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_fwd")) return e;
+  hipLaunchKernelGGL(conv32_fwd_kernel, dim3(as_div_up(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  AS_CHECK_LAUNCH("as_conv32_fwd");
+  return AS_OK;
+}
+
+static int wgrad_plan(const as_pcl* gout, const as_conv_shape* s, int* tg, int* rows_per_chunk, int* nchunks) {
+  const int T = s->kd * s->kh * s->kw;
+  *tg = (T % 3 == 0) ? 3 : (T % 5 == 0 ? 5 : 1);
+  const int rows = gout->B * gout->D * gout->H;
+  // aim at ~4 waves per SIMD over the chip (256 CUs x 4 SIMDs), at least 4 rows (one per
+  // wave) per chunk, and cap the slab count so the partial buffer stays a few MB.
+  const int groups = T / *tg;
+  int want_chunks = (4096 + groups * 4 - 1) / (groups * 4);
+  if (want_chunks > 512) want_chunks = 512;
+  int rpc = (rows + want_chunks - 1) / want_chunks;
+  if (rpc < 4) rpc = 4;
+  *rows_per_chunk = rpc;
+  *nchunks = (rows + rpc - 1) / rpc;
+  return T;
+}
+
+extern "C" int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return -1;
+  int tg, rpc, nchunks;
+  const int T = wgrad_plan(gout, s, &tg, &rpc, &nchunks);
+  return (int64_t)nchunks * T * 1024 + (int64_t)nchunks * 32;
+}
+
+template <int TG>
+static void launch_wgrad(const WgradArgs& a, int groups, int nchunks, hipStream_t st) {
+  const size_t lds = (size_t)(3 * TG * 16 * 64 + 4 * 32) * sizeof(float);
+  hipLaunchKernelGGL(conv32_wgrad_kernel<TG>, dim3(groups, nchunks), dim3(256), lds, st, a);
+}
+
+extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
+                               const as_conv_shape* s, float* dW, float* db, float* workspace, void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_wgrad")) return e;
+  AS_CHECK_ARG(x && gz && dW && workspace, "as_conv32_wgrad: null pointer");
+  AS_CHECK_ARG(s->stride == 1, "as_conv32_wgrad: stride must be 1");
+  int tg, rpc, nchunks;
+  const int T = wgrad_plan(gout, s, &tg, &rpc, &nchunks);
+  WgradArgs a;
+  a.x = x; a.gz = gz; a.partial = workspace; a.partial_db = workspace + (int64_t)nchunks * T * 1024;
+  a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
+  a.rows = gout->B * gout->D * gout->H; a.rows_per_chunk = rpc; a.ntaps = T;
+  if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_wgrad")) return e;
+  hipStream_t st = (hipStream_t)stream;
+  if (tg == 3) launch_wgrad<3>(a, T / 3, nchunks, st);
+  else if (tg == 5) launch_wgrad<5>(a, T / 5, nchunks, st);
+  else launch_wgrad<1>(a, T, nchunks, st);
+  AS_CHECK_LAUNCH("as_conv32_wgrad");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 256)), dim3(256), 0, st,
+                     a.partial, a.partial_db, nchunks, T, dW, db);
+  AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
+  return AS_OK;
+}

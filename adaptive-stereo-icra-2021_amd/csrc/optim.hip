@@ -1,0 +1,93 @@
+// a12: global-norm clip + Adam over one flat fp32 arena, and library bookkeeping.
+// Reference semantics: nn.utils.clip_grad_norm_(stereo_net.parameters(), 1.0) followed by
+// torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step() — adapt.py:208-210, 391-393.
+// The reference issues one small kernel per parameter tensor per Adam sub-step (~100
+// tensors x ~6 ops).  Here parameters, gradients and both moments live at equal offsets
+// of flat arenas (the same flat gradient arena is the RCCL all-reduce bucket), so the whole
+// update is one sum-of-squares reduction and one element-wise pass.  HBM-bound, 1.7 MB.
+#include "as_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void as_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* as_last_error(void) { return g_err; }
+extern "C" int as_version(void) { return 1; }
+
+extern "C" int64_t as_pcl_numel(const as_pcl* g) {
+  if (!g) return -1;
+  return (int64_t)g->B * (g->D + 2 * g->pd) * (g->H + 2 * g->ph) * (g->W + 2 * g->pw) * 32;
+}
+
+#define SS_BLOCKS 256
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double v = (double)g[i];
+    s += v * v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += partial[i];
+  out[0] = (float)s;
+}
+
+extern "C" int64_t as_sumsq_workspace(int64_t n) { return n > 0 ? 2 * SS_BLOCKS : -1; }
+
+extern "C" int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream) {
+  AS_CHECK_ARG(g && out && workspace && n > 0, "as_sumsq: bad argument");
+  AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_sumsq: workspace must be 8-byte aligned");
+  long nb = (n + 255) / 256;
+  if (nb > SS_BLOCKS) nb = SS_BLOCKS;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, partial);
+  AS_CHECK_LAUNCH("as_sumsq");
+  hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)nb, out);
+  AS_CHECK_LAUNCH("as_sumsq(finalize)");
+  return AS_OK;
+}
+
+// torch.optim.Adam (single-tensor path): m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g;
+// denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n,
+                                                    const float* __restrict__ grad_scale, float lr, float b1, float b2,
+                                                    float eps, float bc1, float bc2_sqrt) {
+  const float gs = grad_scale ? grad_scale[0] : 1.f;
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                            const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
+                            int step, void* stream) {
+  AS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "as_adam_step: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                     (long)n, grad_scale_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+  AS_CHECK_LAUNCH("as_adam_step");
+  return AS_OK;
+}

@@ -1,0 +1,336 @@
+// a10: monodepth photometric loss (SSIM + L1 + edge-aware smoothness), forward and
+// hand-written backward, plus the masked mean of adapt.py:81-83.
+// Reference semantics: adaptive_stereo/utils/loss_functions.py:41-72 (SSIM, 3x3
+// avg_pool2d stride 1 pad 1, zero padding counted), :75-103 (smoothness), :106-138
+// (0.85*SSIM + 0.15*L1 + w*smooth; disparity normalised by its per-image mean + 1e-7).
+//
+// Forward is one full-resolution stencil pass (plus a per-image mean reduction);
+// backward is two passes: (A) per window-centre partial derivatives w.r.t. the pooled
+// moments, (B) a 3x3 gather of those onto each warped pixel.  All HBM/L2-bound.
+// fp contraction is disabled in this file so sigma = E[x^2] - mu^2 rounds the way the
+// reference's separate ATen multiply / subtract do (the subtraction cancels ~2 digits).
+#include "as_common.h"
+#pragma clang fp contract(off)
+
+#define PH_BLOCKS_PER_IMAGE 128
+
+// ---- deterministic per-image reductions --------------------------------------------------
+// partial[b][blk] (fp64) then a fixed-order finalize.
+__global__ __launch_bounds__(256) void image_sum_kernel(const float* __restrict__ v, long n_per_image,
+                                                         double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int b = blockIdx.y;
+  const float* p = v + (long)b * n_per_image;
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_per_image; i += (long)gridDim.x * 256) s += (double)p[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[b] = sum_blk partial[b][blk] * mul
+__global__ void image_sum_finalize_kernel(const double* __restrict__ partial, int nblk, int B, double mul,
+                                          float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += partial[(long)b * nblk + i];
+  out[b] = (float)(s * mul);
+}
+
+// ---- shared per-pixel SSIM arithmetic --------------------------------------------------------
+struct SsimTerms { float mux, muy, A1, A2, B1, B2, n, d, raw; };
+
+__device__ inline SsimTerms ssim_at(const float* __restrict__ X, const float* __restrict__ Y, int y, int x, int H, int W) {
+  float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= W) continue;
+      const float a = X[(long)yy * W + xx], b = Y[(long)yy * W + xx];
+      sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+    }
+  }
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  SsimTerms t;
+  t.mux = sx / 9.f; t.muy = sy / 9.f;
+  const float sigx = sxx / 9.f - t.mux * t.mux;
+  const float sigy = syy / 9.f - t.muy * t.muy;
+  const float sigxy = sxy / 9.f - t.mux * t.muy;
+  t.A1 = 2.f * t.mux * t.muy + C1;
+  t.A2 = 2.f * sigxy + C2;
+  t.B1 = t.mux * t.mux + t.muy * t.muy + C1;
+  t.B2 = sigx + sigy + C2;
+  t.n = t.A1 * t.A2;
+  t.d = t.B1 * t.B2;
+  t.raw = (1.f - t.n / t.d) / 2.f;
+  return t;
+}
+
+__device__ inline float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// edge weights exp(-mean_c |I(p) - I(p+e)|)
+__device__ inline float edge_wx(const float* __restrict__ img, long plane, int y, int x, int W) {
+  const long o = (long)y * W + x;
+  const float m = (fabsf(img[o] - img[o + 1]) + fabsf(img[plane + o] - img[plane + o + 1]) +
+                   fabsf(img[2 * plane + o] - img[2 * plane + o + 1])) / 3.f;
+  return expf(-m);
+}
+__device__ inline float edge_wy(const float* __restrict__ img, long plane, int y, int x, int W) {
+  const long o = (long)y * W + x;
+  const float m = (fabsf(img[o] - img[o + W]) + fabsf(img[plane + o] - img[plane + o + W]) +
+                   fabsf(img[2 * plane + o] - img[2 * plane + o + W])) / 3.f;
+  return expf(-m);
+}
+
+// ---- forward -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void monodepth_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ img,
+                                                             const float* __restrict__ warped, const float* __restrict__ mean_disp,
+                                                             int B, int H, int W, float sw,
+                                                             float* __restrict__ total, float* __restrict__ l1,
+                                                             float* __restrict__ ssim, float* __restrict__ smooth) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long plane = (long)H * W;
+  if (i >= (long)B * plane) return;
+  const int x = i % W, y = (i / W) % H, b = i / plane;
+  const float* I = img + (long)b * 3 * plane;
+  const float* Wp = warped + (long)b * 3 * plane;
+  float s_acc = 0.f, l_acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const SsimTerms t = ssim_at(I + c * plane, Wp + c * plane, y, x, H, W);
+    s_acc += fminf(fmaxf(t.raw, 0.f), 1.f);
+    l_acc += fabsf(I[c * plane + (long)y * W + x] - Wp[c * plane + (long)y * W + x]);
+  }
+  const float ps = s_acc / 3.f, pl = l_acc / 3.f;
+  const float den = mean_disp[b] + 1e-7f;
+  const float* P = pred + (long)b * plane;
+  const float nd = P[(long)y * W + x] / den;
+  float sm = 0.f;
+  if (x < W - 1) sm += fabsf(nd - P[(long)y * W + x + 1] / den) * edge_wx(I, plane, y, x, W);
+  if (y < H - 1) sm += fabsf(nd - P[(long)(y + 1) * W + x] / den) * edge_wy(I, plane, y, x, W);
+  const float photo = 0.85f * ps + 0.15f * pl;
+  if (total) total[i] = photo + sw * sm;
+  if (l1) l1[i] = pl;
+  if (ssim) ssim[i] = ps;
+  if (smooth) smooth[i] = sm;
+}
+
+// ---- backward pass A: per-centre SSIM coefficients, g_nd, and partial sums of g_nd*pred -------------
+// coef layout: [B][10][H][W]: (a,b,c) x 3 channels, then g_nd.
+__global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
+    const float* __restrict__ g_total, const float* __restrict__ g_ssim, const float* __restrict__ g_smooth,
+    const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ warped,
+    const float* __restrict__ mean_disp, int B, int H, int W, float sw,
+    float* __restrict__ coef, double* __restrict__ partial) {
+  __shared__ double red[4];
+  const long plane = (long)H * W;
+  const int b = blockIdx.y;
+  const float* I = img + (long)b * 3 * plane;
+  const float* Wp = warped + (long)b * 3 * plane;
+  const float* P = pred + (long)b * plane;
+  const float den = mean_disp[b] + 1e-7f;
+  double s_local = 0.0;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < plane; o += (long)gridDim.x * 256) {
+    const int x = o % W, y = o / W;
+    const long gi = (long)b * plane + o;
+    const float gt = g_total ? g_total[gi] : 0.f;
+    const float G_ssim = 0.85f * gt + (g_ssim ? g_ssim[gi] : 0.f);
+    float* cf = coef + (long)b * 10 * plane + o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const SsimTerms t = ssim_at(I + c * plane, Wp + c * plane, y, x, H, W);
+      const float pass = (t.raw >= 0.f && t.raw <= 1.f) ? 1.f : 0.f;
+      const float Gq = (G_ssim / 3.f) * (-0.5f) * pass;
+      const float d2 = t.d * t.d;
+      cf[(3 * c + 0) * plane] = Gq * ((2.f * t.mux * (t.A2 - t.A1)) * t.d - t.n * (2.f * t.muy * (t.B2 - t.B1))) / d2;
+      cf[(3 * c + 1) * plane] = Gq * (-(t.n * t.B1)) / d2;
+      cf[(3 * c + 2) * plane] = Gq * (2.f * t.A1) / t.d;
+    }
+    // smoothness: derivative w.r.t. the normalised disparity at this pixel
+    const float nd = P[o] / den;
+    float g_nd = 0.f;
+    if (x < W - 1) {
+      const float Gs = sw * gt + (g_smooth ? g_smooth[gi] : 0.f);
+      g_nd += Gs * edge_wx(I, plane, y, x, W) * sgn(nd - P[o + 1] / den);
+    }
+    if (x > 0) {
+      const float gtl = g_total ? g_total[gi - 1] : 0.f;
+      const float Gs = sw * gtl + (g_smooth ? g_smooth[gi - 1] : 0.f);
+      g_nd -= Gs * edge_wx(I, plane, y, x - 1, W) * sgn(P[o - 1] / den - nd);
+    }
+    if (y < H - 1) {
+      const float Gs = sw * gt + (g_smooth ? g_smooth[gi] : 0.f);
+      g_nd += Gs * edge_wy(I, plane, y, x, W) * sgn(nd - P[o + W] / den);
+    }
+    if (y > 0) {
+      const float gtu = g_total ? g_total[gi - W] : 0.f;
+      const float Gs = sw * gtu + (g_smooth ? g_smooth[gi - W] : 0.f);
+      g_nd -= Gs * edge_wy(I, plane, y - 1, x, W) * sgn(P[o - W] / den - nd);
+    }
+    cf[9 * plane] = g_nd;
+    s_local += (double)g_nd * (double)P[o];
+  }
+  s_local = wave_sum_d(s_local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s_local;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(long)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---- backward pass B: gather ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void monodepth_bwd_b_kernel(
+    const float* __restrict__ g_total, const float* __restrict__ g_l1,
+    const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ warped,
+    const float* __restrict__ mean_disp, const float* __restrict__ coef, const float* __restrict__ sum_gnd_pred,
+    int B, int H, int W, float* __restrict__ g_pred, float* __restrict__ g_warped) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long plane = (long)H * W;
+  if (i >= (long)B * plane) return;
+  const int x = i % W, y = (i / W) % H, b = i / plane;
+  const long o = (long)y * W + x;
+  const float* I = img + (long)b * 3 * plane;
+  const float* Wp = warped + (long)b * 3 * plane;
+  const float* cf = coef + (long)b * 10 * plane;
+  const float gt = g_total ? g_total[i] : 0.f;
+  const float G_l1 = 0.15f * gt + (g_l1 ? g_l1[i] : 0.f);
+  if (g_warped) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float xv = I[c * plane + o], yv = Wp[c * plane + o];
+      float sa = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = x + dx;
+          if (xx < 0 || xx >= W) continue;
+          const long q = (long)yy * W + xx;
+          sa += cf[(3 * c + 0) * plane + q];
+          sb += cf[(3 * c + 1) * plane + q];
+          sc += cf[(3 * c + 2) * plane + q];
+        }
+      }
+      float g = (sa + 2.f * sb * yv + sc * xv) / 9.f;
+      g += (G_l1 / 3.f) * (-sgn(xv - yv));
+      g_warped[((long)b * 3 + c) * plane + o] = g;
+    }
+  }
+  if (g_pred) {
+    const float den = mean_disp[b] + 1e-7f;
+    const float r = 1.f / den;
+    // d/d pred of pred/(mean+eps): direct term plus the term through the mean
+    g_pred[i] = cf[9 * plane + o] * r - (sum_gnd_pred[b] * r * r) / (float)plane;
+  }
+}
+
+// ---- masked sum ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_sum_kernel(const float* __restrict__ v, const uint8_t* __restrict__ m,
+                                                          long n, double* __restrict__ partial) {
+  __shared__ double red[2][4];
+  double s = 0.0, c = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (m[i]) { s += (double)v[i]; c += 1.0; }
+  }
+  s = wave_sum_d(s); c = wave_sum_d(c);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ void masked_sum_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0, c = 0.0;
+  for (int i = 0; i < nblk; ++i) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+  out2[0] = (float)s; out2[1] = (float)c;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------
+extern "C" int64_t as_monodepth_workspace(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return -1;
+  // [mean B | sum B | pad to 16] + fp64 partials [B][PH_BLOCKS] + coef [B][10][H][W]
+  return 64 + 2 * (int64_t)((B + 15) / 16 * 16) + 2 * (int64_t)B * PH_BLOCKS_PER_IMAGE + (int64_t)B * 10 * H * W;
+}
+
+struct PhWs { float* mean; float* sum; double* partial; float* coef; };
+static PhWs carve(float* ws, int B) {
+  PhWs w;
+  const int Bp = (B + 15) / 16 * 16;
+  w.mean = ws; w.sum = ws + Bp;
+  w.partial = reinterpret_cast<double*>(ws + 2 * Bp);
+  w.coef = ws + 2 * Bp + 2 * (int64_t)B * PH_BLOCKS_PER_IMAGE;
+  return w;
+}
+
+static int image_mean(const float* pred, int B, long plane, PhWs& w, hipStream_t st) {
+  hipLaunchKernelGGL(image_sum_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, pred, plane, w.partial);
+  AS_CHECK_LAUNCH("monodepth(mean)");
+  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(as_div_up(B, 64)), dim3(64), 0, st, w.partial,
+                     PH_BLOCKS_PER_IMAGE, B, 1.0 / (double)plane, w.mean);
+  AS_CHECK_LAUNCH("monodepth(mean finalize)");
+  return AS_OK;
+}
+
+extern "C" int as_monodepth_loss_fwd(const float* pred, const float* img, const float* warped, int B, int H, int W,
+                                     float smoothness_weight, float* total, float* l1, float* ssim, float* smooth,
+                                     float* workspace, void* stream) {
+  AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535,
+               "as_monodepth_loss_fwd: bad argument");
+  AS_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "as_monodepth_loss_fwd: workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  PhWs w = carve(workspace, B);
+  const long plane = (long)H * W;
+  if (int e = image_mean(pred, B, plane, w, st)) return e;
+  hipLaunchKernelGGL(monodepth_fwd_kernel, dim3(as_div_up((long)B * plane, 256)), dim3(256), 0, st, pred, img, warped,
+                     w.mean, B, H, W, smoothness_weight, total, l1, ssim, smooth);
+  AS_CHECK_LAUNCH("as_monodepth_loss_fwd");
+  return AS_OK;
+}
+
+extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
+                                     const float* pred, const float* img, const float* warped, int B, int H, int W,
+                                     float smoothness_weight, float* g_pred, float* g_warped,
+                                     float* workspace, void* stream) {
+  AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535,
+               "as_monodepth_loss_bwd: bad argument");
+  AS_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "as_monodepth_loss_bwd: workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  PhWs w = carve(workspace, B);
+  const long plane = (long)H * W;
+  if (int e = image_mean(pred, B, plane, w, st)) return e;
+  hipLaunchKernelGGL(monodepth_bwd_a_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, g_total, g_ssim, g_smooth,
+                     pred, img, warped, w.mean, B, H, W, smoothness_weight, w.coef, w.partial);
+  AS_CHECK_LAUNCH("as_monodepth_loss_bwd(A)");
+  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(as_div_up(B, 64)), dim3(64), 0, st, w.partial,
+                     PH_BLOCKS_PER_IMAGE, B, 1.0, w.sum);
+  AS_CHECK_LAUNCH("as_monodepth_loss_bwd(sum)");
+  hipLaunchKernelGGL(monodepth_bwd_b_kernel, dim3(as_div_up((long)B * plane, 256)), dim3(256), 0, st, g_total, g_l1,
+                     pred, img, warped, w.mean, w.coef, w.sum, B, H, W, g_pred, g_warped);
+  AS_CHECK_LAUNCH("as_monodepth_loss_bwd(B)");
+  return AS_OK;
+}
+
+#define MS_BLOCKS 512
+extern "C" int64_t as_masked_sum_workspace(int64_t n) { return n > 0 ? 4 * MS_BLOCKS : -1; }
+
+extern "C" int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream) {
+  AS_CHECK_ARG(v && mask && out2 && workspace && n > 0, "as_masked_sum: bad argument");
+  AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_masked_sum: workspace must be 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  long nb = (n + 255) / 256;
+  if (nb > MS_BLOCKS) nb = MS_BLOCKS;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(masked_sum_kernel, dim3((int)nb), dim3(256), 0, st, v, mask, (long)n, partial);
+  AS_CHECK_LAUNCH("as_masked_sum");
+  hipLaunchKernelGGL(masked_sum_finalize_kernel, dim3(1), dim3(64), 0, st, partial, (int)nb, out2);
+  AS_CHECK_LAUNCH("as_masked_sum(finalize)");
+  return AS_OK;
+}

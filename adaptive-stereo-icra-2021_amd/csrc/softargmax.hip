@@ -1,0 +1,286 @@
+// a4 + a5 + a8: 32->1 3-D convolution to logits, soft-argmax disparity regression,
+// arg-max index and feature-contrast score.
+// Reference semantics:
+//   conv3d_alone = nn.Conv3d(32,1,3,padding=1)        stereo_net.py:162,187
+//   softmax(+cost, dim=1); sum_d d*p_d                 stereo_net.py:190-192,124-134
+//   FCS = sorted[0] - mean(sorted[2:]) over d          utils/feature_contrast.py:12-23
+//
+// The 32->1 convolution has N=1: a matrix-core tile would waste 31/32 of the MFMA, so it
+// is a bandwidth kernel: 8 lanes share a voxel (float4 of channels each: one 128-byte
+// line per voxel per tap, fully coalesced), 27 taps from the zero-haloed PCL input, then
+// a 3-step wavefront-shuffle (xor 1,2,4) reduction across the 8 lanes.
+// Soft-argmax keeps one pixel per lane (d-strided, W-coalesced reads of the logits);
+// Dc is 8..24, so the per-pixel reduction over d is a short in-register loop.
+#include "as_common.h"
+
+struct OutConvArgs {
+  const float* a;
+  const float* w;      // [32][27] PyTorch order
+  const float* bias;   // [1]
+  float* logits;       // [B][D][H][W]
+  PclDev g;
+  long M;
+  int tap_off[27];
+};
+
+__global__ __launch_bounds__(256) void conv3d_out_fwd_kernel(OutConvArgs p) {
+  __shared__ float sw[27 * 32];
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+    const int t = i >> 5, c = i & 31;
+    sw[i] = p.w[c * 27 + t];
+  }
+  __syncthreads();
+  const int c4 = threadIdx.x & 7;
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  const long stride = (long)gridDim.x * 32;
+  const long Mr = (p.M + 31) & ~31L;      // keep the 8-lane groups converged for the shuffles
+  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < Mr; v += stride) {
+    const bool valid = v < p.M;
+    long t = valid ? v : p.M - 1;
+    const int x = t % p.g.W; t /= p.g.W;
+    const int y = t % p.g.H; t /= p.g.H;
+    const int d = t % p.g.D;
+    const int b = t / p.g.D;
+    const float* base = p.a + p.g.vox(b, d, y, x) * 32 + c4 * 4;
+    float acc = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(base + (long)p.tap_off[tp] * 32);
+      const float* ww = sw + tp * 32 + c4 * 4;
+      acc += q.x * ww[0] + q.y * ww[1] + q.z * ww[2] + q.w * ww[3];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (valid && c4 == 0) p.logits[v] = acc + bias;
+  }
+}
+
+// g_a[v][c] = sum_t g_logits[v - off(t)] * w[c][t]   (only where v - off(t) is a real voxel)
+struct OutConvBwdArgs {
+  const float* g_logits;
+  const float* a;
+  const float* w;
+  float* g_a;
+  float* partial;   // [blocks][27*32 + 1]
+  PclDev g;
+  long M;
+  int tap_off[27];
+};
+
+__global__ __launch_bounds__(256) void conv3d_out_dgrad_kernel(OutConvBwdArgs p) {
+  __shared__ float sw[27 * 32];
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+    const int t = i >> 5, c = i & 31;
+    sw[i] = p.w[c * 27 + t];
+  }
+  __syncthreads();
+  const int c4 = threadIdx.x & 7;
+  const int D = p.g.D, H = p.g.H, W = p.g.W;
+  const long stride = (long)gridDim.x * 32;
+  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < p.M; v += stride) {
+    long t = v;
+    const int x = t % W; t /= W;
+    const int y = t % H; t /= H;
+    const int d = t % D;
+    const int b = t / D;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          // output voxel u with u + (kd-1,kh-1,kw-1) = v
+          const int ud = d - (kd - 1), uy = y - (kh - 1), ux = x - (kw - 1);
+          if (ud < 0 || ud >= D || uy < 0 || uy >= H || ux < 0 || ux >= W) continue;
+          const float gl = p.g_logits[(((long)b * D + ud) * H + uy) * W + ux];
+          const float* ww = sw + ((kd * 3 + kh) * 3 + kw) * 32 + c4 * 4;
+          acc.x += gl * ww[0]; acc.y += gl * ww[1]; acc.z += gl * ww[2]; acc.w += gl * ww[3];
+        }
+    *reinterpret_cast<f32x4*>(p.g_a + p.g.vox(b, d, y, x) * 32 + c4 * 4) = acc;
+  }
+}
+
+// g_w[c][t] = sum_v g_logits[v] * a[v + off(t)][c];  g_bias = sum_v g_logits[v].
+__global__ __launch_bounds__(256) void conv3d_out_wgrad_kernel(OutConvBwdArgs p) {
+  __shared__ float red[32][33];
+  const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
+  f32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float gsum = 0.f;
+  const long stride = (long)gridDim.x * 32;
+  for (long v = (long)blockIdx.x * 32 + vl; v < p.M; v += stride) {
+    long t = v;
+    const int x = t % p.g.W; t /= p.g.W;
+    const int y = t % p.g.H; t /= p.g.H;
+    const int d = t % p.g.D;
+    const int b = t / p.g.D;
+    const float gl = p.g_logits[v];
+    gsum += gl;
+    const float* base = p.a + p.g.vox(b, d, y, x) * 32 + c4 * 4;
+#pragma unroll
+    for (int tp = 0; tp < 27; ++tp)
+      acc[tp] += gl * *reinterpret_cast<const f32x4*>(base + (long)p.tap_off[tp] * 32);
+  }
+  float* out = p.partial + (long)blockIdx.x * (27 * 32 + 1);
+  for (int tp = 0; tp < 27; ++tp) {
+    __syncthreads();
+    red[vl][c4 * 4 + 0] = acc[tp].x; red[vl][c4 * 4 + 1] = acc[tp].y;
+    red[vl][c4 * 4 + 2] = acc[tp].z; red[vl][c4 * 4 + 3] = acc[tp].w;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += red[j][threadIdx.x];
+      out[tp * 32 + threadIdx.x] = s;
+    }
+  }
+  __syncthreads();
+  if (c4 == 0) red[vl][0] = gsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < 32; ++j) s += red[j][0];
+    out[27 * 32] = s;
+  }
+}
+
+__global__ void conv3d_out_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks,
+                                               float* __restrict__ g_w, float* __restrict__ g_bias) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx > 27 * 32) return;
+  double s = 0.0;
+  for (int i = 0; i < nblocks; ++i) s += (double)partial[(long)i * (27 * 32 + 1) + idx];
+  if (idx == 27 * 32) { if (g_bias) g_bias[0] = (float)s; }
+  else { const int t = idx >> 5, c = idx & 31; g_w[c * 27 + t] = (float)s; }
+}
+
+// ---- soft-argmax ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softargmax_fwd_kernel(const float* __restrict__ logits, int B, int D, long HW,
+                                                              float* __restrict__ pred, int32_t* __restrict__ argmax,
+                                                              float* __restrict__ fcs) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  const long b = i / HW, pix = i % HW;
+  const float* l = logits + b * D * HW + pix;
+  float m1 = -INFINITY, m2 = -INFINITY, sum = 0.f;
+  int am = 0;
+  for (int d = 0; d < D; ++d) {
+    const float v = l[d * HW];
+    sum += v;
+    if (v > m1) { m2 = m1; m1 = v; am = d; }
+    else if (v > m2) { m2 = v; }
+  }
+  float se = 0.f;
+  for (int d = 0; d < D; ++d) se += expf(l[d * HW] - m1);
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) acc += (expf(l[d * HW] - m1) / se) * (float)d;
+  pred[i] = acc;
+  if (argmax) argmax[i] = am;
+  if (fcs) fcs[i] = (D > 2) ? m1 - (sum - m1 - m2) / (float)(D - 2) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void softargmax_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ g_pred,
+                                                              const float* __restrict__ g_in, int B, int D, long HW,
+                                                              float* __restrict__ g_logits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  const long b = i / HW, pix = i % HW;
+  const float* l = logits + b * D * HW + pix;
+  float m1 = -INFINITY;
+  for (int d = 0; d < D; ++d) m1 = fmaxf(m1, l[d * HW]);
+  float se = 0.f;
+  for (int d = 0; d < D; ++d) se += expf(l[d * HW] - m1);
+  float pr = 0.f;
+  for (int d = 0; d < D; ++d) pr += (expf(l[d * HW] - m1) / se) * (float)d;
+  const float gp = g_pred ? g_pred[i] : 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float pd = expf(l[d * HW] - m1) / se;
+    float gv = pd * ((float)d - pr) * gp;
+    if (g_in) gv += g_in[b * D * HW + d * HW + pix];
+    g_logits[b * D * HW + d * HW + pix] = gv;
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------
+static void fill27(const as_pcl* g, int* off) {
+  const int Hp = g->H + 2 * g->ph, Wp = g->W + 2 * g->pw;
+  int n = 0;
+  for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) for (int l = -1; l <= 1; ++l)
+    off[n++] = (i * Hp + j) * Wp + l;
+}
+
+static int check_out(const as_pcl* g, const char* who) {
+  AS_CHECK_ARG(as_pcl_ok(g), "%s: bad geometry", who);
+  AS_CHECK_ARG(g->pd >= 1 && g->ph >= 1 && g->pw >= 1, "%s: needs a halo of 1", who);
+  return AS_OK;
+}
+
+static inline int out_blocks(long M) {
+  long nb = (M + 31) / 32;
+  if (nb > 2048) nb = 2048;
+  return (int)nb;
+}
+#define OUTW_BLOCKS 256
+
+extern "C" int as_conv3d_out_fwd(const float* a, const as_pcl* g, const float* w, const float* bias,
+                                 float* logits, void* stream) {
+  if (int e = check_out(g, "as_conv3d_out_fwd")) return e;
+  AS_CHECK_ARG(a && w && logits, "as_conv3d_out_fwd: null pointer");
+  OutConvArgs p;
+  p.a = a; p.w = w; p.bias = bias; p.logits = logits; p.g = as_make_dev(g);
+  p.M = (long)g->B * g->D * g->H * g->W;
+  fill27(g, p.tap_off);
+  hipLaunchKernelGGL(conv3d_out_fwd_kernel, dim3(out_blocks(p.M)), dim3(256), 0, (hipStream_t)stream, p);
+  AS_CHECK_LAUNCH("as_conv3d_out_fwd");
+  return AS_OK;
+}
+
+extern "C" int64_t as_conv3d_out_bwd_workspace(const as_pcl* g) {
+  if (!as_pcl_ok(g)) return -1;
+  return (int64_t)OUTW_BLOCKS * (27 * 32 + 1);
+}
+
+extern "C" int as_conv3d_out_bwd(const float* g_logits, const float* a, const as_pcl* g, const float* w,
+                                 float* g_a, float* g_w, float* g_bias, float* workspace, void* stream) {
+  if (int e = check_out(g, "as_conv3d_out_bwd")) return e;
+  AS_CHECK_ARG(g_logits && a && w && g_a && g_w && workspace, "as_conv3d_out_bwd: null pointer");
+  OutConvBwdArgs p;
+  p.g_logits = g_logits; p.a = a; p.w = w; p.g_a = g_a; p.partial = workspace; p.g = as_make_dev(g);
+  p.M = (long)g->B * g->D * g->H * g->W;
+  fill27(g, p.tap_off);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3d_out_dgrad_kernel, dim3(out_blocks(p.M)), dim3(256), 0, st, p);
+  AS_CHECK_LAUNCH("as_conv3d_out_bwd(dgrad)");
+  long nb = (p.M + 31) / 32;
+  if (nb > OUTW_BLOCKS) nb = OUTW_BLOCKS;
+  hipLaunchKernelGGL(conv3d_out_wgrad_kernel, dim3((int)nb), dim3(256), 0, st, p);
+  AS_CHECK_LAUNCH("as_conv3d_out_bwd(wgrad)");
+  hipLaunchKernelGGL(conv3d_out_wgrad_reduce_kernel, dim3(as_div_up(27 * 32 + 1, 256)), dim3(256), 0, st,
+                     workspace, (int)nb, g_w, g_bias);
+  AS_CHECK_LAUNCH("as_conv3d_out_bwd(reduce)");
+  return AS_OK;
+}
+
+extern "C" int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,
+                                 float* pred, int32_t* argmax, float* fcs, void* stream) {
+  AS_CHECK_ARG(logits && pred, "as_softargmax_fwd: null pointer");
+  AS_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "as_softargmax_fwd: bad shape");
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(softargmax_fwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     logits, B, D, (long)H * W, pred, argmax, fcs);
+  AS_CHECK_LAUNCH("as_softargmax_fwd");
+  return AS_OK;
+}
+
+extern "C" int as_softargmax_bwd(const float* logits, const float* g_pred, const float* g_logits_in,
+                                 int B, int D, int H, int W, float* g_logits, void* stream) {
+  AS_CHECK_ARG(logits && g_logits, "as_softargmax_bwd: null pointer");
+  AS_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "as_softargmax_bwd: bad shape");
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(softargmax_bwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     logits, g_pred, g_logits_in, B, D, (long)H * W, g_logits);
+  AS_CHECK_LAUNCH("as_softargmax_bwd");
+  return AS_OK;
+}

@@ -1,0 +1,187 @@
+/*
+ * adaptive_stereo_hip.h — C ABI of libadaptive_stereo_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the StereoNet online-adaptation hot path
+ * (SURVEY.md §8).  The reference (miloknowles/adaptive-stereo-icra-2021) is pure
+ * Python/PyTorch and has no FFI of its own: the interfaces these entry points
+ * replace are the PyTorch op sequences inside the reference's nn.Module.forward()
+ * bodies and loss functions, cited per function below (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no
+ *     entry point synchronises, allocates or frees (safe under hipGraph capture);
+ *   - the caller owns every buffer; nothing is retained after return;
+ *   - return value: 0 on success, negative on error; as_last_error() returns a
+ *     thread-local description of the last failure;
+ *   - "NCHW"/"NCDHW" are the reference's contiguous PyTorch layouts;
+ *   - "PCL" (padded channel-last) is this library's internal activation layout:
+ *       float buf[B][D+2*pd][H+2*ph][W+2*pw][32]
+ *     with a zero halo that kernels never write.  Halo zeros implement the
+ *     convolutions' zero padding, so no kernel needs bounds predicates, and the
+ *     32 channels of a voxel are one aligned 128-byte line.  2-D maps use D=1, pd=0.
+ */
+#ifndef ADAPTIVE_STEREO_HIP_H_
+#define ADAPTIVE_STEREO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AS_CHANNELS 32
+#define AS_MAX_TAPS 32
+
+/* Geometry of one PCL tensor. */
+typedef struct as_pcl {
+  int32_t B, D, H, W;     /* logical extent */
+  int32_t pd, ph, pw;     /* halo width on each side of D, H, W */
+} as_pcl;
+
+/* Shape of a 32->32 convolution over PCL tensors. kd=1 for 2-D. */
+typedef struct as_conv_shape {
+  int32_t kd, kh, kw;     /* kernel extent */
+  int32_t pad_d, pad_h, pad_w;   /* logical zero padding (must be <= input halo) */
+  int32_t dil;            /* dilation on H and W (and D when kd>1) */
+  int32_t stride;         /* stride on H and W (D always 1) */
+} as_conv_shape;
+
+const char* as_last_error(void);
+int  as_version(void);
+/* Number of floats a PCL tensor occupies. */
+int64_t as_pcl_numel(const as_pcl* g);
+
+/* ---- a2: difference cost volume — stereo_net.py:173-184 -------------------
+ * vol[b,d,y,x,c] = L[b,c,y,x] - R[b,c,y,x-d]  (x >= d), else 0.
+ * L, R: NCHW [B,32,H,W].  vol: PCL {B,D,H,W}.  bwd adds nothing: it overwrites gL, gR. */
+int as_cost_volume_fwd(const float* L, const float* R, float* vol, const as_pcl* g, void* stream);
+int as_cost_volume_bwd(const float* gvol, float* gL, float* gR, const as_pcl* g, void* stream);
+
+/* ---- a3 (and a1/a7 32->32 convs): fp32-MFMA implicit-GEMM convolution ------
+ * Replaces nn.Conv3d(32,32,3,padding=1) of convbn_3d (stereo_net.py:21-30,185-186)
+ * and the 32->32 nn.Conv2d layers (stereo_net.py:10-18).
+ *
+ * as_conv32_pack_weights: w is the PyTorch weight [32(out)][32(in)][kd][kh][kw];
+ *   packed is [taps][2][32][16] floats in MFMA operand order.  transpose_flip=1
+ *   produces the weights of the data-gradient convolution (in/out swapped, taps
+ *   mirrored), so dgrad is the same kernel as forward.
+ * as_conv32_fwd: z = conv(x) + bias into the interior of PCL z.
+ *   epilogue 0: raw output; if stat_mean != NULL also writes per-workgroup
+ *               (mean, M2) partials [nblocks][32] for train-mode BatchNorm;
+ *   epilogue 1: z = lrelu(acc*ep_scale[c] + ep_shift[c]) (+ residual[v][c] if given):
+ *               eval-mode BatchNorm + LeakyReLU (+ BasicBlock skip) fused.
+ *   Returns the number of workgroups launched via *nblocks_out (may be NULL).
+ * as_conv32_wgrad: dW[o][i][tap] (PyTorch layout) = sum_v x[v+tap][i] * gz[v][o];
+ *   workspace must hold as_conv32_wgrad_workspace() floats. db (may be NULL) gets
+ *   sum_v gz[v][o]. */
+int as_conv32_pack_weights(const float* w, float* packed, const as_conv_shape* s,
+                           int transpose_flip, void* stream);
+int as_conv32_num_blocks(const as_pcl* gout);
+int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, const float* bias,
+                  float* z, const as_pcl* gout, const as_conv_shape* s,
+                  int epilogue, const float* ep_scale, const float* ep_shift, float slope,
+                  const float* residual, float* stat_mean, float* stat_m2, void* stream);
+int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
+                    const as_conv_shape* s, float* dW, float* db, float* workspace, void* stream);
+
+/* ---- BatchNorm (train/eval) + LeakyReLU around the convolution --------------
+ * nn.BatchNorm3d / nn.BatchNorm2d (eps, momentum as given) + nn.LeakyReLU(0.2)
+ * (stereo_net.py:17,29,39,94,159).
+ * as_bn_finalize: merges the conv's per-workgroup (mean,M2) partials (Chan, fp64),
+ *   writes save_mean/save_invstd, scale = gamma*invstd, shift = beta - mean*scale,
+ *   and updates running_mean / running_var (unbiased) with `momentum`.
+ * as_bn_eval_affine: scale/shift from the running statistics (eval mode).
+ * as_bn_act_fwd: a = lrelu(z*scale+shift) (+ residual) on the interior.
+ * as_bn_act_bwd: given g_a, z: writes g_z (PCL interior), g_gamma, g_beta; train=1 uses
+ *   batch statistics (full BatchNorm backward), train=0 treats mean/invstd as constants.
+ *   workspace: as_bn_bwd_workspace() floats. If g_res != NULL it receives nothing (the
+ *   skip connection's gradient is g_a itself and is handled by the caller). */
+int as_bn_finalize(const float* stat_mean, const float* stat_m2, int nblocks, int64_t count,
+                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   float momentum, float eps, float* save_mean, float* save_invstd,
+                   float* scale, float* shift, void* stream);
+int as_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* save_mean, float* save_invstd,
+                      float* scale, float* shift, void* stream);
+int as_bn_act_fwd(const float* z, const float* scale, const float* shift, float slope,
+                  const float* residual, float* a, const as_pcl* g, void* stream);
+int64_t as_bn_bwd_workspace(const as_pcl* g);
+int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const float* shift,
+                  const float* save_mean, const float* save_invstd, const float* gamma,
+                  float slope, int train, float* g_z, float* g_gamma, float* g_beta,
+                  float* workspace, const as_pcl* g, void* stream);
+
+/* ---- a4 + a5 + a8: conv3d 32->1, soft-argmax, arg-max index, FCS ---------------
+ * nn.Conv3d(32,1,3,padding=1) (stereo_net.py:162,187), F.softmax(dim=1) +
+ * DisparityRegression (stereo_net.py:190-192,124-134), feature_contrast_mean
+ * (utils/feature_contrast.py:12-23).
+ * w: [32][27] (PyTorch [1][32][3][3][3]).  logits: [B][D][H][W] (the reference's
+ * "cost_volume_{side}/{scale}" output).  pred/fcs: [B][H][W]; argmax: int32 [B][H][W]. */
+int as_conv3d_out_fwd(const float* a, const as_pcl* g, const float* w, const float* bias,
+                      float* logits, void* stream);
+int64_t as_conv3d_out_bwd_workspace(const as_pcl* g);
+int as_conv3d_out_bwd(const float* g_logits, const float* a, const as_pcl* g, const float* w,
+                      float* g_a, float* g_w, float* g_bias, float* workspace, void* stream);
+int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,
+                      float* pred, int32_t* argmax, float* fcs, void* stream);
+/* g_logits[d] = p_d*(d - pred)*g_pred (+ g_logits_in[d] when not NULL). */
+int as_softargmax_bwd(const float* logits, const float* g_pred, const float* g_logits_in,
+                      int B, int D, int H, int W, float* g_logits, void* stream);
+
+/* ---- a6/a7 head: bilinear up-sampling, align_corners=False -------------------
+ * F.interpolate(pred.unsqueeze(1), size=(H,W), mode="bilinear") * gain
+ * (stereo_net.py:106-114, 201-202).  src: [B][h][w], dst: [B][1][H][W]. */
+int as_upsample_bilinear_fwd(const float* src, int B, int h, int w, float* dst, int H, int W,
+                             float gain, void* stream);
+int as_upsample_bilinear_bwd(const float* g_dst, int B, int H, int W, float* g_src, int h, int w,
+                             float gain, void* stream);
+
+/* ---- a9: LinearWarping — models/linear_warping.py:18-57 -----------------------
+ * grid_sample(bilinear, border, align_corners=False) at (x -/+ disp, y) after the
+ * 2x/w-1 normalisation => samples at (x -/+ d - 0.5, y - 0.5).  img: NCHW [B,C,H,W];
+ * disp: [B,1,H,W]; warped: [B,C,H,W]; mask: uint8 [B,1,H,W].  bwd: gradient w.r.t.
+ * disp only (the image has no gradient in the adaptation loss). */
+int as_warp_fwd(const float* img, const float* disp, int B, int C, int H, int W, int right_to_left,
+                float* warped, uint8_t* mask, void* stream);
+int as_warp_bwd(const float* g_warped, const float* img, const float* disp, int B, int C, int H, int W,
+                int right_to_left, float* g_disp, void* stream);
+
+/* ---- a10: monodepth photometric loss — utils/loss_functions.py:41-138 ---------
+ * total = 0.85*mean_c(SSIM dist) + 0.15*mean_c|I - I~| + sw*smooth(d/(mean d + 1e-7), I).
+ * pred: [B,1,H,W]; img, warped: [B,3,H,W]; the four outputs: [B,1,H,W].
+ * workspace: as_monodepth_workspace() floats.
+ * bwd: g_* may be NULL (treated as zero).  Writes g_pred [B,1,H,W], g_warped [B,3,H,W]. */
+int64_t as_monodepth_workspace(int B, int H, int W);
+int as_monodepth_loss_fwd(const float* pred, const float* img, const float* warped, int B, int H, int W,
+                          float smoothness_weight, float* total, float* l1, float* ssim, float* smooth,
+                          float* workspace, void* stream);
+int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
+                          const float* pred, const float* img, const float* warped, int B, int H, int W,
+                          float smoothness_weight, float* g_pred, float* g_warped,
+                          float* workspace, void* stream);
+
+/* ---- loss[mask].mean() without a host sync — adapt.py:81-83 --------------------
+ * out[0] = sum(v*m), out[1] = count(m); value = out[0]/out[1] is formed by the caller
+ * on device.  workspace: as_masked_sum_workspace(n) floats. */
+int64_t as_masked_sum_workspace(int64_t n);
+int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream);
+
+/* ---- a12: clip_grad_norm_ + Adam, multi-tensor — adapt.py:208-210,391-393 ------
+ * One flat fp32 arena holds params / grads / exp_avg / exp_avg_sq at equal offsets.
+ * as_sumsq: out[0] = sum(g[0:n]^2) (deterministic two-stage).
+ * as_adam_step: g is first multiplied by *grad_scale_dev (a device scalar, e.g. the clip
+ * coefficient; NULL = 1), then the torch.optim.Adam update (no weight decay / amsgrad). */
+int64_t as_sumsq_workspace(int64_t n);
+int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream);
+int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
+                 int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* ADAPTIVE_STEREO_HIP_H_ */
