@@ -1,0 +1,173 @@
+"""One online-adaptation step, as the reference's adapt.py performs it, on MI355X.
+
+Reference sequence (adapt.py:304-396, NONSTOP mode; evaluation/stereonet_timing.py:44-72):
+  feature_net(left), feature_net(right) -> stereo_net(..., output_cost_volume=True)
+  -> LinearWarping(right, pred) -> monodepth_loss[0][mask].mean() -> FCS mean
+  -> zero_grad, backward -> clip_grad_norm_(stereo_net.parameters(), 1.0) -> Adam.step()
+
+What is different here (by design, not semantics):
+  * parameters, gradients and both Adam moments live in FLAT fp32 arenas (stereo_net first, then
+    feature_net — the reference's param-group order, adapt.py:208-209).  Module parameters are views
+    into the arena, ``.grad`` tensors are views into the gradient arena, so autograd accumulates in
+    place, the clip is one sum-of-squares kernel over a slice, Adam is one kernel per group, and —
+    with more than one GPU — the whole gradient arena (+3 scalars) is ONE RCCL all-reduce over xGMI.
+  * the masked mean is a fused reduction (no boolean-index host sync); the step issues no host sync.
+
+Data parallel semantics (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL):
+  independent stereo pairs are sharded over ranks; the loss is the mean over the valid pixels of
+  the WHOLE batch (adapt.py:83), so each rank back-propagates sum_r / N_total (N_total from a 1-float
+  all-reduce issued before backward) and gradients are summed.  BatchNorm statistics are per-replica
+  (each rank normalises with its own shard's statistics), as in torch DDP without SyncBatchNorm.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _native as nat
+from .hip_ops import masked_mean, MaskedMeanFn
+from .models.linear_warping import LinearWarping
+from .utils.loss_functions import monodepth_loss
+from .utils.feature_contrast import feature_contrast_mean
+from .utils.ema import online_ema
+
+
+class FlatArena(object):
+  """Re-homes the parameters of ``modules`` into one flat fp32 buffer (and a twin for gradients)."""
+
+  def __init__(self, modules):
+    self.entries = []          # (module index, name, param, offset, numel)
+    self.group_bounds = []     # (start, end) per module, in floats
+    offset = 0
+    params = []
+    for mi, m in enumerate(modules):
+      start = offset
+      for name, p in m.named_parameters():
+        n = p.numel()
+        self.entries.append((mi, name, p, offset, n))
+        params.append(p)
+        offset += n
+        offset = (offset + 3) // 4 * 4        # keep every tensor 16-byte aligned
+      self.group_bounds.append((start, offset))
+    self.numel = offset
+    dev = params[0].device
+    self.params = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+    self.grads = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+      for _, _, p, off, n in self.entries:
+        self.params[off:off + n].copy_(p.detach().reshape(-1))
+        p.data = self.params[off:off + n].view(p.shape)
+        p.grad = self.grads[off:off + n].view(p.shape)
+
+  def rebind_grads(self):
+    """Makes sure every ``p.grad`` is still the arena view (user code may have set it to None)."""
+    for _, _, p, off, n in self.entries:
+      if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * off:
+        p.grad = self.grads[off:off + n].view(p.shape)
+
+  def zero_grads(self):
+    self.grads.zero_()
+
+
+class FusedClipAdam(object):
+  """clip_grad_norm_(group 0, max_norm) + Adam over the arena (as_sumsq / as_adam_step)."""
+
+  def __init__(self, arena, lr, betas=(0.9, 0.999), eps=1e-8, clip_group=0, max_norm=1.0):
+    self.arena, self.lr, self.betas, self.eps = arena, lr, betas, eps
+    self.clip_group, self.max_norm = clip_group, max_norm
+    dev = arena.params.device
+    self.exp_avg = torch.zeros_like(arena.params)
+    self.exp_avg_sq = torch.zeros_like(arena.params)
+    self.step_count = 0
+    self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+    self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+    self.ws = torch.empty(nat.load().as_sumsq_workspace(arena.numel), dtype=torch.float32, device=dev)
+
+  def step(self, clip=True):
+    a = self.arena
+    self.step_count += 1
+    for gi, (s, e) in enumerate(a.group_bounds):
+      scale = None
+      if clip and gi == self.clip_group:
+        nat.call("as_sumsq", nat.ptr(a.grads[s:e]), e - s, nat.ptr(self.sumsq), nat.ptr(self.ws), nat.stream())
+        # torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+        torch.clamp(self.max_norm / (torch.sqrt(self.sumsq) + 1e-6), max=1.0, out=self.coef)
+        scale = self.coef
+      nat.call("as_adam_step", nat.ptr(a.params[s:e]), nat.ptr(a.grads[s:e]), nat.ptr(self.exp_avg[s:e]),
+               nat.ptr(self.exp_avg_sq[s:e]), e - s, nat.ptr(scale), self.lr, self.betas[0], self.betas[1],
+               self.eps, self.step_count, nat.stream())
+
+  def grad_norm(self):
+    """Pre-clip L2 norm of the clipped group at the last step (device scalar)."""
+    return torch.sqrt(self.sumsq)
+
+
+class OnlineAdapter(object):
+  """feature_net + stereo_net + warper + optimiser bound together for the per-step sequence."""
+
+  def __init__(self, feature_net, stereo_net, height, width, lr=5e-5, clip_grad_norm=True,
+               smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None):
+    self.feature_net, self.stereo_net = feature_net, stereo_net
+    self.scale = stereo_net.input_scale
+    self.coarse_scale = stereo_net.input_scale + stereo_net.k
+    self.warper = LinearWarping(height, width)
+    self.clip = clip_grad_norm
+    self.sw = smoothness_weight
+    self.fcs_ema_weight = fcs_ema_weight
+    self.fcs_smoothed = None
+    self.arena = FlatArena([stereo_net, feature_net])      # adapt.py:208-209 order
+    self.optimizer = FusedClipAdam(self.arena, lr)
+    self.pg = process_group
+    self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    dev = self.arena.params.device
+    self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [count, loss_sum, fcs_sum, pairs]
+
+  # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
+  @torch.no_grad()
+  def infer(self, left, right):
+    self.feature_net.eval(); self.stereo_net.eval()
+    fl, fr = self.feature_net(left), self.feature_net(right)
+    out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+    fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
+    return out, fcs
+
+  # -- one adaptation step: adapt.py:304-396 (NONSTOP) --------------------------------------------
+  def step(self, left, right):
+    self.feature_net.train(); self.stereo_net.train()
+    self.arena.rebind_grads()
+    self.arena.zero_grads()
+
+    fl, fr = self.feature_net(left), self.feature_net(right)
+    out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+    pred = out["pred_disp_l/{}".format(self.scale)]
+    warped, mask = self.warper(right, pred, right_to_left=True)
+    total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+    fcs_map = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
+
+    if self.world == 1:
+      loss = masked_mean(total, mask)
+      fcs = fcs_map.mean()
+      loss.backward()
+    else:
+      loss, fcs = self._distributed_backward(total, mask, fcs_map, left.shape[0])
+
+    self.optimizer.step(clip=self.clip)
+    self.fcs_smoothed = fcs if self.fcs_smoothed is None else online_ema(self.fcs_smoothed, fcs,
+                                                                          self.fcs_ema_weight)
+    out["left_warped/{}".format(self.scale)] = warped
+    return {"loss": loss.detach(), "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
+
+  def _distributed_backward(self, total, mask, fcs_map, pairs):
+    m8 = mask.to(torch.uint8)
+    lib = nat.load()
+    n = total.numel()
+    ws = torch.empty(lib.as_masked_sum_workspace(n), dtype=torch.float32, device=total.device)
+    local = torch.empty(2, dtype=torch.float32, device=total.device)
+    nat.call("as_masked_sum", nat.ptr(total.detach().contiguous()), nat.ptr(m8.contiguous()), n, nat.ptr(local),
+             nat.ptr(ws), nat.stream())
+    s = self.scalars
+    s[0] = local[1]; s[1] = local[0]; s[2] = fcs_map.sum(); s[3] = float(fcs_map.numel())
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.pg)          # 16 bytes, before backward
+    n_total = s[0]
+    # d(global mean)/d(total) on this rank = mask / N_total
+    total.backward(m8.to(torch.float32) / n_total)
+    dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM, group=self.pg)   # ONE flat bucket over xGMI
+    return s[1] / n_total, s[2] / s[3]

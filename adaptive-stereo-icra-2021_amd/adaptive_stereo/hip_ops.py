@@ -195,8 +195,8 @@ class CostAggregationFn(torch.autograd.Function):
     lib = nat.load()
 
     g_logits = torch.empty_like(logits)
-    call("as_softargmax_bwd", ptr(logits), ptr(f32c(g_pred)), ptr(f32c(g_logits_in)), B, D, H, W, ptr(g_logits),
-         stream())
+    g_pred, g_logits_in = f32c(g_pred), f32c(g_logits_in)      # keep any contiguous copies alive past the launch
+    call("as_softargmax_bwd", ptr(logits), ptr(g_pred), ptr(g_logits_in), B, D, H, W, ptr(g_logits), stream())
 
     grads = [None] * 18
     w_out = params[16]
@@ -276,7 +276,8 @@ class LinearWarpFn(torch.autograd.Function):
       raise NotImplementedError("LinearWarpFn: gradient w.r.t. the image is not part of the adaptation path")
     B, C, H, W = img.shape
     g_disp = torch.empty_like(disp)
-    call("as_warp_bwd", ptr(f32c(g_warped)), ptr(img), ptr(disp), B, C, H, W, ctx.r2l, ptr(g_disp), stream())
+    g_warped = f32c(g_warped)
+    call("as_warp_bwd", ptr(g_warped), ptr(img), ptr(disp), B, C, H, W, ctx.r2l, ptr(g_disp), stream())
     return None, g_disp, None
 
 
@@ -309,7 +310,8 @@ class MonodepthLossFn(torch.autograd.Function):
     g_pred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
     g_warped = torch.empty_like(warped) if ctx.needs_input_grad[2] else None
     ws = _empty(nat.load().as_monodepth_workspace(B, H, W), dev)
-    call("as_monodepth_loss_bwd", ptr(f32c(g_total)), ptr(f32c(g_l1)), ptr(f32c(g_ssim)), ptr(f32c(g_smooth)),
+    g_total, g_l1, g_ssim, g_smooth = f32c(g_total), f32c(g_l1), f32c(g_ssim), f32c(g_smooth)
+    call("as_monodepth_loss_bwd", ptr(g_total), ptr(g_l1), ptr(g_ssim), ptr(g_smooth),
          ptr(pred), ptr(img), ptr(warped), B, H, W, ctx.sw, ptr(g_pred), ptr(g_warped), ptr(ws), stream())
     return g_pred, None, g_warped, None
 

@@ -29,7 +29,7 @@ def stereo_pair(batch: int, height: int, width: int, seed: int = 1,
                 disparities=(5.0, 17.0, 40.0), noise: float = 0.02):
   """Returns (left, right) fp32 images in [0, 1], shape [B, 3, H, W].
 
-  The left image is a smooth random field plus fine texture. The right image
+  The left image is a band-limited random field (two octaves) plus 5% pixel noise. The right image
   is the left image shifted by a per-sample integer disparity d0 (so that
   R(x) = L(x + d0), i.e. a left pixel x appears at x - d0 in the right view)
   plus a little independent noise. A constant-zero image, as used by the
@@ -37,11 +37,16 @@ def stereo_pair(batch: int, height: int, width: int, seed: int = 1,
   volume identically zero and is useless for a parity check.
   """
   g = _gen(seed)
-  coarse_h, coarse_w = max(height // 16, 2), max(width // 16, 2)
-  low = torch.rand(batch, 3, coarse_h, coarse_w, generator=g)
-  smooth = F.interpolate(low, size=(height, width), mode="bilinear", align_corners=False)
-  texture = torch.rand(batch, 3, height, width, generator=g)
-  left = (0.7 * smooth + 0.3 * texture).clamp_(0.0, 1.0)
+
+  def field(div):
+    lo = torch.rand(batch, 3, max(height // div, 2), max(width // div, 2), generator=g)
+    return F.interpolate(lo, size=(height, width), mode="bicubic", align_corners=False)
+
+  # Band-limited like real imagery: structure at 1/16 and 1/4 resolution plus a little
+  # per-pixel sensor noise.  (Per-pixel white noise at large amplitude would make the
+  # warp's disparity gradient (I[x+1]-I[x]) chaotic under 1e-4-relative perturbations.)
+  pixel = torch.rand(batch, 3, height, width, generator=g)
+  left = (0.55 * field(16) + 0.40 * field(4) + 0.05 * pixel).clamp_(0.0, 1.0)
 
   right = torch.empty_like(left)
   for b in range(batch):
@@ -65,10 +70,10 @@ def synthetic_state_dict(reference_state: "OrderedDict[str, torch.Tensor]", seed
   affine parameters and running statistics so that every term of the BN
   arithmetic is exercised.
 
-  ``logit_gain`` multiplies ``conv3d_alone.{weight,bias}``: with random weights
-  the post-aggregation logits span only about [-0.03, -0.01]; a gain of ~1e3
-  gives a "trained-like" range comparable to the reference's plots
-  (evaluation/cost_volume_analysis.py:147-150).
+  ``logit_gain`` multiplies ``conv3d_alone.{weight,bias}``: with these random
+  weights the post-aggregation logits span about +-1 (FCS ~0.6); a gain of ~20
+  gives a "trained-like" range (FCS ~12) comparable to the reference's plots
+  (evaluation/cost_volume_analysis.py:147-150) and its OOD thresholds (~12).
   """
   keys = set(reference_state.keys())
   out = OrderedDict()

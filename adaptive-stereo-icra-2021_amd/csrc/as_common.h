@@ -12,6 +12,8 @@
 #define AS_ERR_LAUNCH (-2)
 
 void as_set_error(const char* fmt, ...);
+// measurement hook (optim.hip): event pair around a kernel launch; no-ops unless enabled
+void as_prof_mark(int kernel_id, hipStream_t st, int begin, double flops);
 
 #define AS_CHECK_ARG(cond, ...)            \
   do {                                     \

@@ -376,7 +376,9 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
   a.M = (int)M; a.stride = s->stride; a.ntaps = s->kd * s->kh * s->kw;
   a.epilogue = epilogue; a.slope = slope;
   if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_fwd")) return e;
+  as_prof_mark(0, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(conv32_fwd_kernel, dim3(as_div_up(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  as_prof_mark(0, (hipStream_t)stream, 0, 2.0 * (double)M * 1024.0 * a.ntaps);
   AS_CHECK_LAUNCH("as_conv32_fwd");
   return AS_OK;
 }
@@ -423,9 +425,11 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
   a.rows = gout->B * gout->D * gout->H; a.rows_per_chunk = rpc; a.ntaps = T;
   if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_wgrad")) return e;
   hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(1, st, 1, 0.0);
   if (tg == 3) launch_wgrad<3>(a, T / 3, nchunks, st);
   else if (tg == 5) launch_wgrad<5>(a, T / 5, nchunks, st);
   else launch_wgrad<1>(a, T, nchunks, st);
+  as_prof_mark(1, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
   AS_CHECK_LAUNCH("as_conv32_wgrad");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 256)), dim3(256), 0, st,
                      a.partial, a.partial_db, nchunks, T, dW, db);

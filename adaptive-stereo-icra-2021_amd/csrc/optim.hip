@@ -25,6 +25,54 @@ extern "C" int64_t as_pcl_numel(const as_pcl* g) {
   return (int64_t)g->B * (g->D + 2 * g->pd) * (g->H + 2 * g->ph) * (g->W + 2 * g->pw) * 32;
 }
 
+// ---- measurement hook -------------------------------------------------------------------
+#define PROF_IDS 2
+#define PROF_MAX 8192
+static int g_prof_on = 0;
+static hipEvent_t g_prof_ev[PROF_IDS][PROF_MAX][2];
+static int g_prof_created[PROF_IDS] = {0, 0};
+static int g_prof_n[PROF_IDS] = {0, 0};
+static double g_prof_flops[PROF_IDS] = {0.0, 0.0};
+
+void as_prof_mark(int id, hipStream_t st, int begin, double flops) {
+  if (!g_prof_on || id < 0 || id >= PROF_IDS) return;
+  int n = g_prof_n[id];
+  if (n >= PROF_MAX) return;
+  if (n >= g_prof_created[id]) {
+    if (hipEventCreate(&g_prof_ev[id][n][0]) != hipSuccess) return;
+    if (hipEventCreate(&g_prof_ev[id][n][1]) != hipSuccess) return;
+    g_prof_created[id] = n + 1;
+  }
+  if (begin) {
+    (void)hipEventRecord(g_prof_ev[id][n][0], st);
+  } else {
+    (void)hipEventRecord(g_prof_ev[id][n][1], st);
+    g_prof_flops[id] += flops;
+    g_prof_n[id] = n + 1;
+  }
+}
+
+extern "C" int as_prof_enable(int on) { g_prof_on = on ? 1 : 0; return AS_OK; }
+extern "C" int as_prof_reset(void) {
+  for (int i = 0; i < PROF_IDS; ++i) { g_prof_n[i] = 0; g_prof_flops[i] = 0.0; }
+  return AS_OK;
+}
+extern "C" int as_prof_read(int id, int64_t* launches, double* total_ms, double* total_flops) {
+  AS_CHECK_ARG(id >= 0 && id < PROF_IDS && launches && total_ms && total_flops, "as_prof_read: bad argument");
+  double ms = 0.0;
+  for (int i = 0; i < g_prof_n[id]; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof_ev[id][i][1]) != hipSuccess ||
+        hipEventElapsedTime(&t, g_prof_ev[id][i][0], g_prof_ev[id][i][1]) != hipSuccess) {
+      as_set_error("as_prof_read: event query failed");
+      return AS_ERR_LAUNCH;
+    }
+    ms += (double)t;
+  }
+  *launches = g_prof_n[id]; *total_ms = ms; *total_flops = g_prof_flops[id];
+  return AS_OK;
+}
+
 #define SS_BLOCKS 256
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ partial) {
   __shared__ double red[4];

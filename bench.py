@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path named by BASELINE.json: stereo pairs/s at KITTI 1242x375,
+maxdisp 192 (k=4, input_scale=0), forward + one online-adaptation step, synthetic inputs,
+1..8 MI355X (one process per GPU, RCCL gradient all-reduce).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = feature nets on both images + StereoNet forward + LinearWarping + monodepth loss +
+FCS + backward + clip_grad_norm_(stereo_net, 1.0) + Adam(lr 5e-5) on a batch of `--batch` pairs
+per GPU (reference: adapt.py:304-396 NONSTOP / evaluation/stereonet_timing.py:44-72).
+Prints ONE JSON line (rank 0).  `value` is the adaptation-step rate; the forward-only rate
+(eval, no_grad, evaluation/stereonet_timing.py:22-41) is reported next to it.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "adaptive-stereo-icra-2021_amd")):
+  if p not in sys.path:
+    sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--batch", type=int, default=4, help="stereo pairs per GPU per step (32/8 in BASELINE configs[3])")
+  ap.add_argument("--height", type=int, default=375)
+  ap.add_argument("--width", type=int, default=1242)
+  ap.add_argument("--k", type=int, default=4)
+  ap.add_argument("--maxdisp", type=int, default=192)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  return ap.parse_args()
+
+
+def log(msg):
+  if int(os.environ.get("RANK", "0")) == 0:
+    print("[bench %7.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
+def timed(fn, steps, world):
+  """barrier + synchronize, K calls, synchronize + barrier; MAX over ranks (seconds)."""
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    fn()
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+  return dt
+
+
+def host_threads():
+  """Threads to use for the CPU baseline: the box's CPU share (16 per GPU), not the host's core count."""
+  try:
+    n = len(os.sched_getaffinity(0))
+  except AttributeError:
+    n = os.cpu_count() or 1
+  return max(1, min(n, int(os.environ.get("AS_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(args, fsd, ssd, budget_s=12.0):
+  """The oracle (a port of the reference's CPU path) on this host's cores; bounded sample:
+  one warm-up then as many repetitions as fit in ~budget_s seconds per mode (at least one)."""
+  from adaptive_stereo.utils import synthetic as syn
+  from oracle import stereo_oracle as orc
+  torch.set_num_threads(host_threads())
+  left, right = syn.stereo_pair(1, args.height, args.width, seed=1)
+  fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
+  state = {}
+
+  def sample(fn):
+    fn()                                        # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+      fn(); n += 1
+      dt = time.perf_counter() - t0
+      if dt >= budget_s or n >= 10:
+        return dt / n, n
+
+  t_adapt, n_adapt = sample(lambda: orc.adapt_step(fp, sp, state, left, right, args.k, 0, args.maxdisp))
+  log("cpu baseline: adapt %.3f s/step (%d reps)" % (t_adapt, n_adapt))
+  t_fwd, n_fwd = sample(lambda: orc.forward_only(fsd, ssd, left, right, args.k, 0, args.maxdisp))
+  log("cpu baseline: forward %.3f s (%d reps)" % (t_fwd, n_fwd))
+  return {"value": round(1.0 / t_adapt, 4), "unit": "stereo pairs/s (fwd+adapt-step)", "cores": torch.get_num_threads(),
+          "kind": "port", "fwd_value": round(1.0 / t_fwd, 4),
+          "sample": "oracle/stereo_oracle.py (PyTorch CPU fp32), batch 1 at %dx%d: 1 warm-up + %d adapt steps, "
+                    "1 warm-up + %d forwards" % (args.width, args.height, n_adapt, n_fwd)}
+
+
+def main():
+  args = parse()
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world > 1:
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+  assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
+  dev = torch.device("cuda", local_rank)
+
+  from adaptive_stereo import _native as nat
+  from adaptive_stereo.adaptation import OnlineAdapter
+  from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+  from adaptive_stereo.utils import synthetic as syn
+
+  fnet, snet = FeatureExtractorNetwork(args.k), StereoNet(args.k, 1, 0, maxdisp=args.maxdisp)
+  fsd = syn.synthetic_state_dict(fnet.state_dict(), seed=123)
+  ssd = syn.synthetic_state_dict(snet.state_dict(), seed=123)
+  fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+  fnet, snet = fnet.to(dev), snet.to(dev)
+  B = args.batch
+  left, right = syn.stereo_pair(B, args.height, args.width, seed=1 + rank)
+  left, right = left.to(dev), right.to(dev)
+  adapter = OnlineAdapter(fnet, snet, args.height, args.width, lr=5e-5, clip_grad_norm=True)
+
+  lib = nat.load()
+  log("setup done: %d pairs/GPU at %dx%d, world %d" % (B, args.width, args.height, world))
+  # ---- forward + adaptation step ---------------------------------------------------------
+  for i in range(args.warmup):
+    adapter.step(left, right)
+    torch.cuda.synchronize()
+    log("warm-up adapt step %d done" % i)
+  lib.as_prof_reset(); lib.as_prof_enable(1)
+  t_adapt = timed(lambda: adapter.step(left, right), args.steps, world)
+  lib.as_prof_enable(0)
+  prof = []
+  for kid in (0, 1):
+    n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+    nat.call("as_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+    prof.append((n.value, ms.value, fl.value))
+
+  log("timed adapt: %.2f ms/step" % (1e3 * t_adapt / args.steps))
+  # ---- forward only --------------------------------------------------------------------------
+  for _ in range(max(1, args.warmup // 2)):
+    adapter.infer(left, right)
+  torch.cuda.synchronize()
+  log("warm-up forward done")
+  t_fwd = timed(lambda: adapter.infer(left, right), args.steps, world)
+  log("timed forward: %.2f ms/step" % (1e3 * t_fwd / args.steps))
+
+  if rank != 0:
+    if world > 1:
+      dist.destroy_process_group()
+    return
+
+  pairs = world * B * args.steps
+  # dominant hand-written kernel: the fp32-MFMA implicit-GEMM convolution (forward + data-gradient
+  # launches of the 3-D aggregation).  achieved = algorithmic FLOPs (2*voxels*32*32*27 per launch)
+  # / mean launch duration from HIP events recorded on the launch stream during the timed steps.
+  n0, ms0, fl0 = prof[0]
+  n1, ms1, fl1 = prof[1]
+  roofline = None
+  if n0 > 0 and ms0 > 0:
+    achieved = fl0 / (ms0 * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "pmc_conv32_fwd.json")
+    if os.path.exists(pmc):
+      traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+    roofline = {"bound": "mfma", "kernel": "conv32_fwd_kernel", "achieved": round(achieved, 3),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": traffic, "launches": n0, "avg_launch_us": round(1e3 * ms0 / n0, 2),
+                "flops_per_launch": fl0 / n0,
+                "wgrad_kernel": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 3) if ms1 > 0 else None,
+                                 "launches": n1, "avg_launch_us": round(1e3 * ms1 / max(n1, 1), 2)}}
+
+  out = {
+    "metric": "stereo pairs/sec (fwd+adapt-step), KITTI 1242x375 D=192",
+    "value": round(pairs / t_adapt, 3),
+    "unit": "stereo pairs/s",
+    "n_gpus": world,
+    "steps": args.steps,
+    "warmup": args.warmup,
+    "ms_per_step": round(1e3 * t_adapt / args.steps, 3),
+    "higher_is_better": True,
+    "scaling": "weak",
+    "vs_baseline": None,
+    "dtype": "f32",
+    "data": "synthetic",
+    "config": {"workload": "KITTI-2015 %dx%d, maxdisp %d, k=%d (Dc=%d, %dx%d cost volume), forward + one online-adapt "
+                           "step (train-mode BN, monodepth loss, clip 1.0, Adam lr 5e-5)" % (
+                               args.width, args.height, args.maxdisp, args.k, (args.maxdisp + 1) // 2 ** args.k,
+                               -(-args.height // 2 ** args.k), -(-args.width // 2 ** args.k)),
+               "pairs_per_gpu": B, "global_batch": world * B,
+               "parallelism": "dp%d (per-replica BatchNorm statistics, one flat RCCL gradient all-reduce)" % world,
+               "conv2d_backend": "MIOpen (feature extractor, refinement); all other ops hand-written HIP"},
+    "fwd_pairs_per_s": round(pairs / t_fwd, 3),
+    "fwd_ms_per_step": round(1e3 * t_fwd / args.steps, 3),
+    "roofline": roofline,
+  }
+  if world == 1 and not args.no_cpu_baseline:
+    out["cpu_baseline"] = cpu_baseline(args, fsd, ssd)
+    log("cpu baseline done")
+  print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -181,6 +181,15 @@ int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
                  int step, void* stream);
 
+/* ---- measurement hook (bench.py roofline leg) -----------------------------------
+ * When enabled, as_conv32_fwd (kernel id 0) and as_conv32_wgrad (id 1) bracket their main
+ * kernel with HIP events on the launch stream and account its algorithmic FLOPs
+ * (2 * voxels * 32 * 32 * taps).  as_prof_read synchronises on the recorded events.
+ * Disabled by default; must stay disabled under hipGraph capture. */
+int as_prof_enable(int on);
+int as_prof_reset(void);
+int as_prof_read(int kernel_id, int64_t* launches, double* total_ms, double* total_flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,8 +56,8 @@ CASES = [
   dict(name="plumbing_240x320_k3_b1", B=1, H=240, W=320, k=3, s=0, maxdisp=64, gain=1.0, dense=True),
   dict(name="plumbing_240x320_k3_b2", B=2, H=240, W=320, k=3, s=0, maxdisp=64, gain=1.0, dense=False),
   dict(name="crop_96x256_k4_b1", B=1, H=96, W=256, k=4, s=0, maxdisp=192, gain=1.0, dense=True),
-  dict(name="crop_96x256_k4_b2_trained", B=2, H=96, W=256, k=4, s=0, maxdisp=192, gain=600.0, dense=True),
-  dict(name="odd_75x131_k3_b1", B=1, H=75, W=131, k=3, s=0, maxdisp=96, gain=300.0, dense=True),
+  dict(name="crop_96x256_k4_b2_trained", B=2, H=96, W=256, k=4, s=0, maxdisp=192, gain=20.0, dense=True),
+  dict(name="odd_75x131_k3_b1", B=1, H=75, W=131, k=3, s=0, maxdisp=96, gain=20.0, dense=True),
   dict(name="kitti_375x1242_k4_b1", B=1, H=375, W=1242, k=4, s=0, maxdisp=192, gain=1.0, dense=False),
 ]
 

@@ -1,0 +1,102 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, the
+product modules reproduce the reference's state_dict contract, host-side control utilities behave
+like the reference's, and the product refuses to run without a GPU (there is no CPU fallback)."""
+import os
+import random
+import re
+
+import pytest
+import torch
+
+from conftest import REPO
+from adaptive_stereo import _native as nat
+from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+from adaptive_stereo.utils.ema import online_ema
+from adaptive_stereo.utils.stereo_reservoir import StereoReservoir
+
+HEADER = os.path.join(REPO, "include", "adaptive_stereo_hip.h")
+
+
+def declared_symbols():
+  text = open(HEADER).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(as_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+  lib = nat.load()
+  names = declared_symbols()
+  assert len(names) >= 30
+  for n in names:
+    assert hasattr(lib, n), "libadaptive_stereo_hip.so does not export %s" % n
+  # the ctypes signature table covers exactly the header
+  assert sorted(nat.EXPORTED_SYMBOLS) == names
+  assert lib.as_version() >= 1
+
+
+def test_geometry_helpers_without_gpu():
+  lib = nat.load()
+  g = nat.Pcl(2, 12, 24, 78, 1, 1, 1)
+  assert lib.as_pcl_numel(g) == 2 * 14 * 26 * 80 * 32 == g.numel()
+  assert lib.as_conv32_num_blocks(g) == (2 * 12 * 24 * 78 + 127) // 128
+  s = nat.ConvShape(3, 3, 3, 1, 1, 1, 1, 1)
+  assert lib.as_conv32_wgrad_workspace(g, g, s) > 0
+  # argument validation happens before any launch
+  bad = nat.Pcl(0, 1, 1, 1, 0, 0, 0)
+  assert lib.as_cost_volume_fwd(None, None, None, bad, None) != 0
+  assert b"geometry" in lib.as_last_error()
+
+
+@pytest.mark.parametrize("k", [3, 4])
+def test_state_dict_contract_matches_reference(k, golden_loader):
+  """Key names, shapes and dtypes equal the reference's (taken from the fixtures' 'after/' entries,
+  which were dumped from the reference's own state_dict())."""
+  gold = golden_loader("plumbing_240x320_k3_b1" if k == 3 else "crop_96x256_k4_b1")
+  fnet, snet = FeatureExtractorNetwork(k), StereoNet(k, 1, 0, maxdisp=192)
+  for prefix, net, expect in (("stereo", snet, 123), ("feature", fnet, 92 if k == 3 else 94)):
+    sd = net.state_dict()
+    assert len(sd) == expect
+    ref_keys = sorted(x[len("after/%s." % prefix):] for x in gold.z.files if x.startswith("after/%s." % prefix))
+    ref_keys += sorted(x[len("shape__after/%s." % prefix):] for x in gold.z.files
+                       if x.startswith("shape__after/%s." % prefix))
+    assert sorted(sd.keys()) == sorted(set(ref_keys))
+    for name, t in sd.items():
+      skey = "shape__after/%s.%s" % (prefix, name)
+      if skey in gold.z.files:
+        assert tuple(t.shape) == tuple(int(v) for v in gold.z[skey]), name
+  assert snet.state_dict()["filter.0.0.0.weight"].shape == (32, 32, 3, 3, 3)
+  assert "edge_aware_refinements.0.residual_astrous_blocks.3.conv2.1.running_var" in snet.state_dict()
+
+
+def test_product_refuses_cpu_tensors():
+  fnet, snet = FeatureExtractorNetwork(3), StereoNet(3, 1, 0, maxdisp=64)
+  x = torch.zeros(1, 3, 32, 32)
+  with pytest.raises(RuntimeError, match="no CPU path"):
+    fnet(x)
+  with pytest.raises(RuntimeError, match="no CPU path"):
+    snet(x, torch.zeros(1, 32, 4, 4), torch.zeros(1, 32, 4, 4), "l")
+
+
+def test_reservoir_is_uniform_like_the_reference():
+  """Mirrors the reference's test/test_stereo_reservoir.py: mean of kept items ~ 500 +- 5."""
+  random.seed(123)
+  total = 0.0
+  trials = 1000
+  for _ in range(trials):
+    r = StereoReservoir(10)
+    for i in range(1000):
+      r.add(None, None, float(i), i)
+    assert r.size() == 10
+    total += r.average_value()
+  assert abs(total / trials - 499.5) < 5.0
+  r = StereoReservoir(2)
+  assert r.add(None, None, 1.0, 7) is True
+  assert r.add(None, None, 1.0, 7) is False          # duplicate index refused
+  r.update_value(0, 3.0)
+  assert r.average_value() == 3.0
+
+
+def test_online_ema():
+  assert online_ema(2.0, 4.0, weight=0.75) == 2.0 * 0.75 + 0.25 * 4.0
+  t = online_ema(torch.tensor(1.0), torch.tensor(3.0))
+  assert abs(float(t) - (0.999 + 0.003)) < 1e-6

@@ -1,0 +1,332 @@
+"""Kernel-level parity: every C-ABI entry point against the oracle / a plain PyTorch fp32
+CPU evaluation of the same op, on seeded inputs with ragged (non-multiple-of-tile) extents.
+
+All tests here need a real MI355X (``-m gpu``) and call the HIP library through the C ABI.
+Tolerances are written next to each assertion; integer/index outputs must be exact.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from adaptive_stereo import _native as nat
+from adaptive_stereo import hip_ops as ops
+from adaptive_stereo.hip_ops import Pcl, ConvShape
+from oracle import stereo_oracle as orc
+
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(got, exp, atol, rtol=0.0, what=""):
+  got, exp = got.detach().cpu().double(), exp.detach().cpu().double()
+  assert got.shape == exp.shape, "%s shape %s vs %s" % (what, tuple(got.shape), tuple(exp.shape))
+  err = (got - exp).abs()
+  tol = atol + rtol * exp.abs()
+  assert bool((err <= tol).all()), "%s: max err %.3e, %d/%d over tol" % (what, float(err.max()), int((err > tol).sum()), err.numel())
+
+
+# ----------------------------------------------------------------------------- a2
+@pytest.mark.parametrize("B,D,H,W", [(1, 8, 5, 9), (2, 12, 7, 78), (1, 24, 3, 131), (1, 1, 1, 1), (1, 4, 2, 3)])
+def test_cost_volume_fwd_is_bit_exact(B, D, H, W):
+  fl, fr = rnd(B, 32, H, W, seed=1), rnd(B, 32, H, W, seed=2)
+  g = Pcl(B, D, H, W, 1, 1, 1)
+  vol = ops.pcl_zeros(g, DEV)
+  fld, frd = fl.to(DEV), fr.to(DEV)     # named: a temporary's memory would be recycled before the launch
+  nat.call("as_cost_volume_fwd", nat.ptr(fld), nat.ptr(frd), nat.ptr(vol), g, nat.stream())
+  exp = orc.cost_volume(fl, fr, D)
+  assert torch.equal(ops.pcl_to_ncdhw(vol, g).cpu(), exp)          # one fp32 subtract: exact
+  # the halo must still be zero
+  full = ops.pcl_view(vol, g).clone()
+  ops.pcl_interior(full, g).zero_()
+  assert float(full.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,D,H,W", [(1, 8, 5, 9), (2, 12, 4, 78), (1, 24, 3, 70)])
+def test_cost_volume_bwd(B, D, H, W):
+  fl = rnd(B, 32, H, W, seed=1).requires_grad_(True)
+  fr = rnd(B, 32, H, W, seed=2).requires_grad_(True)
+  gv = rnd(B, 32, D, H, W, seed=3)
+  orc.cost_volume(fl, fr, D).backward(gv)
+  g = Pcl(B, D, H, W, 1, 1, 1)
+  gbuf = ops.ncdhw_to_pcl(gv.to(DEV), g)
+  gl, gr = torch.empty(B, 32, H, W, device=DEV), torch.empty(B, 32, H, W, device=DEV)
+  nat.call("as_cost_volume_bwd", nat.ptr(gbuf), nat.ptr(gl), nat.ptr(gr), g, nat.stream())
+  # sums of <= D terms: fp32 reassociation only
+  close(gl, fl.grad, 1e-5, 1e-5, "gL"); close(gr, fr.grad, 1e-5, 1e-5, "gR")
+
+
+# ----------------------------------------------------------------------------- a3
+def _conv_ref(x, w, b, shape):
+  if shape.kd > 1:
+    return F.conv3d(x, w, b, stride=1, padding=(shape.pad_d, shape.pad_h, shape.pad_w), dilation=shape.dil)
+  return F.conv2d(x[:, :, 0], w, b, stride=shape.stride, padding=(shape.pad_h, shape.pad_w), dilation=shape.dil).unsqueeze(2)
+
+
+CONV_CASES = [
+  # B, D, H, W, shape, halo
+  (1, 8, 5, 9, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
+  (2, 12, 6, 19, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
+  (1, 3, 24, 78, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
+  (2, 1, 17, 37, ConvShape(1, 3, 3, 0, 1, 1, 1, 1), (0, 1, 1)),
+  (1, 1, 21, 45, ConvShape(1, 3, 3, 0, 2, 2, 2, 1), (0, 8, 8)),
+  (1, 1, 33, 40, ConvShape(1, 3, 3, 0, 8, 8, 8, 1), (0, 8, 8)),
+]
+
+
+@pytest.mark.parametrize("B,D,H,W,shape,halo", CONV_CASES)
+def test_conv32_fwd_dgrad_wgrad(B, D, H, W, shape, halo):
+  taps = shape.taps()
+  wshape = (32, 32, 3, 3, 3) if shape.kd > 1 else (32, 32, 3, 3)
+  x = rnd(B, 32, D, H, W, seed=1).requires_grad_(True)
+  w = rnd(*wshape, seed=2, scale=1.0 / (32 * taps) ** 0.5).requires_grad_(True)
+  b = rnd(32, seed=3, scale=0.1).requires_grad_(True)
+  wr = w if shape.kd > 1 else w
+  z_ref = _conv_ref(x, wr, b, shape)
+  gz = rnd(*z_ref.shape, seed=4)
+  z_ref.backward(gz)
+
+  g = Pcl(B, D, H, W, *halo)
+  xb = ops.ncdhw_to_pcl(x.detach().to(DEV), g)
+  wd, bd = w.detach().to(DEV), b.detach().to(DEV)
+  wp = ops.pack_weights(wd, shape, False)
+  nblk = nat.load().as_conv32_num_blocks(g)
+  stats = (torch.empty(nblk * 32, device=DEV), torch.empty(nblk * 32, device=DEV))
+  zb = ops.conv32(xb, g, wp, bd, g, shape, stats=stats)
+  # fp32 fma chain over K = 32*taps products of O(1/sqrt(K)) terms
+  close(ops.pcl_to_ncdhw(zb, g), z_ref, 2e-5, 1e-5, "conv fwd")
+  full = ops.pcl_view(zb, g).clone(); ops.pcl_interior(full, g).zero_()
+  assert float(full.abs().max()) == 0.0, "conv wrote into the halo"
+
+  # train-mode BatchNorm statistics from the epilogue partials
+  gamma, beta = rnd(32, seed=5) * 0.5 + 1.0, rnd(32, seed=6) * 0.2
+  rm, rv = rnd(32, seed=7) * 0.1, rnd(32, seed=8).abs() + 0.5
+  rm_d, rv_d = rm.to(DEV).clone(), rv.to(DEV).clone()
+  st = ops.bn_train_stats(stats, g.voxels(), gamma.to(DEV), beta.to(DEV), rm_d, rv_d, nblk)
+  zr = z_ref.detach()
+  mean_ref = zr.mean(dim=(0, 2, 3, 4))
+  var_ref = zr.var(dim=(0, 2, 3, 4), unbiased=False)
+  close(st.mean, mean_ref, 2e-6, 1e-5, "bn mean")
+  close(st.invstd, 1.0 / torch.sqrt(var_ref + 1e-5), 0, 2e-5, "bn invstd")
+  rm_ref, rv_ref = rm.clone(), rv.clone()
+  F.batch_norm(zr, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+  close(rm_d, rm_ref, 2e-6, 1e-5, "running_mean"); close(rv_d, rv_ref, 2e-6, 2e-5, "running_var")
+
+  # data gradient = same kernel on mirrored/transposed weights
+  gzb = ops.ncdhw_to_pcl(gz.to(DEV), g)
+  wpt = ops.pack_weights(wd, shape, True)
+  gxb = ops.conv32(gzb, g, wpt, None, g, shape)
+  close(ops.pcl_to_ncdhw(gxb, g), x.grad, 3e-5, 1e-5, "conv dgrad")
+
+  # weight / bias gradient: sums over B*D*H*W voxels
+  dW, db = ops.conv32_wgrad(xb, g, gzb, g, shape)
+  n = g.voxels()
+  close(dW, w.grad, 2e-6 * n ** 0.5 + 1e-5, 2e-5, "conv wgrad")
+  close(db, b.grad, 2e-6 * n ** 0.5 + 1e-5, 2e-5, "conv bias grad")
+
+
+def test_conv32_fused_eval_epilogue_and_residual():
+  B, D, H, W = 1, 1, 19, 23
+  shape, halo = ConvShape(1, 3, 3, 0, 2, 2, 2, 1), (0, 8, 8)
+  x, w, b = rnd(B, 32, D, H, W, seed=1), rnd(32, 32, 3, 3, seed=2, scale=0.06), rnd(32, seed=3, scale=0.1)
+  sc, sh = rnd(32, seed=4) * 0.5 + 1.0, rnd(32, seed=5) * 0.3
+  ref = x + F.leaky_relu(_conv_ref(x, w, b, shape) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1), 0.2)
+  g = Pcl(B, D, H, W, *halo)
+  xb = ops.ncdhw_to_pcl(x.to(DEV), g)
+  out = ops.conv32(xb, g, ops.pack_weights(w.to(DEV), shape, False), b.to(DEV), g, shape, epilogue=1,
+                   scale=sc.to(DEV), shift=sh.to(DEV), residual=xb)
+  close(ops.pcl_to_ncdhw(out, g), ref, 2e-5, 1e-5, "fused epilogue")
+
+
+# ----------------------------------------------------------------------------- BN + LeakyReLU
+@pytest.mark.parametrize("train", [True, False])
+def test_bn_act_fwd_bwd(train):
+  B, D, H, W = 2, 5, 7, 11
+  g = Pcl(B, D, H, W, 1, 1, 1)
+  z = rnd(B, 32, D, H, W, seed=1, scale=2.0).requires_grad_(True)
+  gamma = (rnd(32, seed=2) * 0.5 + 1.0).requires_grad_(True)
+  beta = (rnd(32, seed=3) * 0.2).requires_grad_(True)
+  rm, rv = rnd(32, seed=4) * 0.1, rnd(32, seed=5).abs() + 0.5
+  a_ref = F.leaky_relu(F.batch_norm(z, rm.clone(), rv.clone(), gamma, beta, train, 0.1, 1e-5), 0.2)
+  ga = rnd(B, 32, D, H, W, seed=6)
+  a_ref.backward(ga)
+
+  zb = ops.ncdhw_to_pcl(z.detach().to(DEV), g)
+  gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+  if train:
+    # statistics through the public path: an identity "convolution" is not available, so feed exact stats
+    zr = z.detach()
+    st = ops.BnState(DEV)
+    st.mean.copy_(zr.mean(dim=(0, 2, 3, 4)))
+    st.invstd.copy_(1.0 / torch.sqrt(zr.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5))
+    st.scale.copy_(st.invstd * gd); st.shift.copy_(bd - st.mean * st.scale)
+  else:
+    st = ops.bn_eval_stats(gd, bd, rm.to(DEV), rv.to(DEV))
+  ab = ops.bn_act(zb, st, g)
+  close(ops.pcl_to_ncdhw(ab, g), a_ref, 1e-5, 1e-5, "bn+lrelu fwd")
+  gab = ops.ncdhw_to_pcl(ga.to(DEV), g)
+  g_z, g_gamma, g_beta = ops.bn_act_bwd(gab, zb, st, gd, g, train)
+  close(ops.pcl_to_ncdhw(g_z, g), z.grad, 2e-5, 1e-4, "bn bwd g_z")
+  close(g_gamma, gamma.grad, 2e-4, 1e-4, "bn bwd g_gamma")
+  close(g_beta, beta.grad, 2e-4, 1e-4, "bn bwd g_beta")
+
+
+# ----------------------------------------------------------------------------- a4 + a5 + a8
+@pytest.mark.parametrize("B,D,H,W,gain", [(1, 8, 5, 9, 1.0), (2, 12, 6, 19, 50.0), (1, 24, 4, 33, 300.0)])
+def test_out_conv_softargmax_fcs(B, D, H, W, gain):
+  g = Pcl(B, D, H, W, 1, 1, 1)
+  a = rnd(B, 32, D, H, W, seed=1).requires_grad_(True)
+  w = (rnd(1, 32, 3, 3, 3, seed=2, scale=0.03) * gain).requires_grad_(True)
+  b = (rnd(1, seed=3, scale=0.1) * gain).requires_grad_(True)
+  logits_ref = F.conv3d(a, w, b, padding=1).squeeze(1)
+  pred_ref = orc.soft_argmax(logits_ref)
+  gp = rnd(B, H, W, seed=4)
+  gl_in = rnd(B, D, H, W, seed=5, scale=0.1)
+  (pred_ref * gp).sum().backward(retain_graph=True)
+  ga_pred_only = a.grad.clone()
+
+  ab = ops.ncdhw_to_pcl(a.detach().to(DEV), g)
+  wd, bd = w.detach().to(DEV).contiguous(), b.detach().to(DEV)
+  logits = torch.empty(B, D, H, W, device=DEV)
+  nat.call("as_conv3d_out_fwd", nat.ptr(ab), g, nat.ptr(wd), nat.ptr(bd), nat.ptr(logits), nat.stream())
+  close(logits, logits_ref, 3e-6 * max(1.0, gain), 1e-5, "logits")
+
+  # soft-argmax on the ORACLE's logits so that index equality is a statement about this kernel alone
+  lr = logits_ref.detach().to(DEV).contiguous()
+  pred = torch.empty(B, H, W, device=DEV); am = torch.empty(B, H, W, dtype=torch.int32, device=DEV)
+  fcs = torch.empty(B, H, W, device=DEV)
+  nat.call("as_softargmax_fwd", nat.ptr(lr), B, D, H, W, nat.ptr(pred), nat.ptr(am), nat.ptr(fcs), nat.stream())
+  assert torch.equal(am.cpu().long(), torch.argmax(logits_ref.detach(), dim=1)), "arg-max indices must be bit-exact"
+  close(pred, pred_ref, 2e-5, 1e-5, "soft-argmax")
+  close(fcs, orc.feature_contrast_mean(logits_ref.detach()), 1e-5 * max(1.0, gain), 1e-5, "fcs")
+
+  g_logits = torch.empty(B, D, H, W, device=DEV)
+  gpd, gl_ind = gp.to(DEV), gl_in.to(DEV)
+  nat.call("as_softargmax_bwd", nat.ptr(lr), nat.ptr(gpd), nat.ptr(gl_ind), B, D, H, W,
+           nat.ptr(g_logits), nat.stream())
+  l2 = logits_ref.detach().clone().requires_grad_(True)
+  ((orc.soft_argmax(l2) * gp).sum() + (l2 * gl_in).sum()).backward()
+  close(g_logits, l2.grad, 2e-6, 1e-4, "soft-argmax bwd")
+
+  # backward of the 32->1 convolution, driven with the reference's d(pred)/d(logits)
+  a.grad = None; w.grad = None; b.grad = None
+  gl = rnd(B, D, H, W, seed=7)
+  F.conv3d(a, w, b, padding=1).squeeze(1).backward(gl)
+  lib = nat.load()
+  g_a = ops.pcl_zeros(g, DEV); g_w = torch.empty_like(wd); g_b = torch.empty(1, device=DEV)
+  ws = torch.empty(lib.as_conv3d_out_bwd_workspace(g), device=DEV)
+  gld = gl.to(DEV)
+  nat.call("as_conv3d_out_bwd", nat.ptr(gld), nat.ptr(ab), g, nat.ptr(wd), nat.ptr(g_a), nat.ptr(g_w),
+           nat.ptr(g_b), nat.ptr(ws), nat.stream())
+  close(ops.pcl_to_ncdhw(g_a, g), a.grad, 2e-6 * max(1.0, gain), 1e-5, "out-conv dgrad")
+  n = g.voxels()
+  close(g_w, w.grad, 2e-6 * n ** 0.5, 1e-5, "out-conv wgrad")
+  close(g_b, b.grad, 2e-6 * n ** 0.5, 1e-5, "out-conv bias grad")
+  assert ga_pred_only is not None
+
+
+def test_softargmax_ties_and_extremes():
+  """First maximum wins (torch.argmax semantics); large logits must not overflow."""
+  l = torch.zeros(1, 6, 1, 4)
+  l[0, :, 0, 1] = torch.tensor([1.0, 5.0, 5.0, 0.0, 5.0, -1.0])      # three-way tie -> index 1
+  l[0, :, 0, 2] = torch.tensor([-300.0, 200.0, -50.0, 199.0, 0.0, 10.0])
+  l[0, :, 0, 3] = torch.tensor([3e4, -3e4, 0.0, 0.0, 0.0, 0.0])
+  ld = l.to(DEV)
+  pred = torch.empty(1, 1, 4, device=DEV); am = torch.empty(1, 1, 4, dtype=torch.int32, device=DEV)
+  fcs = torch.empty(1, 1, 4, device=DEV)
+  nat.call("as_softargmax_fwd", nat.ptr(ld), 1, 6, 1, 4, nat.ptr(pred), nat.ptr(am), nat.ptr(fcs), nat.stream())
+  assert am.cpu().flatten().tolist() == torch.argmax(l, dim=1).flatten().tolist()
+  close(pred, orc.soft_argmax(l), 1e-5, 1e-5, "soft-argmax extremes")
+  close(fcs, orc.feature_contrast_mean(l), 1e-2, 1e-6, "fcs extremes")
+  assert bool(torch.isfinite(pred).all())
+
+
+# ----------------------------------------------------------------------------- a6
+@pytest.mark.parametrize("B,h,w,H,W", [(1, 3, 4, 24, 32), (2, 24, 78, 375, 1242), (1, 10, 17, 75, 131), (1, 1, 1, 5, 7)])
+def test_upsample_bilinear(B, h, w, H, W):
+  src = rnd(B, h, w, seed=1).requires_grad_(True)
+  gain = W / w
+  ref = F.interpolate(src.unsqueeze(1), size=(H, W), mode="bilinear", align_corners=False) * gain
+  gd = rnd(B, 1, H, W, seed=2)
+  ref.backward(gd)
+  s = src.detach().to(DEV).requires_grad_(True)
+  out = ops.UpsampleBilinearFn.apply(s, H, W, gain)
+  close(out, ref, 2e-6 * gain, 1e-5, "upsample fwd")
+  out.backward(gd.to(DEV))
+  close(s.grad, src.grad, 3e-4 * gain, 1e-4, "upsample bwd")
+
+
+# ----------------------------------------------------------------------------- a9
+@pytest.mark.parametrize("r2l", [True, False])
+@pytest.mark.parametrize("B,H,W", [(1, 9, 17), (2, 33, 70)])
+def test_linear_warp(B, H, W, r2l):
+  img = rnd(B, 3, H, W, seed=1) * 0.5 + 0.5
+  disp = (rnd(B, 1, H, W, seed=2) * 6.0 + 4.0)          # includes negatives and out-of-image targets
+  disp[:, :, 0, :3] = 0.0
+  d = disp.clone().requires_grad_(True)
+  warped_ref, mask_ref = orc.linear_warp(img, d, r2l)
+  gw = rnd(B, 3, H, W, seed=3)
+  warped_ref.backward(gw)
+  dd = disp.to(DEV).requires_grad_(True)
+  warped, mask = ops.LinearWarpFn.apply(img.to(DEV), dd, r2l)
+  assert torch.equal(mask.cpu(), mask_ref), "validity mask must be exact"
+  close(warped, warped_ref, 2e-6, 1e-5, "warp fwd")
+  warped.backward(gw.to(DEV))
+  close(dd.grad, d.grad, 2e-5, 1e-4, "warp bwd")
+
+
+# ----------------------------------------------------------------------------- a10
+@pytest.mark.parametrize("B,H,W", [(1, 8, 11), (2, 37, 53)])
+def test_monodepth_loss_fwd_bwd(B, H, W):
+  img = rnd(B, 3, H, W, seed=1) * 0.5 + 0.5
+  warped = (img + rnd(B, 3, H, W, seed=2) * 0.2).clamp(0, 1)
+  pred = rnd(B, 1, H, W, seed=3).abs() * 20 + 1
+  p = pred.clone().requires_grad_(True); wv = warped.clone().requires_grad_(True)
+  ref = orc.monodepth_loss(p, img, wv, 1e-3)
+  gs = [rnd(B, 1, H, W, seed=10 + i) for i in range(4)]
+  sum((r * g).sum() for r, g in zip(ref, gs)).backward()
+
+  pd = pred.to(DEV).requires_grad_(True); wd = warped.to(DEV).requires_grad_(True)
+  out = ops.MonodepthLossFn.apply(pd, img.to(DEV), wd, 1e-3)
+  for name, o, r in zip(("total", "l1", "ssim", "smooth"), out, ref):
+    close(o, r, 3e-6, 2e-5, "monodepth " + name)
+  sum((o * g.to(DEV)).sum() for o, g in zip(out, gs)).backward()
+  close(wd.grad, wv.grad, 1e-5 + 1e-4 * float(wv.grad.abs().max()), 1e-3, "monodepth g_warped")
+  close(pd.grad, p.grad, 1e-6 + 1e-4 * float(p.grad.abs().max()), 1e-3, "monodepth g_pred")
+
+
+def test_masked_mean_matches_boolean_index_mean():
+  v = rnd(2, 1, 37, 53, seed=1).requires_grad_(True)
+  m = rnd(2, 1, 37, 53, seed=2) > 0.3
+  ref = v[m].mean(); ref.backward()
+  vd = v.detach().to(DEV).requires_grad_(True)
+  out = ops.masked_mean(vd, m.to(DEV))
+  close(out, ref, 1e-6, 1e-5, "masked mean")
+  out.backward()
+  close(vd.grad, v.grad, 1e-9, 1e-5, "masked mean grad")
+
+
+# ----------------------------------------------------------------------------- a12
+def test_sumsq_and_adam_step():
+  n = 313698
+  p, g = rnd(n, seed=1), rnd(n, seed=2, scale=1e-2)
+  lib = nat.load()
+  gd = g.to(DEV)
+  out = torch.empty(1, device=DEV); ws = torch.empty(lib.as_sumsq_workspace(n), device=DEV)
+  nat.call("as_sumsq", nat.ptr(gd), n, nat.ptr(out), nat.ptr(ws), nat.stream())
+  close(out, (g.double() ** 2).sum().float().view(1), 0, 1e-6, "sumsq")
+
+  pr, state = p.clone(), {}
+  pd = p.to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+  coef = torch.tensor([0.37], device=DEV)
+  for step in (1, 2, 3):
+    orc.adam_step(pr, g * 0.37, state, 5e-5)
+    nat.call("as_adam_step", nat.ptr(pd), nat.ptr(gd), nat.ptr(m), nat.ptr(v), n, nat.ptr(coef), 5e-5, 0.9, 0.999,
+             1e-8, step, nat.stream())
+  close(pd, pr, 1e-7, 1e-6, "adam params")
+  close(m, state["exp_avg"], 1e-9, 1e-5, "adam m"); close(v, state["exp_avg_sq"], 1e-12, 1e-5, "adam v")
