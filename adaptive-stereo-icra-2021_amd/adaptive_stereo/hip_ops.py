@@ -47,6 +47,34 @@ def _empty(n, device, dtype=torch.float32):
   return torch.empty(int(n), dtype=dtype, device=device)
 
 
+class PclPool(object):
+  """Recycles PCL buffers.  Kernels only ever write the interior of a PCL tensor, so a buffer
+  that was allocated zero-filled keeps a zero halo for life and can be handed out again without
+  a memset (a full-resolution activation is 60 MB per pair: clearing ~30 of them per step would
+  cost more HBM traffic than the soft-argmax path moves in total)."""
+
+  def __init__(self):
+    self.free = {}
+
+  def get(self, g: Pcl, device, channels=32):
+    key = (str(device), g.key(), channels)
+    lst = self.free.get(key)
+    if lst:
+      return lst.pop()
+    return torch.zeros(g.numel() // 32 * channels, dtype=torch.float32, device=device)
+
+  def put(self, buf, g: Pcl, channels=32):
+    if buf is None:
+      return
+    self.free.setdefault((str(buf.device), g.key(), channels), []).append(buf)
+
+  def clear(self):
+    self.free.clear()
+
+
+POOL = PclPool()
+
+
 # ----------------------------------------------------------------------------------------
 # Thin call helpers
 # ----------------------------------------------------------------------------------------
@@ -60,7 +88,7 @@ def pack_weights(w, shape: ConvShape, transpose_flip: bool):
 def conv32(x, gin: Pcl, packed_w, bias, gout: Pcl, shape: ConvShape, out=None, epilogue=0, scale=None,
            shift=None, residual=None, stats=None):
   """Returns the PCL output buffer. ``stats`` = (mean_partials, m2_partials) to fill."""
-  z = out if out is not None else pcl_zeros(gout, x.device)
+  z = out if out is not None else POOL.get(gout, x.device)
   sm, s2 = stats if stats is not None else (None, None)
   call("as_conv32_fwd", ptr(x), gin, ptr(packed_w), ptr(bias), ptr(z), gout, shape, int(epilogue),
        ptr(scale), ptr(shift), LEAKY_SLOPE, ptr(residual), ptr(sm), ptr(s2), stream())
@@ -106,7 +134,7 @@ def bn_eval_stats(gamma, beta, running_mean, running_var):
 
 
 def bn_act(z, st: BnState, g: Pcl, residual=None, out=None):
-  a = out if out is not None else pcl_zeros(g, z.device)
+  a = out if out is not None else POOL.get(g, z.device)
   call("as_bn_act_fwd", ptr(z), ptr(st.scale), ptr(st.shift), LEAKY_SLOPE, ptr(residual), ptr(a), g, stream())
   return a
 
@@ -114,12 +142,58 @@ def bn_act(z, st: BnState, g: Pcl, residual=None, out=None):
 def bn_act_bwd(g_a, z, st: BnState, gamma, g: Pcl, train: bool):
   lib = nat.load()
   dev = z.device
-  g_z = pcl_zeros(g, dev)
+  g_z = POOL.get(g, dev)
   g_gamma, g_beta = _empty(32, dev), _empty(32, dev)
   ws = _empty(lib.as_bn_bwd_workspace(g), dev)
   call("as_bn_act_bwd", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
        LEAKY_SLOPE, int(train), ptr(g_z), ptr(g_gamma), ptr(g_beta), ptr(ws), g, stream())
   return g_z, g_gamma, g_beta
+
+
+# ----------------------------------------------------------------------------------------
+# conv -> BatchNorm -> LeakyReLU (-> + skip) blocks on PCL tensors: shared by the 3-D aggregation
+# (stereo_net.py:155-161), the feature extractor's and the refinement's BasicBlocks (:33-51)
+# ----------------------------------------------------------------------------------------
+def conv_shape_2d(dilation=1):
+  pad = dilation if dilation > 1 else 1
+  return ConvShape(1, 3, 3, 0, pad, pad, dilation, 1)
+
+
+def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train, skip, keep_z):
+  """Returns (z or None, a, BnState).  train: batch statistics (+ running-stat update);
+  otherwise running statistics, fused into the convolution epilogue when z is not needed."""
+  dev = x.device
+  wp = pack_weights(w, shape, False)
+  if train:
+    nblocks = nat.load().as_conv32_num_blocks(g)
+    stats = (_empty(nblocks * 32, dev), _empty(nblocks * 32, dev))
+    z = conv32(x, g, wp, b, g, shape, stats=stats)
+    st = bn_train_stats(stats, g.voxels(), gamma, beta, rm, rv, nblocks)
+    a = bn_act(z, st, g, residual=x if skip else None)
+  else:
+    st = bn_eval_stats(gamma, beta, rm, rv)
+    if keep_z:
+      z = conv32(x, g, wp, b, g, shape)
+      a = bn_act(z, st, g, residual=x if skip else None)
+    else:
+      z = None
+      a = conv32(x, g, wp, b, g, shape, epilogue=1, scale=st.scale, shift=st.shift, residual=x if skip else None)
+  if not keep_z and z is not None:
+    POOL.put(z, g); z = None
+  return z, a, st
+
+
+def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx):
+  """g_out: gradient w.r.t. the block output (PCL).  Returns (g_x or None, dW, db, g_gamma, g_beta).
+  With a skip connection g_x = g_out + dgrad(...) — the add is fused into the dgrad epilogue."""
+  g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train)
+  dW, db = conv32_wgrad(x, g, g_z, g, shape)
+  g_x = None
+  if need_dx:
+    wp_t = pack_weights(w, shape, True)
+    g_x = conv32(g_z, g, wp_t, None, g, shape, residual=g_out if skip else None)
+  POOL.put(g_z, g)
+  return g_x, dW, db, g_gamma, g_beta
 
 
 # ----------------------------------------------------------------------------------------
@@ -142,37 +216,19 @@ class CostAggregationFn(torch.autograd.Function):
     D = int(num_disp)
     g = Pcl(B, D, H, W, 1, 1, 1)
     need_bwd = any(ctx.needs_input_grad)
-    count = g.voxels()
-    nblocks = nat.load().as_conv32_num_blocks(g)
 
-    vol = pcl_zeros(g, dev)
+    vol = POOL.get(g, dev)
     call("as_cost_volume_fwd", ptr(fl), ptr(fr), ptr(vol), g, stream())
-
-    x = vol
     xs, zs, sts = [vol], [], []
     for l in range(4):
       w, b, gamma, beta = params[4 * l:4 * l + 4]
       rm, rv = bn_buffers[l]
-      wp = pack_weights(w, CONV3D_333, False)
-      if train:
-        stats = (_empty(nblocks * 32, dev), _empty(nblocks * 32, dev))
-        z = conv32(x, g, wp, b, g, CONV3D_333, stats=stats)
-        st = bn_train_stats(stats, count, gamma, beta, rm, rv, nblocks)
-        a = bn_act(z, st, g)
-      else:
-        st = bn_eval_stats(gamma, beta, rm, rv)
-        if need_bwd:
-          z = conv32(x, g, wp, b, g, CONV3D_333)
-          a = bn_act(z, st, g)
-        else:
-          z = None    # eval inference: BatchNorm + LeakyReLU fused into the conv epilogue
-          a = conv32(x, g, wp, b, g, CONV3D_333, epilogue=1, scale=st.scale, shift=st.shift)
+      z, a, st = block_forward(xs[-1], g, CONV3D_333, w, b, gamma, beta, rm, rv, train, False, need_bwd)
       zs.append(z); sts.append(st); xs.append(a)
-      x = a
 
     w_out, b_out = params[16], params[17]
     logits = torch.empty(B, D, H, W, dtype=torch.float32, device=dev)
-    call("as_conv3d_out_fwd", ptr(x), g, ptr(w_out), ptr(b_out), ptr(logits), stream())
+    call("as_conv3d_out_fwd", ptr(xs[4]), g, ptr(w_out), ptr(b_out), ptr(logits), stream())
     pred = torch.empty(B, H, W, dtype=torch.float32, device=dev)
     argmax = torch.empty(B, H, W, dtype=torch.int32, device=dev)
     fcs = torch.empty(B, H, W, dtype=torch.float32, device=dev)
@@ -183,6 +239,9 @@ class CostAggregationFn(torch.autograd.Function):
       ctx.train = bool(train)
       ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
       ctx.save_for_backward(logits, *params)
+    else:
+      for buf in xs:
+        POOL.put(buf, g)
     ctx.mark_non_differentiable(argmax, fcs)
     return logits, pred, argmax, fcs
 
@@ -193,6 +252,7 @@ class CostAggregationFn(torch.autograd.Function):
     dev = logits.device
     B, D, H, W = logits.shape
     lib = nat.load()
+    xs, zs, sts = ctx.xs, ctx.zs, ctx.sts
 
     g_logits = torch.empty_like(logits)
     g_pred, g_logits_in = f32c(g_pred), f32c(g_logits_in)      # keep any contiguous copies alive past the launch
@@ -200,30 +260,231 @@ class CostAggregationFn(torch.autograd.Function):
 
     grads = [None] * 18
     w_out = params[16]
-    g_a = pcl_zeros(g, dev)
+    g_a = POOL.get(g, dev)
     g_wout = torch.empty_like(w_out)
     g_bout = _empty(1, dev)
     ws = _empty(lib.as_conv3d_out_bwd_workspace(g), dev)
-    call("as_conv3d_out_bwd", ptr(g_logits), ptr(ctx.xs[4]), g, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout),
+    call("as_conv3d_out_bwd", ptr(g_logits), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout),
          ptr(ws), stream())
     grads[16], grads[17] = g_wout, g_bout
 
     need_feat = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
     for l in range(3, -1, -1):
       w, b, gamma, beta = params[4 * l:4 * l + 4]
-      g_z, g_gamma, g_beta = bn_act_bwd(g_a, ctx.zs[l], ctx.sts[l], gamma, g, ctx.train)
-      dW, db = conv32_wgrad(ctx.xs[l], g, g_z, g, CONV3D_333)
+      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], w, gamma, g, CONV3D_333, ctx.train,
+                                                    False, l > 0 or need_feat)
       grads[4 * l:4 * l + 4] = [dW, db, g_gamma, g_beta]
-      if l > 0 or need_feat:
-        wp_t = pack_weights(w, CONV3D_333, True)
-        g_a = conv32(g_z, g, wp_t, None, g, CONV3D_333)
+      POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
+      g_a = g_x
     g_fl = g_fr = None
     if need_feat:
       g_fl = torch.empty(B, 32, H, W, dtype=torch.float32, device=dev)
       g_fr = torch.empty_like(g_fl)
       call("as_cost_volume_bwd", ptr(g_a), ptr(g_fl), ptr(g_fr), g, stream())
+      POOL.put(g_a, g)
+    POOL.put(xs[0], g)
     ctx.xs = ctx.zs = ctx.sts = None
     return (g_fl, g_fr, None, None, None) + tuple(grads)
+
+
+# ----------------------------------------------------------------------------------------
+# a1 trunk: six BasicBlocks + conv_alone of FeatureExtractorNetwork (stereo_net.py:70-77, 83-85)
+# ----------------------------------------------------------------------------------------
+class FeatureTrunkFn(torch.autograd.Function):
+  """x [B,32,H,W] (NCHW, the output of the strided convolutions) -> features [B,32,H,W].
+  params: 6 x (conv w, conv b, bn w, bn b), then conv_alone (w, b)."""
+
+  @staticmethod
+  def forward(ctx, x, train, bn_buffers, *params):
+    assert len(params) == 26
+    x = f32c(x)
+    params = [f32c(p) for p in params]
+    B, C, H, W = x.shape
+    dev = x.device
+    g = Pcl(B, 1, H, W, 0, 1, 1)
+    shape = conv_shape_2d(1)
+    need_bwd = any(ctx.needs_input_grad)
+    x0 = POOL.get(g, dev)
+    pcl_interior(x0, g).copy_(x.permute(0, 2, 3, 1).unsqueeze(1))
+    xs, zs, sts = [x0], [], []
+    for l in range(6):
+      w, b, gamma, beta = params[4 * l:4 * l + 4]
+      rm, rv = bn_buffers[l]
+      z, a, st = block_forward(xs[-1], g, shape, w, b, gamma, beta, rm, rv, train, True, need_bwd)
+      zs.append(z); sts.append(st); xs.append(a)
+    wp = pack_weights(params[24], shape, False)
+    out = conv32(xs[6], g, wp, params[25], g, shape)
+    feats = pcl_interior(out, g)[:, 0].permute(0, 3, 1, 2).contiguous()
+    POOL.put(out, g)
+    if need_bwd:
+      ctx.g, ctx.train = g, bool(train)
+      ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
+      ctx.save_for_backward(*params)
+    else:
+      for buf in xs:
+        POOL.put(buf, g)
+    return feats
+
+  @staticmethod
+  def backward(ctx, g_feats):
+    params = ctx.saved_tensors
+    g, xs, zs, sts = ctx.g, ctx.xs, ctx.zs, ctx.sts
+    dev = g_feats.device
+    shape = conv_shape_2d(1)
+    grads = [None] * 26
+    g_out = POOL.get(g, dev)
+    pcl_interior(g_out, g).copy_(g_feats.permute(0, 2, 3, 1).unsqueeze(1))
+    dW, db = conv32_wgrad(xs[6], g, g_out, g, shape)
+    grads[24], grads[25] = dW, db
+    g_a = conv32(g_out, g, pack_weights(params[24], shape, True), None, g, shape)
+    POOL.put(g_out, g)
+    for l in range(5, -1, -1):
+      w, b, gamma, beta = params[4 * l:4 * l + 4]
+      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], w, gamma, g, shape, ctx.train, True,
+                                                    True)
+      grads[4 * l:4 * l + 4] = [dW, db, g_gamma, g_beta]
+      POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
+      g_a = g_x
+    g_x = pcl_interior(g_a, g)[:, 0].permute(0, 3, 1, 2).contiguous() if ctx.needs_input_grad[0] else None
+    POOL.put(g_a, g); POOL.put(xs[0], g)
+    ctx.xs = ctx.zs = ctx.sts = None
+    return (g_x, None, None) + tuple(grads)
+
+
+# ----------------------------------------------------------------------------------------
+# a7: EdgeAwareRefinement (stereo_net.py:88-121), whole module in PCL, forward and backward
+# ----------------------------------------------------------------------------------------
+REFINE_DILATIONS = (1, 2, 4, 8, 1, 1)
+REFINE_HALO = 8
+
+
+class EdgeRefineFn(torch.autograd.Function):
+  """coarse [B,h,w], guidance rgb [B,3,H,W] -> refined disparity [B,1,H,W].
+  params: conv2d_feature (w[32,4,3,3], b, bn w, bn b), 6 x (w[32,32,3,3], b, bn w, bn b), conv2d_out (w[1,32,3,3], b)."""
+
+  @staticmethod
+  def forward(ctx, coarse, rgb, train, bn_buffers, *params):
+    assert len(params) == 30
+    coarse, rgb = f32c(coarse), f32c(rgb)
+    params = [f32c(p) for p in params]
+    B, h, w = coarse.shape
+    _, C, H, W = rgb.shape
+    if C != 3 or rgb.shape[0] != B:
+      raise RuntimeError("EdgeRefineFn: guidance image must be [B,3,H,W]")
+    dev = rgb.device
+    lib = nat.load()
+    need_bwd = any(ctx.needs_input_grad)
+    gain = W / w                                     # float ratio (stereo_net.py:113)
+    g = Pcl(B, 1, H, W, 0, REFINE_HALO, REFINE_HALO)
+    g4 = Pcl(B, 1, H, W, 0, 1, 1)
+    s33 = conv_shape_2d(1)
+
+    up = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+    call("as_upsample_bilinear_fwd", ptr(coarse), B, h, w, ptr(up), H, W, float(gain), stream())
+    in4 = POOL.get(g4, dev, channels=4)
+    call("as_pack_in4", ptr(up), ptr(rgb), 3, ptr(in4), g4, stream())
+
+    # conv2d_feature: 4 -> 32, BatchNorm, LeakyReLU
+    w0, b0, gamma0, beta0 = params[0:4]
+    rm0, rv0 = bn_buffers[0]
+    wp4 = _empty(9 * 128, dev)
+    call("as_conv4_pack_weights", ptr(w0), 4, ptr(wp4), s33, stream())
+    nblocks = lib.as_conv32_num_blocks(g)
+    if train:
+      stats = (_empty(nblocks * 32, dev), _empty(nblocks * 32, dev))
+      z0 = POOL.get(g, dev)
+      call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(z0), g, s33, 0, None, None, LEAKY_SLOPE,
+           ptr(stats[0]), ptr(stats[1]), stream())
+      st0 = bn_train_stats(stats, g.voxels(), gamma0, beta0, rm0, rv0, nblocks)
+      a0 = bn_act(z0, st0, g)
+    else:
+      st0 = bn_eval_stats(gamma0, beta0, rm0, rv0)
+      if need_bwd:
+        z0 = POOL.get(g, dev)
+        call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(z0), g, s33, 0, None, None, LEAKY_SLOPE, None, None,
+             stream())
+        a0 = bn_act(z0, st0, g)
+      else:
+        z0 = None
+        a0 = POOL.get(g, dev)
+        call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(a0), g, s33, 1, ptr(st0.scale), ptr(st0.shift),
+             LEAKY_SLOPE, None, None, stream())
+    if not need_bwd and z0 is not None:
+      POOL.put(z0, g); z0 = None
+
+    xs, zs, sts = [a0], [], []
+    for l, dil in enumerate(REFINE_DILATIONS):
+      wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
+      rm, rv = bn_buffers[1 + l]
+      z, a, st = block_forward(xs[-1], g, conv_shape_2d(dil), wl, bl, gamma, beta, rm, rv, train, True, need_bwd)
+      zs.append(z); sts.append(st); xs.append(a)
+      if not need_bwd:
+        POOL.put(xs[-2], g)
+
+    w_out, b_out = params[28], params[29]
+    out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+    call("as_conv32to1_fwd", ptr(xs[-1]), g, s33, ptr(w_out), ptr(b_out), ptr(up), 1, ptr(out), stream())
+
+    if need_bwd:
+      ctx.g, ctx.g4, ctx.train = g, g4, bool(train)
+      ctx.dims = (B, h, w, H, W, float(gain))
+      ctx.in4, ctx.z0, ctx.st0 = in4, z0, st0
+      ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
+      ctx.save_for_backward(out, *params)
+    else:
+      POOL.put(xs[-1], g); POOL.put(in4, g4, channels=4)
+    return out
+
+  @staticmethod
+  def backward(ctx, g_out):
+    out, *params = ctx.saved_tensors
+    g, g4 = ctx.g, ctx.g4
+    B, h, w, H, W, gain = ctx.dims
+    dev = out.device
+    lib = nat.load()
+    s33 = conv_shape_2d(1)
+    xs, zs, sts = ctx.xs, ctx.zs, ctx.sts
+    grads = [None] * 30
+
+    g_pre = (f32c(g_out) * (out > 0)).contiguous()            # through the final ReLU (stereo_net.py:121)
+    w_out = params[28]
+    g_a = POOL.get(g, dev)
+    g_wout, g_bout = torch.empty_like(w_out), _empty(1, dev)
+    ws = _empty(lib.as_conv32to1_bwd_workspace(g, s33), dev)
+    call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout), ptr(ws),
+         stream())
+    grads[28], grads[29] = g_wout, g_bout
+
+    for l in range(5, -1, -1):
+      wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
+      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], wl, gamma, g,
+                                                    conv_shape_2d(REFINE_DILATIONS[l]), ctx.train, True, True)
+      grads[4 + 4 * l:8 + 4 * l] = [dW, db, g_gamma, g_beta]
+      POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
+      g_a = g_x
+
+    # conv2d_feature backward
+    w0, b0, gamma0, beta0 = params[0:4]
+    g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train)
+    dW0 = torch.empty_like(w0); db0 = _empty(32, dev)
+    ws4 = _empty(lib.as_conv4_wgrad_workspace(g, s33), dev)
+    call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(dW0), ptr(db0), ptr(ws4), stream())
+    grads[0:4] = [dW0, db0, g_gamma0, g_beta0]
+
+    g_coarse = None
+    if ctx.needs_input_grad[0]:
+      # d/d(up-sampled disparity) = direct path (g_pre) + conv2d_feature's data gradient for input
+      # channel 0, which is a 32->1 convolution of g_z0 with mirrored taps; the add is fused.
+      w_ch0 = w0[:, 0].flip(-1, -2).reshape(32, 9).contiguous()
+      g_up = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+      call("as_conv32to1_fwd", ptr(g_z0), g, s33, ptr(w_ch0), None, ptr(g_pre), 0, ptr(g_up), stream())
+      g_coarse = torch.empty(B, h, w, dtype=torch.float32, device=dev)
+      call("as_upsample_bilinear_bwd", ptr(g_up), B, H, W, ptr(g_coarse), h, w, gain, stream())
+    if ctx.needs_input_grad[1]:
+      raise NotImplementedError("EdgeRefineFn: gradient w.r.t. the guidance image is not part of the adaptation path")
+    POOL.put(g_z0, g); POOL.put(g_a, g); POOL.put(ctx.z0, g); POOL.put(xs[0], g); POOL.put(ctx.in4, g4, channels=4)
+    ctx.xs = ctx.zs = ctx.sts = ctx.in4 = ctx.z0 = None
+    return (g_coarse, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------

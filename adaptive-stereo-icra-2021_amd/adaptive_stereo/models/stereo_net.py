@@ -11,14 +11,13 @@ Drop-in surface (reference: adaptive_stereo/models/stereo_net.py):
 The modules below are parameter containers: their nested ModuleLists exist to reproduce
 the reference's key names.  ``forward`` never calls an nn.Conv3d/BatchNorm3d: the cost
 volume, the 3-D aggregation, the soft-argmax, the up-sampling and their backward passes
-run as hand-written HIP kernels behind ``libadaptive_stereo_hip.so`` (hip_ops.py).  The
-2-D convolutions of the feature extractor and of the edge-aware refinement are issued
-through MIOpen in this revision ("MIOpen first").
+run as hand-written HIP kernels behind ``libadaptive_stereo_hip.so`` (hip_ops.py), and so do
+the edge-aware refinement (a7) and the feature extractor's residual trunk (a1).  Only the k
+strided 5x5 convolutions at the head of the feature extractor are still issued through MIOpen.
 There is no CPU path: tensors must be on the GPU and the HIP library must be built.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import _native as nat
 from .. import hip_ops
@@ -45,8 +44,9 @@ class _ConvBN(nn.ModuleList):
 
 
 class _ResidualBlock2d(nn.Module):
-  """x + LeakyReLU(BN(Conv3x3_dilated(x))).  ``conv2`` holds parameters the reference
-  allocates but never uses (stereo_net.py:40, 44-51); they receive no gradient."""
+  """Parameters of x + LeakyReLU(BN(Conv3x3_dilated(x))).  ``conv2`` holds tensors the reference
+  allocates but never uses (stereo_net.py:40, 44-51); they receive no gradient.  The arithmetic
+  lives in hip_ops.block_forward / block_backward."""
 
   def __init__(self, dilation):
     super().__init__()
@@ -54,14 +54,21 @@ class _ResidualBlock2d(nn.Module):
     self.conv1 = nn.ModuleList([_ConvBN(2, 32, 32, 3, dilation)])
     self.conv2 = _ConvBN(2, 32, 32, 3, dilation)
 
-  def forward(self, x):
-    cb = self.conv1[0]
-    y = F.conv2d(x, cb.conv.weight, cb.conv.bias, 1, cb.conv.padding, cb.conv.dilation)
-    y = F.batch_norm(y, cb.bn.running_mean, cb.bn.running_var, cb.bn.weight, cb.bn.bias,
-                     self.training, cb.bn.momentum, cb.bn.eps)
-    if self.training:
-      cb.bn.num_batches_tracked += 1
-    return x + F.leaky_relu(y, LEAKY_SLOPE)
+  def live(self):
+    return self.conv1[0]
+
+
+def _block_params(blocks):
+  params, buffers = [], []
+  for cb in blocks:
+    params += [cb.conv.weight, cb.conv.bias, cb.bn.weight, cb.bn.bias]
+    buffers.append((cb.bn.running_mean, cb.bn.running_var))
+  return params, buffers
+
+
+def _count_batches(blocks):
+  for cb in blocks:
+    cb.bn.num_batches_tracked += 1
 
 
 class FeatureExtractorNetwork(nn.Module):
@@ -76,11 +83,15 @@ class FeatureExtractorNetwork(nn.Module):
   def forward(self, rgb_img):
     nat.require_gpu(rgb_img)
     x = rgb_img
-    for conv in self.downsample:          # no activation between the strided convs (:81-82)
+    for conv in self.downsample:          # no activation between the strided convs (:81-82); MIOpen for now
       x = conv(x)
-    for block in self.residual_blocks:
-      x = block(x)
-    return self.conv_alone(x)
+    live = [b.live() for b in self.residual_blocks]
+    params, buffers = _block_params(live)
+    params += [self.conv_alone.weight, self.conv_alone.bias]
+    out = hip_ops.FeatureTrunkFn.apply(x, self.training, buffers, *params)
+    if self.training:
+      _count_batches(live)
+    return out
 
 
 class EdgeAwareRefinement(nn.Module):
@@ -91,19 +102,13 @@ class EdgeAwareRefinement(nn.Module):
     self.conv2d_out = nn.Conv2d(32, 1, kernel_size=3, stride=1, padding=1)
 
   def forward(self, coarse_disparity, guidance_rgb):
-    H, W = guidance_rgb.shape[-2:]
-    gain = W / coarse_disparity.shape[-1]          # float ratio, e.g. 1242/78 (:113)
-    up = hip_ops.UpsampleBilinearFn.apply(coarse_disparity, H, W, gain)
-    cb = self.conv2d_feature[0]
-    x = F.conv2d(torch.cat([up, guidance_rgb], dim=1), cb.conv.weight, cb.conv.bias, 1, 1)
-    x = F.batch_norm(x, cb.bn.running_mean, cb.bn.running_var, cb.bn.weight, cb.bn.bias,
-                     self.training, cb.bn.momentum, cb.bn.eps)
+    live = [self.conv2d_feature[0]] + [b.live() for b in self.residual_astrous_blocks]
+    params, buffers = _block_params(live)
+    params += [self.conv2d_out.weight, self.conv2d_out.bias]
+    out = hip_ops.EdgeRefineFn.apply(coarse_disparity, guidance_rgb, self.training, buffers, *params)
     if self.training:
-      cb.bn.num_batches_tracked += 1
-    x = F.leaky_relu(x, LEAKY_SLOPE)
-    for block in self.residual_astrous_blocks:
-      x = block(x)
-    return F.relu(up + self.conv2d_out(x))
+      _count_batches(live)
+    return out
 
 
 class DisparityRegression(nn.Module):

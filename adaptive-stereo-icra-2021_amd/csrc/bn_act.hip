@@ -9,34 +9,46 @@
 // All element-wise passes are HBM-bound: float4 per lane over the PCL interior.
 #include "as_common.h"
 
-// ---- finalize: one workgroup, 256 threads = 8 slices x 32 channels -----------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+// ---- finalize: one workgroup, 1024 threads = 32 slices x 32 channels ---------------------
+// Exact merge of the per-workgroup (n, mean, M2) triples in fp64, in two division-free passes:
+//   mean = sum n_i*mean_i / N;   M2 = sum [ M2_i + n_i*(mean_i - mean)^2 ].
+// (Every partial covers 128 voxels except the last.)  Reads are 128-byte rows, fixed order.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* __restrict__ stat_mean, const float* __restrict__ stat_m2, int nblocks, long count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
     float momentum, float eps, float* save_mean, float* save_invstd, float* scale, float* shift) {
-  __shared__ double sn[8][32], smean[8][32], sm2[8][32];
+  __shared__ double red[32][33];
+  __shared__ double smean[32];
   const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int i = sl; i < nblocks; i += 8) {
-    const long first = (long)i * 128;
-    const double nb = (double)((count - first) < 128 ? (count - first) : 128);
-    const double mb = (double)stat_mean[i * 32 + c], qb = (double)stat_m2[i * 32 + c];
-    const double tot = n + nb, delta = mb - mean;
-    mean += delta * (nb / tot);
-    m2 += qb + delta * delta * (n * nb / tot);
-    n = tot;
+  double s = 0.0;
+  for (int i = sl; i < nblocks; i += 32) {
+    const long left = count - (long)i * 128;
+    const double nb = (double)(left < 128 ? left : 128);
+    s += nb * (double)stat_mean[i * 32 + c];
   }
-  sn[sl][c] = n; smean[sl][c] = mean; sm2[sl][c] = m2;
+  red[sl][c] = s;
   __syncthreads();
   if (sl == 0) {
-    for (int j = 1; j < 8; ++j) {
-      const double nb = sn[j][c];
-      if (nb == 0.0) continue;
-      const double tot = n + nb, delta = smean[j][c] - mean;
-      mean += delta * (nb / tot);
-      m2 += sm2[j][c] + delta * delta * (n * nb / tot);
-      n = tot;
-    }
+    double t = 0.0;
+    for (int j = 0; j < 32; ++j) t += red[j][c];
+    smean[c] = t / (double)count;
+  }
+  __syncthreads();
+  const double mean = smean[c];
+  double q = 0.0;
+  for (int i = sl; i < nblocks; i += 32) {
+    const long left = count - (long)i * 128;
+    const double nb = (double)(left < 128 ? left : 128);
+    const double dm = (double)stat_mean[i * 32 + c] - mean;
+    q += (double)stat_m2[i * 32 + c] + nb * dm * dm;
+  }
+  __syncthreads();
+  red[sl][c] = q;
+  __syncthreads();
+  if (sl == 0) {
+    double m2 = 0.0;
+    for (int j = 0; j < 32; ++j) m2 += red[j][c];
+    const double n = (double)count;
     const double var_b = m2 / n;
     const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
     const float meanf = (float)mean;
@@ -136,24 +148,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// stage 2: fixed-order sum of the slabs; emits g_gamma, g_beta and the per-channel
-// coefficients of stage 3:  g_z = (g_y - k1 - (z-mean)*k2) * k3.
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long count,
-                                       const float* __restrict__ invstd, const float* __restrict__ gamma, int train,
-                                       float* g_gamma, float* g_beta, float* coef) {
-  const int c = threadIdx.x;
-  if (c >= 32) return;
-  double sdy = 0.0, sdx = 0.0;
-  for (int i = 0; i < nblocks; ++i) {
-    sdy += partial[(long)i * 64 + c];
-    sdx += partial[(long)i * 64 + 32 + c];
+// stage 2: fixed-order sum of the slabs (256 threads = 4 slices x 64 sums); emits g_gamma, g_beta and
+// the per-channel coefficients of stage 3:  g_z = (g_y - k1 - (z-mean)*k2) * k3.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long count,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               int train, float* g_gamma, float* g_beta, float* coef) {
+  __shared__ double red[4][64];
+  const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int i = sl; i < nblocks; i += 4) s += partial[(long)i * 64 + j];
+  red[sl][j] = s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int c = threadIdx.x;
+    const double sdy = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    const double sdx = red[0][32 + c] + red[1][32 + c] + red[2][32 + c] + red[3][32 + c];
+    const double is = (double)invstd[c];
+    g_gamma[c] = (float)(sdx * is);
+    g_beta[c] = (float)sdy;
+    coef[c] = train ? (float)(sdy / (double)count) : 0.f;
+    coef[32 + c] = train ? (float)(sdx * is * is / (double)count) : 0.f;
+    coef[64 + c] = invstd[c] * gamma[c];
   }
-  const double is = (double)invstd[c];
-  g_gamma[c] = (float)(sdx * is);
-  g_beta[c] = (float)sdy;
-  coef[c] = train ? (float)(sdy / (double)count) : 0.f;
-  coef[32 + c] = train ? (float)(sdx * is * is / (double)count) : 0.f;
-  coef[64 + c] = invstd[c] * gamma[c];
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g_a, const float* __restrict__ z,
@@ -203,7 +219,7 @@ extern "C" int as_bn_finalize(const float* stat_mean, const float* stat_m2, int 
   AS_CHECK_ARG(nblocks >= 1 && count >= 1 && (int64_t)nblocks == (count + 127) / 128,
                "as_bn_finalize: nblocks=%d inconsistent with count=%lld", nblocks, (long long)count);
   AS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "as_bn_finalize: running stats must pair");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stat_mean, stat_m2, nblocks,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stat_mean, stat_m2, nblocks,
                      (long)count, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                      scale, shift);
   AS_CHECK_LAUNCH("as_bn_finalize");
@@ -262,7 +278,7 @@ extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scal
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g_a, z, scale, shift, save_mean, slope,
                      partial, gd, M);
   AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nb, M, save_invstd, gamma, train,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nb, M, save_invstd, gamma, train,
                      g_gamma, g_beta, coef);
   AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(M)), dim3(256), 0, st, g_a, z, scale, shift,

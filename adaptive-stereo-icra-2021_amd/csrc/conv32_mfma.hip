@@ -24,23 +24,16 @@
 // The data gradient is the same kernel run on mirrored/transposed weights.
 // The weight gradient is a second kernel: M = ci, N = co, K = voxels.
 #include "as_common.h"
+#include "conv_epilogue.h"
 
 struct ConvArgs {
   const float* x;
   const float* wp;
-  const float* bias;
-  float* z;
-  const float* ep_scale;
-  const float* ep_shift;
-  const float* residual;
-  float* stat_mean;
-  float* stat_m2;
+  EpilogueArgs ep;
   PclDev gin, gout;
   int M;          // B*D*H*W output voxels
   int stride;
   int ntaps;
-  int epilogue;
-  float slope;
   int tap_off[AS_MAX_TAPS];   // voxel offsets in the INPUT geometry
 };
 
@@ -60,6 +53,12 @@ __device__ inline void mfma16(f32x16& acc, const f32x4 (&a)[4], const f32x4 (&b)
 }
 
 // One wave = one 32-voxel x 32-channel output tile; 4 waves per workgroup.
+// NT = number of taps, a compile-time constant: the tap loop is fully unrolled into straight-line
+// code with a static two-deep register ring (tap t+1's eight 16-byte loads are issued before tap
+// t's sixteen MFMAs).  A runtime tap loop made hipcc (ROCm 7.2) (a) bounce the accumulator between
+// AGPRs and VGPRs at every loop-carried branch, draining the matrix pipe, and (b) wait vmcnt(3)
+// immediately after issuing the prefetch — 40 % of the fp32 MFMA peak instead of the pipelined rate.
+template <int NT>
 __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
   __shared__ float red[4][32];
   __shared__ float bmean[32];
@@ -68,105 +67,31 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
   const int tile = blockIdx.x * 4 + wave;
   const int v = tile * 32 + li;
   const bool valid = v < p.M;
-  const int vc = valid ? v : p.M - 1;
-
-  const int W = p.gout.W, H = p.gout.H, D = p.gout.D;
-  int t = vc;
-  const int x = t % W; t /= W;
-  const int y = t % H; t /= H;
-  const int d = t % D;
-  const int b = t / D;
-  const int in_vox = (int)p.gin.vox(b, d, y * p.stride, x * p.stride);
-  const int out_vox = (int)p.gout.vox(b, d, y, x);
+  int in_vox, out_vox;
+  conv_decode(valid ? v : p.M - 1, p.gin, p.gout, p.stride, in_vox, out_vox);
 
   const float* xa = p.x + (long)in_vox * 32 + h * 16;
   const float* wb = p.wp + lane * 16;
 
   f32x16 acc;
-  {
-    const float bv = p.bias ? p.bias[li] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bv;
-  }
+  conv_init_acc(acc, p.ep.bias, li);
 
-  f32x4 a0[4], b0[4], a1[4], b1[4];
-  const int nt = p.ntaps;
-  load16(a0, xa + (long)p.tap_off[0] * 32);
-  load16(b0, wb);
-  for (int tp = 0; tp < nt; tp += 2) {
-    const bool has1 = tp + 1 < nt;
-    if (has1) {
-      load16(a1, xa + (long)p.tap_off[tp + 1] * 32);
-      load16(b1, wb + (tp + 1) * 1024);
-    }
-    mfma16(acc, a0, b0);
-    if (has1) {
-      if (tp + 2 < nt) {
-        load16(a0, xa + (long)p.tap_off[tp + 2] * 32);
-        load16(b0, wb + (tp + 2) * 1024);
-      }
-      mfma16(acc, a1, b1);
-    }
-  }
-
-  // ---- epilogue: acc[r] = Z[voxel row(r,h)][channel li] -------------------------
-  if (p.epilogue == 1) {
-    const float sc = p.ep_scale[li], sh = p.ep_shift[li];
+  f32x4 a[2][4], b[2][4];
+  load16(a[0], xa + (long)p.tap_off[0] * 32);
+  load16(b[0], wb);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int ov = __shfl(out_vox, row, 64);
-      const int rv = __shfl((int)valid, row, 64);
-      float yv = acc[r] * sc + sh;
-      yv = yv > 0.f ? yv : yv * p.slope;
-      if (rv) {
-        if (p.residual) yv += p.residual[(long)ov * 32 + li];
-        p.z[(long)ov * 32 + li] = yv;
-      }
+  for (int tp = 0; tp < NT; ++tp) {
+    if (tp + 1 < NT) {
+      load16(a[(tp + 1) & 1], xa + (long)p.tap_off[tp + 1] * 32);
+      load16(b[(tp + 1) & 1], wb + (tp + 1) * 1024);
     }
-    return;
+    // keep the prefetch above the MFMAs: without the fences hipcc sinks every load next to its
+    // use (2 loads -> vmcnt -> 4 MFMAs), trading the latency hiding for registers
+    __builtin_amdgcn_sched_barrier(0);
+    mfma16(acc, a[tp & 1], b[tp & 1]);
+    __builtin_amdgcn_sched_barrier(0);
   }
-
-  float s1 = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int ov = __shfl(out_vox, row, 64);
-    const int rv = __shfl((int)valid, row, 64);
-    if (rv) {
-      p.z[(long)ov * 32 + li] = acc[r];
-      s1 += acc[r];
-    }
-  }
-  if (p.stat_mean == nullptr) return;
-
-  // Per-workgroup (mean, M2) over its valid voxels, per channel: exact two-pass on
-  // the register-resident tile; merged across workgroups by as_bn_finalize (Chan).
-  const int first = blockIdx.x * 128;
-  const int nvalid = min(128, p.M - first);
-  s1 += __shfl_xor(s1, 32, 64);
-  if (h == 0) red[wave][li] = s1;
-  __syncthreads();
-  if (threadIdx.x < 32)
-    bmean[li] = (red[0][li] + red[1][li] + red[2][li] + red[3][li]) / (float)nvalid;
-  __syncthreads();
-  const float mu = bmean[li];
-  float s2 = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int rv = __shfl((int)valid, row, 64);
-    const float dv = acc[r] - mu;
-    if (rv) s2 += dv * dv;
-  }
-  s2 += __shfl_xor(s2, 32, 64);
-  __syncthreads();
-  if (h == 0) red[wave][li] = s2;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    p.stat_mean[blockIdx.x * 32 + li] = mu;
-    p.stat_m2[blockIdx.x * 32 + li] = red[0][li] + red[1][li] + red[2][li] + red[3][li];
-  }
+  conv_epilogue(acc, p.ep, out_vox, valid, p.M, red, bmean);
 }
 
 // ---------------------------------------------------------------------------------
@@ -203,6 +128,7 @@ struct WgradArgs {
   int rows;           // B*D*H
   int rows_per_chunk;
   int ntaps;
+  int stride;
   int tap_off[AS_MAX_TAPS];
 };
 
@@ -227,28 +153,39 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
 #pragma unroll
   for (int g = 0; g < TG; ++g) toff[g] = p.tap_off[group * TG + g] * 32;
 
+  // K loop over voxel pairs of the wave's rows.  Loads of WG_U steps (WG_U*(TG+1) coalesced 256-byte
+  // wave loads) are issued as a group before their MFMAs so that the memory latency of a whole group
+  // — not of a single step — is what the co-resident waves have to cover.
+  constexpr int WG_U = 8;
   const int nsteps = (W + 1) >> 1;
+  const int xs = 32 * p.stride;
   for (int row = r0 + wave; row < r1; row += 4) {
     int t = row;
     const int y = t % H; t /= H;
     const int d = t % D;
     const int b = t / D;
-    const float* xr = p.x + p.gin.vox(b, d, y, 0) * 32 + li;
+    const float* xr = p.x + p.gin.vox(b, d, y * p.stride, 0) * 32 + li;
     const float* gr = p.gz + p.gout.vox(b, d, y, 0) * 32 + li;
-#pragma unroll 4
-    for (int s = 0; s < nsteps; ++s) {
-      const int xc = 2 * s + h;
-      const bool ok = xc < W;
-      const int xcl = ok ? xc : W - 1;
-      float bv = gr[xcl * 32];
-      bv = ok ? bv : 0.f;
-      bsum += bv;
-      float av[TG];
+    for (int s0 = 0; s0 < nsteps; s0 += WG_U) {
+      float bv[WG_U], av[WG_U][TG];
 #pragma unroll
-      for (int g = 0; g < TG; ++g) av[g] = xr[xcl * 32 + toff[g]];
+      for (int u = 0; u < WG_U; ++u) {
+        const int xc = 2 * (s0 + u) + h;
+        const bool ok = xc < W;
+        const int xcl = ok ? xc : W - 1;
+        const float g0 = gr[xcl * 32];
+        bv[u] = ok ? g0 : 0.f;
 #pragma unroll
-      for (int g = 0; g < TG; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g], bv, acc[g], 0, 0, 0);
+        for (int g = 0; g < TG; ++g) av[u][g] = xr[xcl * xs + toff[g]];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // all loads of the group are issued before its first MFMA
+#pragma unroll
+      for (int u = 0; u < WG_U; ++u) {
+        bsum += bv[u];
+#pragma unroll
+        for (int g = 0; g < TG; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][g], bv[u], acc[g], 0, 0, 0);
+      }
     }
   }
 
@@ -365,19 +302,27 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
                              const float* residual, float* stat_mean, float* stat_m2, void* stream) {
   if (int e = check_conv(gin, gout, s, "as_conv32_fwd")) return e;
   AS_CHECK_ARG(x && packed_w && z, "as_conv32_fwd: null pointer");
-  AS_CHECK_ARG(epilogue == 0 || (epilogue == 1 && ep_scale && ep_shift), "as_conv32_fwd: bad epilogue");
-  AS_CHECK_ARG((stat_mean == nullptr) == (stat_m2 == nullptr), "as_conv32_fwd: stat pointers must come in pairs");
+  AS_CHECK_ARG(epilogue_args_ok(epilogue, ep_scale, ep_shift, stat_mean, stat_m2), "as_conv32_fwd: bad epilogue arguments");
   ConvArgs a;
-  a.x = x; a.wp = packed_w; a.bias = bias; a.z = z;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual;
-  a.stat_mean = epilogue == 0 ? stat_mean : nullptr; a.stat_m2 = epilogue == 0 ? stat_m2 : nullptr;
+  a.x = x; a.wp = packed_w;
+  a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = residual;
+  a.ep.stat_mean = epilogue == 0 ? stat_mean : nullptr; a.ep.stat_m2 = epilogue == 0 ? stat_m2 : nullptr;
+  a.ep.epilogue = epilogue; a.ep.slope = slope;
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
   const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;
   a.M = (int)M; a.stride = s->stride; a.ntaps = s->kd * s->kh * s->kw;
-  a.epilogue = epilogue; a.slope = slope;
   if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_fwd")) return e;
   as_prof_mark(0, (hipStream_t)stream, 1, 0.0);
-  hipLaunchKernelGGL(conv32_fwd_kernel, dim3(as_div_up(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(as_div_up(M, 128)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a.ntaps) {
+    case 27: hipLaunchKernelGGL(conv32_fwd_kernel<27>, grid, block, 0, st, a); break;
+    case 25: hipLaunchKernelGGL(conv32_fwd_kernel<25>, grid, block, 0, st, a); break;
+    case 9:  hipLaunchKernelGGL(conv32_fwd_kernel<9>, grid, block, 0, st, a); break;
+    default:
+      as_set_error("as_conv32_fwd: no kernel instance for %d taps (built: 3x3, 5x5, 3x3x3)", a.ntaps);
+      return AS_ERR_ARG;
+  }
   as_prof_mark(0, (hipStream_t)stream, 0, 2.0 * (double)M * 1024.0 * a.ntaps);
   AS_CHECK_LAUNCH("as_conv32_fwd");
   return AS_OK;
@@ -416,13 +361,12 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
                                const as_conv_shape* s, float* dW, float* db, float* workspace, void* stream) {
   if (int e = check_conv(gin, gout, s, "as_conv32_wgrad")) return e;
   AS_CHECK_ARG(x && gz && dW && workspace, "as_conv32_wgrad: null pointer");
-  AS_CHECK_ARG(s->stride == 1, "as_conv32_wgrad: stride must be 1");
   int tg, rpc, nchunks;
   const int T = wgrad_plan(gout, s, &tg, &rpc, &nchunks);
   WgradArgs a;
   a.x = x; a.gz = gz; a.partial = workspace; a.partial_db = workspace + (int64_t)nchunks * T * 1024;
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
-  a.rows = gout->B * gout->D * gout->H; a.rows_per_chunk = rpc; a.ntaps = T;
+  a.rows = gout->B * gout->D * gout->H; a.rows_per_chunk = rpc; a.ntaps = T; a.stride = s->stride;
   if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_wgrad")) return e;
   hipStream_t st = (hipStream_t)stream;
   as_prof_mark(1, st, 1, 0.0);

@@ -87,10 +87,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void sumsq_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += partial[i];
-  out[0] = (float)s;
+  double s = 0.0;                                // one wave; lane-strided, then a shuffle tree: fixed order
+  for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)s;
 }
 
 extern "C" int64_t as_sumsq_workspace(int64_t n) { return n > 0 ? 2 * SS_BLOCKS : -1; }

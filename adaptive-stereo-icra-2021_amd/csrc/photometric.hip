@@ -247,10 +247,10 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const float* __restrict
   }
 }
 __global__ void masked_sum_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out2) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0, c = 0.0;
-  for (int i = 0; i < nblk; ++i) { s += partial[2 * i]; c += partial[2 * i + 1]; }
-  out2[0] = (float)s; out2[1] = (float)c;
+  double s = 0.0, c = 0.0;                       // one wave; lane-strided, then a shuffle tree: fixed order
+  for (int i = threadIdx.x; i < nblk; i += 64) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+  s = wave_sum_d(s); c = wave_sum_d(c);
+  if (threadIdx.x == 0) { out2[0] = (float)s; out2[1] = (float)c; }
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------

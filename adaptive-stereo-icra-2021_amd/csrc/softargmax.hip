@@ -13,66 +13,78 @@
 // Dc is 8..24, so the per-pixel reduction over d is a short in-register loop.
 #include "as_common.h"
 
-struct OutConvArgs {
-  const float* a;
-  const float* w;      // [32][27] PyTorch order
-  const float* bias;   // [1]
-  float* logits;       // [B][D][H][W]
-  PclDev g;
-  long M;
-  int tap_off[27];
+struct OutGeom {
+  int kd, kh, kw, pad_d, pad_h, pad_w, dil, ntaps;
+  int tap_off[27];       // voxel offsets in the PCL input
 };
 
-__global__ __launch_bounds__(256) void conv3d_out_fwd_kernel(OutConvArgs p) {
+struct OutConvArgs {
+  const float* a;
+  const float* w;        // [32][ntaps] PyTorch order
+  const float* bias;     // [1] or null
+  const float* add_src;  // dense [B][D][H][W] added before the optional ReLU, or null
+  float* out;            // dense [B][D][H][W]
+  int relu;
+  PclDev g;
+  long M;
+  OutGeom k;
+};
+
+__global__ __launch_bounds__(256) void conv32to1_fwd_kernel(OutConvArgs p) {
   __shared__ float sw[27 * 32];
-  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+  const int NT = p.k.ntaps;
+  for (int i = threadIdx.x; i < NT * 32; i += 256) {
     const int t = i >> 5, c = i & 31;
-    sw[i] = p.w[c * 27 + t];
+    sw[i] = p.w[c * NT + t];
   }
   __syncthreads();
   const int c4 = threadIdx.x & 7;
   const float bias = p.bias ? p.bias[0] : 0.f;
   const long stride = (long)gridDim.x * 32;
-  const long Mr = (p.M + 31) & ~31L;      // keep the 8-lane groups converged for the shuffles
-  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < Mr; v += stride) {
-    const bool valid = v < p.M;
-    long t = valid ? v : p.M - 1;
+  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < p.M; v += stride) {
+    long t = v;
     const int x = t % p.g.W; t /= p.g.W;
     const int y = t % p.g.H; t /= p.g.H;
     const int d = t % p.g.D;
     const int b = t / p.g.D;
     const float* base = p.a + p.g.vox(b, d, y, x) * 32 + c4 * 4;
     float acc = 0.f;
-#pragma unroll
-    for (int tp = 0; tp < 27; ++tp) {
-      const f32x4 q = *reinterpret_cast<const f32x4*>(base + (long)p.tap_off[tp] * 32);
+    for (int tp = 0; tp < NT; ++tp) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(base + (long)p.k.tap_off[tp] * 32);
       const float* ww = sw + tp * 32 + c4 * 4;
       acc += q.x * ww[0] + q.y * ww[1] + q.z * ww[2] + q.w * ww[3];
     }
+    // the 8 lanes of a voxel are always active together: wavefront-shuffle reduction
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 4, 64);
-    if (valid && c4 == 0) p.logits[v] = acc + bias;
+    if (c4 == 0) {
+      float r = acc + bias;
+      if (p.add_src) r += p.add_src[v];
+      if (p.relu) r = r > 0.f ? r : 0.f;
+      p.out[v] = r;
+    }
   }
 }
 
-// g_a[v][c] = sum_t g_logits[v - off(t)] * w[c][t]   (only where v - off(t) is a real voxel)
+// g_a[v][c] = sum_t g_out[v - off(t)] * w[c][t]   (only where v - off(t) is a real voxel)
 struct OutConvBwdArgs {
-  const float* g_logits;
+  const float* g_out;
   const float* a;
   const float* w;
   float* g_a;
-  float* partial;   // [blocks][27*32 + 1]
+  float* partial;   // [blocks][ntaps*32 + 1]
   PclDev g;
   long M;
-  int tap_off[27];
+  OutGeom k;
 };
 
-__global__ __launch_bounds__(256) void conv3d_out_dgrad_kernel(OutConvBwdArgs p) {
+__global__ __launch_bounds__(256) void conv32to1_dgrad_kernel(OutConvBwdArgs p) {
   __shared__ float sw[27 * 32];
-  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+  const int NT = p.k.ntaps;
+  for (int i = threadIdx.x; i < NT * 32; i += 256) {
     const int t = i >> 5, c = i & 31;
-    sw[i] = p.w[c * 27 + t];
+    sw[i] = p.w[c * NT + t];
   }
   __syncthreads();
   const int c4 = threadIdx.x & 7;
@@ -85,30 +97,30 @@ __global__ __launch_bounds__(256) void conv3d_out_dgrad_kernel(OutConvBwdArgs p)
     const int d = t % D;
     const int b = t / D;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          // output voxel u with u + (kd-1,kh-1,kw-1) = v
-          const int ud = d - (kd - 1), uy = y - (kh - 1), ux = x - (kw - 1);
+    int tp = 0;
+    for (int kd = 0; kd < p.k.kd; ++kd)
+      for (int kh = 0; kh < p.k.kh; ++kh)
+        for (int kw = 0; kw < p.k.kw; ++kw, ++tp) {
+          // output voxel u with u + offset(tap) = v
+          const int ud = d - ((p.k.kd > 1 ? kd * p.k.dil : 0) - p.k.pad_d);
+          const int uy = y - (kh * p.k.dil - p.k.pad_h), ux = x - (kw * p.k.dil - p.k.pad_w);
           if (ud < 0 || ud >= D || uy < 0 || uy >= H || ux < 0 || ux >= W) continue;
-          const float gl = p.g_logits[(((long)b * D + ud) * H + uy) * W + ux];
-          const float* ww = sw + ((kd * 3 + kh) * 3 + kw) * 32 + c4 * 4;
+          const float gl = p.g_out[(((long)b * D + ud) * H + uy) * W + ux];
+          const float* ww = sw + tp * 32 + c4 * 4;
           acc.x += gl * ww[0]; acc.y += gl * ww[1]; acc.z += gl * ww[2]; acc.w += gl * ww[3];
         }
     *reinterpret_cast<f32x4*>(p.g_a + p.g.vox(b, d, y, x) * 32 + c4 * 4) = acc;
   }
 }
 
-// g_w[c][t] = sum_v g_logits[v] * a[v + off(t)][c];  g_bias = sum_v g_logits[v].
-__global__ __launch_bounds__(256) void conv3d_out_wgrad_kernel(OutConvBwdArgs p) {
+// g_w[c][t] = sum_v g_out[v] * a[v + off(t)][c];  g_bias = sum_v g_out[v].
+template <int NT>
+__global__ __launch_bounds__(256) void conv32to1_wgrad_kernel(OutConvBwdArgs p) {
   __shared__ float red[32][33];
   const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
-  f32x4 acc[27];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float gsum = 0.f;
   const long stride = (long)gridDim.x * 32;
   for (long v = (long)blockIdx.x * 32 + vl; v < p.M; v += stride) {
@@ -117,15 +129,16 @@ __global__ __launch_bounds__(256) void conv3d_out_wgrad_kernel(OutConvBwdArgs p)
     const int y = t % p.g.H; t /= p.g.H;
     const int d = t % p.g.D;
     const int b = t / p.g.D;
-    const float gl = p.g_logits[v];
+    const float gl = p.g_out[v];
     gsum += gl;
     const float* base = p.a + p.g.vox(b, d, y, x) * 32 + c4 * 4;
 #pragma unroll
-    for (int tp = 0; tp < 27; ++tp)
-      acc[tp] += gl * *reinterpret_cast<const f32x4*>(base + (long)p.tap_off[tp] * 32);
+    for (int tp = 0; tp < NT; ++tp)
+      acc[tp] += gl * *reinterpret_cast<const f32x4*>(base + (long)p.k.tap_off[tp] * 32);
   }
-  float* out = p.partial + (long)blockIdx.x * (27 * 32 + 1);
-  for (int tp = 0; tp < 27; ++tp) {
+  float* out = p.partial + (long)blockIdx.x * (NT * 32 + 1);
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp) {
     __syncthreads();
     red[vl][c4 * 4 + 0] = acc[tp].x; red[vl][c4 * 4 + 1] = acc[tp].y;
     red[vl][c4 * 4 + 2] = acc[tp].z; red[vl][c4 * 4 + 3] = acc[tp].w;
@@ -142,18 +155,21 @@ __global__ __launch_bounds__(256) void conv3d_out_wgrad_kernel(OutConvBwdArgs p)
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int j = 0; j < 32; ++j) s += red[j][0];
-    out[27 * 32] = s;
+    out[NT * 32] = s;
   }
 }
 
-__global__ void conv3d_out_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks,
-                                               float* __restrict__ g_w, float* __restrict__ g_bias) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx > 27 * 32) return;
+// one wave per output value: lanes stride over the slabs, shuffle-tree sum (fixed order)
+__global__ __launch_bounds__(256) void conv32to1_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int NT,
+                                                                      float* __restrict__ g_w, float* __restrict__ g_bias) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (idx > NT * 32) return;
   double s = 0.0;
-  for (int i = 0; i < nblocks; ++i) s += (double)partial[(long)i * (27 * 32 + 1) + idx];
-  if (idx == 27 * 32) { if (g_bias) g_bias[0] = (float)s; }
-  else { const int t = idx >> 5, c = idx & 31; g_w[c * 27 + t] = (float)s; }
+  for (int i = lane; i < nblocks; i += 64) s += (double)partial[(long)i * (NT * 32 + 1) + idx];
+  s = wave_sum_d(s);
+  if (lane != 0) return;
+  if (idx == NT * 32) { if (g_bias) g_bias[0] = (float)s; }
+  else { const int t = idx >> 5, c = idx & 31; if (g_w) g_w[c * NT + t] = (float)s; }
 }
 
 // ---- soft-argmax ---------------------------------------------------------------------
@@ -204,63 +220,88 @@ __global__ __launch_bounds__(256) void softargmax_bwd_kernel(const float* __rest
 }
 
 // ---- host ------------------------------------------------------------------------------
-static void fill27(const as_pcl* g, int* off) {
+static int fill_out_geom(const as_pcl* g, const as_conv_shape* s, OutGeom* k, const char* who) {
+  AS_CHECK_ARG(as_pcl_ok(g) && s, "%s: bad geometry", who);
+  const int T = s->kd * s->kh * s->kw;
+  AS_CHECK_ARG((T == 27 && s->kd == 3) || (T == 9 && s->kd == 1), "%s: only 3x3x3 and 3x3 kernels are built", who);
+  AS_CHECK_ARG(s->stride == 1 && s->dil >= 1, "%s: stride must be 1", who);
+  AS_CHECK_ARG(s->pad_h <= g->ph && s->pad_w <= g->pw && s->dil * (s->kh - 1) - s->pad_h <= g->ph &&
+               s->dil * (s->kw - 1) - s->pad_w <= g->pw && (s->kd == 1 || (s->pad_d <= g->pd && s->dil * 2 - s->pad_d <= g->pd)),
+               "%s: halo too small", who);
+  AS_CHECK_ARG(2 * s->pad_h == s->dil * (s->kh - 1) && 2 * s->pad_w == s->dil * (s->kw - 1) &&
+               (s->kd == 1 || 2 * s->pad_d == s->dil * (s->kd - 1)), "%s: only 'same' padding is built", who);
+  k->kd = s->kd; k->kh = s->kh; k->kw = s->kw; k->pad_d = s->kd > 1 ? s->pad_d : 0; k->pad_h = s->pad_h; k->pad_w = s->pad_w;
+  k->dil = s->dil; k->ntaps = T;
   const int Hp = g->H + 2 * g->ph, Wp = g->W + 2 * g->pw;
   int n = 0;
-  for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) for (int l = -1; l <= 1; ++l)
-    off[n++] = (i * Hp + j) * Wp + l;
-}
-
-static int check_out(const as_pcl* g, const char* who) {
-  AS_CHECK_ARG(as_pcl_ok(g), "%s: bad geometry", who);
-  AS_CHECK_ARG(g->pd >= 1 && g->ph >= 1 && g->pw >= 1, "%s: needs a halo of 1", who);
+  for (int i = 0; i < s->kd; ++i) for (int j = 0; j < s->kh; ++j) for (int l = 0; l < s->kw; ++l)
+    k->tap_off[n++] = (((s->kd > 1 ? i * s->dil : 0) - k->pad_d) * Hp + (j * s->dil - s->pad_h)) * Wp + (l * s->dil - s->pad_w);
   return AS_OK;
 }
 
 static inline int out_blocks(long M) {
   long nb = (M + 31) / 32;
-  if (nb > 2048) nb = 2048;
+  if (nb > 4096) nb = 4096;
   return (int)nb;
 }
-#define OUTW_BLOCKS 256
+#define OUTW_BLOCKS 512
+
+extern "C" int as_conv32to1_fwd(const float* a, const as_pcl* g, const as_conv_shape* s, const float* w,
+                                const float* bias, const float* add_src, int relu, float* out, void* stream) {
+  OutConvArgs p;
+  if (int e = fill_out_geom(g, s, &p.k, "as_conv32to1_fwd")) return e;
+  AS_CHECK_ARG(a && w && out, "as_conv32to1_fwd: null pointer");
+  p.a = a; p.w = w; p.bias = bias; p.add_src = add_src; p.out = out; p.relu = relu; p.g = as_make_dev(g);
+  p.M = (long)g->B * g->D * g->H * g->W;
+  hipLaunchKernelGGL(conv32to1_fwd_kernel, dim3(out_blocks(p.M)), dim3(256), 0, (hipStream_t)stream, p);
+  AS_CHECK_LAUNCH("as_conv32to1_fwd");
+  return AS_OK;
+}
+
+extern "C" int64_t as_conv32to1_bwd_workspace(const as_pcl* g, const as_conv_shape* s) {
+  if (!as_pcl_ok(g) || !s) return -1;
+  return (int64_t)OUTW_BLOCKS * (s->kd * s->kh * s->kw * 32 + 1);
+}
+
+extern "C" int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl* g, const as_conv_shape* s,
+                                const float* w, float* g_a, float* g_w, float* g_bias, float* workspace, void* stream) {
+  OutConvBwdArgs p;
+  if (int e = fill_out_geom(g, s, &p.k, "as_conv32to1_bwd")) return e;
+  AS_CHECK_ARG(g_out && a && w && workspace, "as_conv32to1_bwd: null pointer");
+  p.g_out = g_out; p.a = a; p.w = w; p.g_a = g_a; p.partial = workspace; p.g = as_make_dev(g);
+  p.M = (long)g->B * g->D * g->H * g->W;
+  hipStream_t st = (hipStream_t)stream;
+  if (g_a) {
+    hipLaunchKernelGGL(conv32to1_dgrad_kernel, dim3(out_blocks(p.M)), dim3(256), 0, st, p);
+    AS_CHECK_LAUNCH("as_conv32to1_bwd(dgrad)");
+  }
+  if (g_w || g_bias) {
+    long nb = (p.M + 31) / 32;
+    if (nb > OUTW_BLOCKS) nb = OUTW_BLOCKS;
+    if (p.k.ntaps == 27) hipLaunchKernelGGL(conv32to1_wgrad_kernel<27>, dim3((int)nb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(conv32to1_wgrad_kernel<9>, dim3((int)nb), dim3(256), 0, st, p);
+    AS_CHECK_LAUNCH("as_conv32to1_bwd(wgrad)");
+    hipLaunchKernelGGL(conv32to1_wgrad_reduce_kernel, dim3(as_div_up(p.k.ntaps * 32 + 1, 4)), dim3(256), 0, st,
+                       workspace, (int)nb, p.k.ntaps, g_w, g_bias);
+    AS_CHECK_LAUNCH("as_conv32to1_bwd(reduce)");
+  }
+  return AS_OK;
+}
+
+// The 3-D entry points of a4 are the generic kernels with a 3x3x3 'same' shape.
+static const as_conv_shape k333 = {3, 3, 3, 1, 1, 1, 1, 1};
 
 extern "C" int as_conv3d_out_fwd(const float* a, const as_pcl* g, const float* w, const float* bias,
                                  float* logits, void* stream) {
-  if (int e = check_out(g, "as_conv3d_out_fwd")) return e;
-  AS_CHECK_ARG(a && w && logits, "as_conv3d_out_fwd: null pointer");
-  OutConvArgs p;
-  p.a = a; p.w = w; p.bias = bias; p.logits = logits; p.g = as_make_dev(g);
-  p.M = (long)g->B * g->D * g->H * g->W;
-  fill27(g, p.tap_off);
-  hipLaunchKernelGGL(conv3d_out_fwd_kernel, dim3(out_blocks(p.M)), dim3(256), 0, (hipStream_t)stream, p);
-  AS_CHECK_LAUNCH("as_conv3d_out_fwd");
-  return AS_OK;
+  return as_conv32to1_fwd(a, g, &k333, w, bias, nullptr, 0, logits, stream);
 }
 
-extern "C" int64_t as_conv3d_out_bwd_workspace(const as_pcl* g) {
-  if (!as_pcl_ok(g)) return -1;
-  return (int64_t)OUTW_BLOCKS * (27 * 32 + 1);
-}
+extern "C" int64_t as_conv3d_out_bwd_workspace(const as_pcl* g) { return as_conv32to1_bwd_workspace(g, &k333); }
 
 extern "C" int as_conv3d_out_bwd(const float* g_logits, const float* a, const as_pcl* g, const float* w,
                                  float* g_a, float* g_w, float* g_bias, float* workspace, void* stream) {
-  if (int e = check_out(g, "as_conv3d_out_bwd")) return e;
-  AS_CHECK_ARG(g_logits && a && w && g_a && g_w && workspace, "as_conv3d_out_bwd: null pointer");
-  OutConvBwdArgs p;
-  p.g_logits = g_logits; p.a = a; p.w = w; p.g_a = g_a; p.partial = workspace; p.g = as_make_dev(g);
-  p.M = (long)g->B * g->D * g->H * g->W;
-  fill27(g, p.tap_off);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv3d_out_dgrad_kernel, dim3(out_blocks(p.M)), dim3(256), 0, st, p);
-  AS_CHECK_LAUNCH("as_conv3d_out_bwd(dgrad)");
-  long nb = (p.M + 31) / 32;
-  if (nb > OUTW_BLOCKS) nb = OUTW_BLOCKS;
-  hipLaunchKernelGGL(conv3d_out_wgrad_kernel, dim3((int)nb), dim3(256), 0, st, p);
-  AS_CHECK_LAUNCH("as_conv3d_out_bwd(wgrad)");
-  hipLaunchKernelGGL(conv3d_out_wgrad_reduce_kernel, dim3(as_div_up(27 * 32 + 1, 256)), dim3(256), 0, st,
-                     workspace, (int)nb, g_w, g_bias);
-  AS_CHECK_LAUNCH("as_conv3d_out_bwd(reduce)");
-  return AS_OK;
+  AS_CHECK_ARG(g_a && g_w, "as_conv3d_out_bwd: null pointer");
+  return as_conv32to1_bwd(g_logits, a, g, &k333, w, g_a, g_w, g_bias, workspace, stream);
 }
 
 extern "C" int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,

@@ -132,6 +132,35 @@ int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,
 int as_softargmax_bwd(const float* logits, const float* g_pred, const float* g_logits_in,
                       int B, int D, int H, int W, float* g_logits, void* stream);
 
+/* ---- generic 32 -> 1 convolution (3x3x3 or 3x3, 'same' padding, any dilation) ----------
+ * The 3-D instance is a4 above; the 2-D instance is EdgeAwareRefinement.conv2d_out =
+ * nn.Conv2d(32,1,3,padding=1) with the block's tail fused: out = relu(add_src + conv(a) + bias)
+ * (stereo_net.py:102,121).  It also serves as the data-gradient of conv2d_feature w.r.t. its
+ * disparity channel (a 32->1 convolution with mirrored taps).  w: [32][taps]; out/add_src/g_out:
+ * dense [B][D][H][W].  bwd: g_a (PCL, may be NULL), g_w [32][taps] (may be NULL), g_bias [1] (may be NULL). */
+int as_conv32to1_fwd(const float* a, const as_pcl* g, const as_conv_shape* s, const float* w,
+                     const float* bias, const float* add_src, int relu, float* out, void* stream);
+int64_t as_conv32to1_bwd_workspace(const as_pcl* g, const as_conv_shape* s);
+int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl* g, const as_conv_shape* s,
+                     const float* w, float* g_a, float* g_w, float* g_bias, float* workspace, void* stream);
+
+/* ---- thin-input convolution: Cin <= 4 -> 32 on "PCL4" ([B][H+2ph][W+2pw][4], zero halo) -----
+ * EdgeAwareRefinement.conv2d_feature = nn.Conv2d(4,32,3,padding=1) over cat([disparity, rgb])
+ * (stereo_net.py:89-94,116-118) and FeatureExtractorNetwork.downsample[0] = nn.Conv2d(3,32,5,
+ * stride=2,padding=2) (:61-69).  as_pack_in4 builds the PCL4 image from an optional dense plane
+ * ch0 [B,1,H,W] followed by the C channels of img [B,C,H,W] (this is the reference's torch.cat).
+ * Epilogue arguments as for as_conv32_fwd.  wgrad: dW in PyTorch layout [32][Cin][kh][kw]. */
+int64_t as_pcl4_numel(const as_pcl* g);
+int as_pack_in4(const float* ch0, const float* img, int C, float* x4, const as_pcl* g, void* stream);
+int as_conv4_pack_weights(const float* w, int Cin, float* packed, const as_conv_shape* s, void* stream);
+int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* packed_w, const float* bias,
+                 float* z, const as_pcl* gout, const as_conv_shape* s,
+                 int epilogue, const float* ep_scale, const float* ep_shift, float slope,
+                 float* stat_mean, float* stat_m2, void* stream);
+int64_t as_conv4_wgrad_workspace(const as_pcl* gout, const as_conv_shape* s);
+int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,
+                   const as_conv_shape* s, int Cin, float* dW, float* db, float* workspace, void* stream);
+
 /* ---- a6/a7 head: bilinear up-sampling, align_corners=False -------------------
  * F.interpolate(pred.unsqueeze(1), size=(H,W), mode="bilinear") * gain
  * (stereo_net.py:106-114, 201-202).  src: [B][h][w], dst: [B][1][H][W]. */

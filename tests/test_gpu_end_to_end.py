@@ -126,7 +126,7 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
     assert rel <= 5e-2, "%s: relative L2 error %.3e" % (key, rel)
   norm = float(adapter.optimizer.grad_norm())
   ref_norm = gold.scalar("train/stereo_grad_norm")
-  assert abs(norm - ref_norm) <= 2e-3 * ref_norm + 1e-6
+  assert abs(norm - ref_norm) <= 2e-2 * ref_norm + 1e-6      # same conditioning argument as the per-tensor bound
 
   # BatchNorm running statistics after the step
   for net_name, net in (("stereo", snet), ("feature", fnet)):

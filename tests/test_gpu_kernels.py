@@ -330,3 +330,92 @@ def test_sumsq_and_adam_step():
              1e-8, step, nat.stream())
   close(pd, pr, 1e-7, 1e-6, "adam params")
   close(m, state["exp_avg"], 1e-9, 1e-5, "adam m"); close(v, state["exp_avg_sq"], 1e-12, 1e-5, "adam v")
+
+
+# ----------------------------------------------------------------------------- thin-input conv (Cin <= 4)
+@pytest.mark.parametrize("B,H,W,Cin,k,stride,pad", [(1, 9, 13, 4, 3, 1, 1), (2, 37, 53, 4, 3, 1, 1),
+                                                    (1, 21, 30, 3, 5, 2, 2), (2, 75, 131, 3, 5, 2, 2)])
+def test_conv4_fwd_and_wgrad(B, H, W, Cin, k, stride, pad):
+  x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+  w = rnd(32, Cin, k, k, seed=2, scale=1.0 / (Cin * k * k) ** 0.5).requires_grad_(True)
+  b = rnd(32, seed=3, scale=0.1).requires_grad_(True)
+  z_ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+  gz = rnd(*z_ref.shape, seed=4)
+  z_ref.backward(gz)
+  Ho, Wo = z_ref.shape[-2:]
+  shape = ConvShape(1, k, k, 0, pad, pad, 1, stride)
+  g4 = Pcl(B, 1, H, W, 0, pad, pad)
+  gout = Pcl(B, 1, Ho, Wo, 0, 2, 2)
+  lib = nat.load()
+  x4 = torch.zeros(lib.as_pcl4_numel(g4), device=DEV)
+  xd = x.detach().to(DEV)
+  if Cin == 4:
+    ch0, img = xd[:, :1].contiguous(), xd[:, 1:].contiguous()
+    nat.call("as_pack_in4", nat.ptr(ch0), nat.ptr(img), 3, nat.ptr(x4), g4, nat.stream())
+  else:
+    nat.call("as_pack_in4", None, nat.ptr(xd), 3, nat.ptr(x4), g4, nat.stream())
+  wd, bd = w.detach().to(DEV), b.detach().to(DEV)
+  wp = torch.empty(k * k * 128, device=DEV)
+  nat.call("as_conv4_pack_weights", nat.ptr(wd), Cin, nat.ptr(wp), shape, nat.stream())
+  z = ops.pcl_zeros(gout, DEV)
+  nat.call("as_conv4_fwd", nat.ptr(x4), g4, nat.ptr(wp), nat.ptr(bd), nat.ptr(z), gout, shape, 0, None, None, 0.2,
+           None, None, nat.stream())
+  close(ops.pcl_to_ncdhw(z, gout)[:, :, 0], z_ref, 1e-5, 1e-5, "conv4 fwd")
+  gzb = ops.ncdhw_to_pcl(gz.unsqueeze(2).to(DEV), gout)
+  dW = torch.empty(32, Cin, k, k, device=DEV); db = torch.empty(32, device=DEV)
+  ws = torch.empty(lib.as_conv4_wgrad_workspace(gout, shape), device=DEV)
+  nat.call("as_conv4_wgrad", nat.ptr(x4), g4, nat.ptr(gzb), gout, shape, Cin, nat.ptr(dW), nat.ptr(db), nat.ptr(ws),
+           nat.stream())
+  n = B * Ho * Wo
+  close(dW, w.grad, 2e-6 * n ** 0.5 + 1e-5, 2e-5, "conv4 wgrad")
+  close(db, b.grad, 2e-6 * n ** 0.5 + 1e-5, 2e-5, "conv4 bias grad")
+
+
+def test_conv32_stride2_fwd_wgrad_and_residual_epilogue():
+  B, H, W = 2, 21, 30
+  shape = ConvShape(1, 5, 5, 0, 2, 2, 1, 2)
+  x = rnd(B, 32, H, W, seed=1).requires_grad_(True)
+  w = rnd(32, 32, 5, 5, seed=2, scale=0.035).requires_grad_(True)
+  b = rnd(32, seed=3, scale=0.1).requires_grad_(True)
+  z_ref = F.conv2d(x, w, b, stride=2, padding=2)
+  gz = rnd(*z_ref.shape, seed=4)
+  z_ref.backward(gz)
+  Ho, Wo = z_ref.shape[-2:]
+  gin, gout = Pcl(B, 1, H, W, 0, 2, 2), Pcl(B, 1, Ho, Wo, 0, 1, 1)
+  xb = ops.ncdhw_to_pcl(x.detach().unsqueeze(2).to(DEV), gin)
+  wd, bd = w.detach().to(DEV), b.detach().to(DEV)
+  res = rnd(B, 32, 1, Ho, Wo, seed=5)
+  resb = ops.ncdhw_to_pcl(res.to(DEV), gout)
+  zb = ops.conv32(xb, gin, ops.pack_weights(wd, shape, False), bd, gout, shape, residual=resb)
+  close(ops.pcl_to_ncdhw(zb, gout), z_ref.unsqueeze(2) + res, 2e-5, 1e-5, "stride-2 conv + residual epilogue")
+  gzb = ops.ncdhw_to_pcl(gz.unsqueeze(2).to(DEV), gout)
+  dW, db = ops.conv32_wgrad(xb, gin, gzb, gout, shape)
+  close(dW, w.grad, 1e-4, 2e-5, "stride-2 wgrad"); close(db, b.grad, 1e-4, 2e-5, "stride-2 bias grad")
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 9, 13), (2, 37, 53)])
+def test_conv32to1_2d_fused_tail(B, H, W):
+  """EdgeAwareRefinement tail: relu(up + Conv2d(32,1,3,p=1)(a)), forward and backward."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(1)
+  a = rnd(B, 32, H, W, seed=1).requires_grad_(True)
+  w = rnd(1, 32, 3, 3, seed=2, scale=0.2).requires_grad_(True)
+  b = rnd(1, seed=3, scale=0.1).requires_grad_(True)
+  up = rnd(B, 1, H, W, seed=4)
+  ref = F.relu(up + F.conv2d(a, w, b, padding=1))
+  go = rnd(B, 1, H, W, seed=5)
+  ref.backward(go)
+  ab = ops.ncdhw_to_pcl(a.detach().unsqueeze(2).to(DEV), g)
+  wd, bd, upd = w.detach().to(DEV).contiguous(), b.detach().to(DEV), up.to(DEV)
+  out = torch.empty(B, 1, H, W, device=DEV)
+  nat.call("as_conv32to1_fwd", nat.ptr(ab), g, shape, nat.ptr(wd), nat.ptr(bd), nat.ptr(upd), 1, nat.ptr(out), nat.stream())
+  close(out, ref, 5e-6, 1e-5, "refinement tail fwd")
+  gpre = (go.to(DEV) * (out > 0)).contiguous()
+  lib = nat.load()
+  g_a = ops.pcl_zeros(g, DEV); g_w = torch.empty_like(wd); g_b = torch.empty(1, device=DEV)
+  ws = torch.empty(lib.as_conv32to1_bwd_workspace(g, shape), device=DEV)
+  nat.call("as_conv32to1_bwd", nat.ptr(gpre), nat.ptr(ab), g, shape, nat.ptr(wd), nat.ptr(g_a), nat.ptr(g_w),
+           nat.ptr(g_b), nat.ptr(ws), nat.stream())
+  close(ops.pcl_to_ncdhw(g_a, g)[:, :, 0], a.grad, 5e-6, 1e-5, "tail dgrad")
+  n = B * H * W
+  close(g_w, w.grad, 2e-6 * n ** 0.5, 1e-5, "tail wgrad"); close(g_b, b.grad, 2e-6 * n ** 0.5, 1e-5, "tail bias grad")
