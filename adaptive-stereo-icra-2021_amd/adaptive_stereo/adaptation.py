@@ -161,13 +161,26 @@ class OnlineAdapter(object):
     n = total.numel()
     ws = torch.empty(lib.as_masked_sum_workspace(n), dtype=torch.float32, device=total.device)
     local = torch.empty(2, dtype=torch.float32, device=total.device)
-    nat.call("as_masked_sum", nat.ptr(total.detach().contiguous()), nat.ptr(m8.contiguous()), n, nat.ptr(local),
-             nat.ptr(ws), nat.stream())
-    s = self.scalars
-    s[0] = local[1]; s[1] = local[0]; s[2] = fcs_map.sum(); s[3] = float(fcs_map.numel())
-    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.pg)          # 16 bytes, before backward
-    n_total = s[0]
+    td, m8c = total.detach().contiguous(), m8.contiguous()
+    nat.call("as_masked_sum", nat.ptr(td), nat.ptr(m8c), n, nat.ptr(local), nat.ptr(ws), nat.stream())
+    s = allreduce_step_scalars(self.scalars, local[0], local[1], fcs_map.sum(), float(fcs_map.numel()), self.pg)
     # d(global mean)/d(total) on this rank = mask / N_total
-    total.backward(m8.to(torch.float32) / n_total)
-    dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM, group=self.pg)   # ONE flat bucket over xGMI
-    return s[1] / n_total, s[2] / s[3]
+    total.backward(m8.to(torch.float32) / s[0])
+    allreduce_gradients(self.arena.grads, self.pg)
+    return s[1] / s[0], s[2] / s[3]
+
+
+def allreduce_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count, group=None):
+    """One 16-byte all-reduce(sum) of [valid-pixel count, loss sum, FCS sum, FCS count], issued BEFORE
+    backward: the reference's loss is the mean over the valid pixels of the whole batch (adapt.py:83),
+    so every rank must scale its local gradient by 1/N_total, not 1/N_rank."""
+    buf[0] = valid_count; buf[1] = loss_sum; buf[2] = fcs_sum; buf[3] = fcs_count
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+def allreduce_gradients(flat_grads, group=None):
+    """ONE all-reduce(sum) of the flat gradient arena (313,698 floats at k=4): on xGMI this message is
+    latency-bound, so a single bucket beats per-tensor or per-layer buckets."""
+    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    return flat_grads

@@ -1,0 +1,142 @@
+"""Data-parallel semantics of the adaptation step, on CPU with gloo (world size 2).
+
+Covers the host logic of adaptive_stereo.adaptation that a multi-GPU run relies on: FlatArena
+(parameters / gradients as views of flat buffers, autograd accumulating in place), the scalar
+all-reduce issued before backward, and the single flat-bucket gradient all-reduce.  The compute is
+the oracle (CPU) in eval-mode BatchNorm, for which sharding pairs over ranks is exactly equivalent
+to one process with the whole batch: sum_r grad(sum_r/N_total) == grad(whole-batch masked mean).
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, PKG
+
+
+def _free_port():
+  s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+  return p
+
+
+def _build():
+  from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+  from adaptive_stereo.utils import synthetic as syn
+  k, maxdisp = 3, 64
+  fnet, snet = FeatureExtractorNetwork(k), StereoNet(k, 1, 0, maxdisp=maxdisp)
+  fsd = syn.synthetic_state_dict(fnet.state_dict(), seed=123)
+  ssd = syn.synthetic_state_dict(snet.state_dict(), seed=123, logit_gain=5.0)
+  left, right = syn.stereo_pair(2, 48, 64, seed=4, disparities=(3.0, 6.0))
+  return k, maxdisp, fsd, ssd, left, right
+
+
+def _loss_terms(fp, sp, left, right, k, maxdisp):
+  """Per-rank pieces of monodepth_single_loss with eval-mode BN: (loss map, mask, fcs map)."""
+  from oracle import stereo_oracle as orc
+  fl = orc.feature_extractor(fp, left, k, False)
+  fr = orc.feature_extractor(fp, right, k, False)
+  out = orc.stereo_forward(sp, left, fl, fr, k, 0, maxdisp, "l", False, True)
+  pred = out["pred_disp_l/0"]
+  warped, mask = orc.linear_warp(right, pred, True)
+  total = orc.monodepth_loss(pred, left, warped, 1e-3)[0]
+  return total, mask, orc.feature_contrast_mean(out["cost_volume_l/%d" % k])
+
+
+class _Holder(torch.nn.Module):
+  """Wraps an oracle parameter dict as a Module so FlatArena can re-home it."""
+
+  def __init__(self, params):
+    super().__init__()
+    self.names = []
+    for i, (name, t) in enumerate(params.items()):
+      if t.requires_grad:
+        self.register_parameter("p%d" % i, torch.nn.Parameter(t.detach().clone()))
+        self.names.append((name, "p%d" % i))
+
+  def as_dict(self, template):
+    out = dict(template)
+    for name, attr in self.names:
+      out[name] = getattr(self, attr)
+    return out
+
+
+def _worker(rank, world, port, result_path):
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  torch.set_num_threads(2)
+  from adaptive_stereo.adaptation import FlatArena, allreduce_step_scalars, allreduce_gradients
+  from oracle import stereo_oracle as orc
+  k, maxdisp, fsd, ssd, left, right = _build()
+  fp0, sp0 = orc.make_params(fsd, True), orc.make_params(ssd, True)
+  hs, hf = _Holder(sp0), _Holder(fp0)
+  arena = FlatArena([hs, hf])                       # stereo first, then feature (adapt.py:208-209)
+  sp, fp = hs.as_dict(sp0), hf.as_dict(fp0)
+  # parameters are views of the arena
+  assert all(p.data_ptr() >= arena.params.data_ptr() for p in list(hs.parameters()) + list(hf.parameters()))
+
+  lo, hi = rank * (2 // world), (rank + 1) * (2 // world)
+  total, mask, fcs = _loss_terms(fp, sp, left[lo:hi], right[lo:hi], k, maxdisp)
+  scal = torch.zeros(4)
+  s = allreduce_step_scalars(scal, (total.detach() * mask).sum(), mask.sum().float(), fcs.sum(), float(fcs.numel()))
+  arena.zero_grads()
+  total.backward(mask.float() / s[0])
+  # autograd accumulated into the arena views in place
+  assert float(arena.grads.abs().sum()) > 0
+  allreduce_gradients(arena.grads)
+  if rank == 0:
+    torch.save({"grads": arena.grads.clone(), "loss": float(s[1] / s[0]), "fcs": float(s[2] / s[3]),
+                "bounds": arena.group_bounds, "n": arena.numel}, result_path)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_whole_batch(tmp_path):
+  from adaptive_stereo.adaptation import FlatArena
+  from oracle import stereo_oracle as orc
+  result = str(tmp_path / "dp.pt")
+  mp.spawn(_worker, args=(2, _free_port(), result), nprocs=2, join=True)
+  got = torch.load(result)
+
+  # single process, whole batch
+  k, maxdisp, fsd, ssd, left, right = _build()
+  fp0, sp0 = orc.make_params(fsd, True), orc.make_params(ssd, True)
+  hs, hf = _Holder(sp0), _Holder(fp0)
+  arena = FlatArena([hs, hf])
+  sp, fp = hs.as_dict(sp0), hf.as_dict(fp0)
+  total, mask, fcs = _loss_terms(fp, sp, left, right, k, maxdisp)
+  loss = total[mask].mean()
+  arena.zero_grads()
+  loss.backward()
+  assert got["n"] == arena.numel and got["bounds"] == arena.group_bounds
+  assert abs(got["loss"] - float(loss)) < 1e-6
+  assert abs(got["fcs"] - float(fcs.mean())) < 1e-5
+  ref = arena.grads
+  err = float((got["grads"] - ref).norm() / ref.norm())
+  assert err < 1e-5, "2-rank all-reduced gradient differs from the whole-batch gradient: rel %.2e" % err
+
+
+def test_flat_arena_views_and_rebinding():
+  from adaptive_stereo.adaptation import FlatArena
+  a, b = torch.nn.Linear(3, 5), torch.nn.Linear(5, 2)
+  w0 = a.weight.detach().clone()
+  arena = FlatArena([a, b])
+  assert torch.equal(a.weight, w0)
+  assert arena.numel % 4 == 0 and len(arena.group_bounds) == 2
+  assert arena.group_bounds[0][0] == 0 and arena.group_bounds[1][0] == arena.group_bounds[0][1]
+  for _, _, p, off, n in arena.entries:
+    assert off % 4 == 0 and p.data_ptr() == arena.params.data_ptr() + 4 * off
+    assert p.grad.data_ptr() == arena.grads.data_ptr() + 4 * off
+  b(a(torch.ones(1, 3))).sum().backward()
+  assert float(arena.grads.abs().sum()) > 0
+  a.weight.grad = None                       # e.g. optimizer.zero_grad(set_to_none=True) in user code
+  arena.rebind_grads()
+  assert a.weight.grad.data_ptr() == arena.grads.data_ptr()
+  arena.params[: a.weight.numel()] += 1.0    # an update of the arena is an update of the module
+  assert torch.allclose(a.weight, w0 + 1.0)
