@@ -48,11 +48,12 @@ _SIGNATURES = {
   "as_cost_volume_bwd": (c_int, [c_vp, c_vp, c_vp, _P(Pcl), c_vp]),
   "as_conv32_pack_weights": (c_int, [c_vp, c_vp, _P(ConvShape), c_int, c_vp]),
   "as_conv32_num_blocks": (c_int, [_P(Pcl)]),
+  "as_conv32_stat_parts": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_float,
-                            c_vp, c_vp, c_vp, c_vp]),
+                            c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_conv32_wgrad_workspace": (c_i64, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp]),
-  "as_bn_finalize": (c_int, [c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp,
+  "as_bn_finalize": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp,
                              c_vp, c_vp]),
   "as_bn_eval_affine": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_bn_act_fwd": (c_int, [c_vp, c_vp, c_vp, c_float, c_vp, c_vp, _P(Pcl), c_vp]),
@@ -69,7 +70,7 @@ _SIGNATURES = {
   "as_pack_in4": (c_int, [c_vp, c_vp, c_int, c_vp, _P(Pcl), c_vp]),
   "as_conv4_pack_weights": (c_int, [c_vp, c_int, c_vp, _P(ConvShape), c_vp]),
   "as_conv4_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_float,
-                           c_vp, c_vp, c_vp]),
+                           c_vp, c_vp, c_vp, c_vp]),
   "as_conv4_wgrad_workspace": (c_i64, [_P(Pcl), _P(ConvShape)]),
   "as_conv4_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_vp, c_vp]),
   "as_softargmax_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),

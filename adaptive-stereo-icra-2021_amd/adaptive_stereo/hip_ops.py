@@ -87,12 +87,27 @@ def pack_weights(w, shape: ConvShape, transpose_flip: bool):
 
 def conv32(x, gin: Pcl, packed_w, bias, gout: Pcl, shape: ConvShape, out=None, epilogue=0, scale=None,
            shift=None, residual=None, stats=None):
-  """Returns the PCL output buffer. ``stats`` = (mean_partials, m2_partials) to fill."""
+  """Returns the PCL output buffer. ``stats`` = StatParts to fill (train-mode BatchNorm)."""
   z = out if out is not None else POOL.get(gout, x.device)
-  sm, s2 = stats if stats is not None else (None, None)
+  sm, s2, sc = (stats.mean, stats.m2, stats.cnt) if stats is not None else (None, None, None)
   call("as_conv32_fwd", ptr(x), gin, ptr(packed_w), ptr(bias), ptr(z), gout, shape, int(epilogue),
-       ptr(scale), ptr(shift), LEAKY_SLOPE, ptr(residual), ptr(sm), ptr(s2), stream())
+       ptr(scale), ptr(shift), LEAKY_SLOPE, ptr(residual), ptr(sm), ptr(s2), ptr(sc), stream())
   return z
+
+
+class StatParts(object):
+  """BatchNorm partial moments written by a convolution epilogue: (count, mean, M2) per workgroup."""
+
+  def __init__(self, nparts, device):
+    self.nparts = int(nparts)
+    buf = torch.empty(self.nparts * 65, dtype=torch.float32, device=device)
+    self.mean = buf[:self.nparts * 32]
+    self.m2 = buf[self.nparts * 32:self.nparts * 64]
+    self.cnt = buf[self.nparts * 64:]
+
+
+def conv32_stat_parts(gin: Pcl, gout: Pcl, shape: ConvShape, device):
+  return StatParts(nat.load().as_conv32_stat_parts(gin, gout, shape), device)
 
 
 def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True):
@@ -118,9 +133,9 @@ class BnState(object):
     self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
 
 
-def bn_train_stats(stats, count, gamma, beta, running_mean, running_var, nblocks):
+def bn_train_stats(stats: StatParts, gamma, beta, running_mean, running_var):
   st = BnState(gamma.device)
-  call("as_bn_finalize", ptr(stats[0]), ptr(stats[1]), int(nblocks), int(count), ptr(gamma), ptr(beta),
+  call("as_bn_finalize", ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stats.nparts, ptr(gamma), ptr(beta),
        ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS, ptr(st.mean), ptr(st.invstd),
        ptr(st.scale), ptr(st.shift), stream())
   return st
@@ -165,10 +180,9 @@ def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train,
   dev = x.device
   wp = pack_weights(w, shape, False)
   if train:
-    nblocks = nat.load().as_conv32_num_blocks(g)
-    stats = (_empty(nblocks * 32, dev), _empty(nblocks * 32, dev))
+    stats = conv32_stat_parts(g, g, shape, dev)
     z = conv32(x, g, wp, b, g, shape, stats=stats)
-    st = bn_train_stats(stats, g.voxels(), gamma, beta, rm, rv, nblocks)
+    st = bn_train_stats(stats, gamma, beta, rm, rv)
     a = bn_act(z, st, g, residual=x if skip else None)
   else:
     st = bn_eval_stats(gamma, beta, rm, rv)
@@ -389,26 +403,25 @@ class EdgeRefineFn(torch.autograd.Function):
     rm0, rv0 = bn_buffers[0]
     wp4 = _empty(9 * 128, dev)
     call("as_conv4_pack_weights", ptr(w0), 4, ptr(wp4), s33, stream())
-    nblocks = lib.as_conv32_num_blocks(g)
     if train:
-      stats = (_empty(nblocks * 32, dev), _empty(nblocks * 32, dev))
+      stats = StatParts(lib.as_conv32_num_blocks(g), dev)
       z0 = POOL.get(g, dev)
       call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(z0), g, s33, 0, None, None, LEAKY_SLOPE,
-           ptr(stats[0]), ptr(stats[1]), stream())
-      st0 = bn_train_stats(stats, g.voxels(), gamma0, beta0, rm0, rv0, nblocks)
+           ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stream())
+      st0 = bn_train_stats(stats, gamma0, beta0, rm0, rv0)
       a0 = bn_act(z0, st0, g)
     else:
       st0 = bn_eval_stats(gamma0, beta0, rm0, rv0)
       if need_bwd:
         z0 = POOL.get(g, dev)
         call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(z0), g, s33, 0, None, None, LEAKY_SLOPE, None, None,
-             stream())
+             None, stream())
         a0 = bn_act(z0, st0, g)
       else:
         z0 = None
         a0 = POOL.get(g, dev)
         call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(a0), g, s33, 1, ptr(st0.scale), ptr(st0.shift),
-             LEAKY_SLOPE, None, None, stream())
+             LEAKY_SLOPE, None, None, None, stream())
     if not need_bwd and z0 is not None:
       POOL.put(z0, g); z0 = None
 

@@ -10,37 +10,47 @@
 #include "as_common.h"
 
 // ---- finalize: one workgroup, 1024 threads = 32 slices x 32 channels ---------------------
-// Exact merge of the per-workgroup (n, mean, M2) triples in fp64, in two division-free passes:
+// Exact merge of the per-partial (n, mean, M2) triples in fp64, in two division-free passes:
 //   mean = sum n_i*mean_i / N;   M2 = sum [ M2_i + n_i*(mean_i - mean)^2 ].
-// (Every partial covers 128 voxels except the last.)  Reads are 128-byte rows, fixed order.
+// Reads are 128-byte rows in a fixed order (deterministic).
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
-    const float* __restrict__ stat_mean, const float* __restrict__ stat_m2, int nblocks, long count,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean, float* running_var,
-    float momentum, float eps, float* save_mean, float* save_invstd, float* scale, float* shift) {
+    const float* __restrict__ stat_mean, const float* __restrict__ stat_m2, const float* __restrict__ stat_cnt,
+    int nparts, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, float momentum, float eps, float* save_mean, float* save_invstd, float* scale, float* shift) {
   __shared__ double red[32][33];
-  __shared__ double smean[32];
+  __shared__ double smean[32], scount;
   const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  double s = 0.0;
-  for (int i = sl; i < nblocks; i += 32) {
-    const long left = count - (long)i * 128;
-    const double nb = (double)(left < 128 ? left : 128);
-    s += nb * (double)stat_mean[i * 32 + c];
+  double s = 0.0, cn = 0.0;
+  for (int i = sl; i < nparts; i += 32) {
+    const double nb = (double)stat_cnt[i];
+    cn += nb;
+    if (nb > 0.0) s += nb * (double)stat_mean[i * 32 + c];
   }
   red[sl][c] = s;
   __syncthreads();
   if (sl == 0) {
     double t = 0.0;
     for (int j = 0; j < 32; ++j) t += red[j][c];
-    smean[c] = t / (double)count;
+    smean[c] = t;
   }
   __syncthreads();
-  const double mean = smean[c];
+  red[sl][c] = cn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int j = 0; j < 32; ++j) t += red[j][0];
+    scount = t;
+  }
+  __syncthreads();
+  const double count = scount;
+  const double mean = smean[c] / count;
   double q = 0.0;
-  for (int i = sl; i < nblocks; i += 32) {
-    const long left = count - (long)i * 128;
-    const double nb = (double)(left < 128 ? left : 128);
-    const double dm = (double)stat_mean[i * 32 + c] - mean;
-    q += (double)stat_m2[i * 32 + c] + nb * dm * dm;
+  for (int i = sl; i < nparts; i += 32) {
+    const double nb = (double)stat_cnt[i];
+    if (nb > 0.0) {
+      const double dm = (double)stat_mean[i * 32 + c] - mean;
+      q += (double)stat_m2[i * 32 + c] + nb * dm * dm;
+    }
   }
   __syncthreads();
   red[sl][c] = q;
@@ -48,7 +58,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   if (sl == 0) {
     double m2 = 0.0;
     for (int j = 0; j < 32; ++j) m2 += red[j][c];
-    const double n = (double)count;
+    const double n = count;
     const double var_b = m2 / n;
     const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
     const float meanf = (float)mean;
@@ -210,17 +220,16 @@ static inline int elementwise_blocks(long M) {
   return (int)nb;
 }
 
-extern "C" int as_bn_finalize(const float* stat_mean, const float* stat_m2, int nblocks, int64_t count,
+extern "C" int as_bn_finalize(const float* stat_mean, const float* stat_m2, const float* stat_cnt, int nparts,
                               const float* gamma, const float* beta, float* running_mean, float* running_var,
                               float momentum, float eps, float* save_mean, float* save_invstd,
                               float* scale, float* shift, void* stream) {
-  AS_CHECK_ARG(stat_mean && stat_m2 && gamma && beta && save_mean && save_invstd && scale && shift,
+  AS_CHECK_ARG(stat_mean && stat_m2 && stat_cnt && gamma && beta && save_mean && save_invstd && scale && shift,
                "as_bn_finalize: null pointer");
-  AS_CHECK_ARG(nblocks >= 1 && count >= 1 && (int64_t)nblocks == (count + 127) / 128,
-               "as_bn_finalize: nblocks=%d inconsistent with count=%lld", nblocks, (long long)count);
+  AS_CHECK_ARG(nparts >= 1, "as_bn_finalize: nparts=%d", nparts);
   AS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "as_bn_finalize: running stats must pair");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stat_mean, stat_m2, nblocks,
-                     (long)count, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stat_mean, stat_m2, stat_cnt,
+                     nparts, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                      scale, shift);
   AS_CHECK_LAUNCH("as_bn_finalize");
   return AS_OK;

@@ -17,14 +17,16 @@
 //   M = voxels (32 per wave tile, lane&31), N = 32 output channels, K = taps*32.
 //   K is ordered (tap, s, h) with ci = 16*h + s, h = lane>>5: the lane-half h of an
 //   MFMA holds k = h, so per tap a lane loads ci = 16h..16h+15 of its voxel: 4 x
-//   dwordx4.  Weights are pre-packed to [tap][h][co][s] so the B operand is likewise
-//   4 x dwordx4 per tap per lane (coalesced 4 KiB per wave, L1/L2 resident: 110 KB
-//   for 27 taps).  The zero halo of PCL supplies the padding: no predicates.
+//   dwordx4.  Weights are pre-packed to [tap][q][lane][4] so each of the B operand's
+//   4 x dwordx4 per tap is one contiguous KB per wave (L1/L2 resident: 110 KB for 27
+//   taps).  The zero halo of PCL supplies the padding: no predicates.
+//   2-D 3x3 stride-1 layers take the LDS-staged kernel in conv32_lds.hip instead.
 //
 // The data gradient is the same kernel run on mirrored/transposed weights.
 // The weight gradient is a second kernel: M = ci, N = co, K = voxels.
 #include "as_common.h"
 #include "conv_epilogue.h"
+#include "conv32_lds.h"
 
 struct ConvArgs {
   const float* x;
@@ -40,6 +42,13 @@ struct ConvArgs {
 __device__ inline void load16(f32x4 (&r)[4], const float* p) {
   const f32x4* q = reinterpret_cast<const f32x4*>(p);
   r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+}
+
+__device__ inline void loadw(f32x4 (&r)[4], const float* p) {
+  r[0] = *reinterpret_cast<const f32x4*>(p);
+  r[1] = *reinterpret_cast<const f32x4*>(p + 256);
+  r[2] = *reinterpret_cast<const f32x4*>(p + 512);
+  r[3] = *reinterpret_cast<const f32x4*>(p + 768);
 }
 
 __device__ inline void mfma16(f32x16& acc, const f32x4 (&a)[4], const f32x4 (&b)[4]) {
@@ -71,19 +80,19 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
   conv_decode(valid ? v : p.M - 1, p.gin, p.gout, p.stride, in_vox, out_vox);
 
   const float* xa = p.x + (long)in_vox * 32 + h * 16;
-  const float* wb = p.wp + lane * 16;
+  const float* wb = p.wp + lane * 4;       // packed [tap][q][lane][4]: each wave load is one contiguous KB
 
   f32x16 acc;
   conv_init_acc(acc, p.ep.bias, li);
 
   f32x4 a[2][4], b[2][4];
   load16(a[0], xa + (long)p.tap_off[0] * 32);
-  load16(b[0], wb);
+  loadw(b[0], wb);
 #pragma unroll
   for (int tp = 0; tp < NT; ++tp) {
     if (tp + 1 < NT) {
       load16(a[(tp + 1) & 1], xa + (long)p.tap_off[tp + 1] * 32);
-      load16(b[(tp + 1) & 1], wb + (tp + 1) * 1024);
+      loadw(b[(tp + 1) & 1], wb + (tp + 1) * 1024);
     }
     // keep the prefetch above the MFMAs: without the fences hipcc sinks every load next to its
     // use (2 loads -> vmcnt -> 4 MFMAs), trading the latency hiding for registers
@@ -91,18 +100,21 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
     mfma16(acc, a[tp & 1], b[tp & 1]);
     __builtin_amdgcn_sched_barrier(0);
   }
-  conv_epilogue(acc, p.ep, out_vox, valid, p.M, red, bmean);
+  TileStats ts;
+  conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.M - (int)blockIdx.x * 128), red, bmean, &ts);
+  stats_write(p.ep, blockIdx.x, ts);
 }
 
 // ---------------------------------------------------------------------------------
-// Weight packing: PyTorch [O][I][taps] -> MFMA B-operand order [tap][h][j][s].
-//   forward : packed[t][h][j][s] = w[o=j][i=16h+s][t]
-//   dgrad   : packed[t][h][j][s] = w[o=16h+s][i=j][T-1-t]
+// Weight packing: PyTorch [O][I][taps] -> MFMA B-operand order [tap][q][lane=(h,j)][e], k = 16h + 4q + e:
+// lane (h, j) reads one float4 per q, and the 64 lanes of a wave read one contiguous KB.
+//   forward : packed = w[o=j][i=k][t]
+//   dgrad   : packed = w[o=k][i=j][T-1-t]
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ packed, int T, int flip) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * 1024) return;
-  const int s = idx & 15, j = (idx >> 4) & 31, h = (idx >> 9) & 1, t = idx >> 10;
-  const int k = 16 * h + s;
+  const int e = idx & 3, j = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, t = idx >> 10;
+  const int k = 16 * h + 4 * q + e;
   float v;
   if (!flip) v = w[((long)j * 32 + k) * T + t];
   else       v = w[((long)k * 32 + j) * T + (T - 1 - t)];
@@ -296,17 +308,28 @@ extern "C" int as_conv32_num_blocks(const as_pcl* gout) {
   return as_div_up(M, 128);
 }
 
+// Number of BatchNorm partials as_conv32_fwd writes for this configuration.
+extern "C" int as_conv32_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
+  if (conv32_lds_applicable(gin, gout, s)) return conv32_lds_grid(gout);
+  return as_conv32_num_blocks(gout);
+}
+
 extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, const float* bias,
                              float* z, const as_pcl* gout, const as_conv_shape* s,
                              int epilogue, const float* ep_scale, const float* ep_shift, float slope,
-                             const float* residual, float* stat_mean, float* stat_m2, void* stream) {
+                             const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream) {
   if (int e = check_conv(gin, gout, s, "as_conv32_fwd")) return e;
   AS_CHECK_ARG(x && packed_w && z, "as_conv32_fwd: null pointer");
-  AS_CHECK_ARG(epilogue_args_ok(epilogue, ep_scale, ep_shift, stat_mean, stat_m2), "as_conv32_fwd: bad epilogue arguments");
+  AS_CHECK_ARG(epilogue_args_ok(epilogue, ep_scale, ep_shift, stat_mean, stat_m2, stat_cnt), "as_conv32_fwd: bad epilogue arguments");
+  if (conv32_lds_applicable(gin, gout, s))
+    return conv32_lds_launch(x, gin, packed_w, bias, z, gout, s, epilogue, ep_scale, ep_shift, slope, residual,
+                             stat_mean, stat_m2, stat_cnt, stream);
   ConvArgs a;
   a.x = x; a.wp = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = residual;
   a.ep.stat_mean = epilogue == 0 ? stat_mean : nullptr; a.ep.stat_m2 = epilogue == 0 ? stat_m2 : nullptr;
+  a.ep.stat_cnt = epilogue == 0 ? stat_cnt : nullptr;
   a.ep.epilogue = epilogue; a.ep.slope = slope;
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
   const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;

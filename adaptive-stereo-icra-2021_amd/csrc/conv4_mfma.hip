@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256) void conv4_fwd_kernel(Conv4Args p) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
   }
-  conv_epilogue(acc, p.ep, out_vox, valid, p.M, red, bmean);
+  TileStats ts;
+  conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.M - (int)blockIdx.x * 128), red, bmean, &ts);
+  stats_write(p.ep, blockIdx.x, ts);
 }
 
 // packed[t][j][h][co] = w[co][c = 2j+h][t]  (0 for c >= Cin)
@@ -224,14 +226,15 @@ extern "C" int as_conv4_pack_weights(const float* w, int Cin, float* packed, con
 extern "C" int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* packed_w, const float* bias,
                             float* z, const as_pcl* gout, const as_conv_shape* s,
                             int epilogue, const float* ep_scale, const float* ep_shift, float slope,
-                            float* stat_mean, float* stat_m2, void* stream) {
+                            float* stat_mean, float* stat_m2, float* stat_cnt, void* stream) {
   if (int e = check4(gin, gout, s, "as_conv4_fwd")) return e;
   AS_CHECK_ARG(x4 && packed_w && z, "as_conv4_fwd: null pointer");
-  AS_CHECK_ARG(epilogue_args_ok(epilogue, ep_scale, ep_shift, stat_mean, stat_m2), "as_conv4_fwd: bad epilogue arguments");
+  AS_CHECK_ARG(epilogue_args_ok(epilogue, ep_scale, ep_shift, stat_mean, stat_m2, stat_cnt), "as_conv4_fwd: bad epilogue arguments");
   Conv4Args a;
   a.x4 = x4; a.wp = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = nullptr;
   a.ep.stat_mean = epilogue == 0 ? stat_mean : nullptr; a.ep.stat_m2 = epilogue == 0 ? stat_m2 : nullptr;
+  a.ep.stat_cnt = epilogue == 0 ? stat_cnt : nullptr;
   a.ep.epilogue = epilogue; a.ep.slope = slope;
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
   const int64_t M = (int64_t)gout->B * gout->H * gout->W;

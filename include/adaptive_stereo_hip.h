@@ -69,21 +69,22 @@ int as_cost_volume_bwd(const float* gvol, float* gL, float* gR, const as_pcl* g,
  *   produces the weights of the data-gradient convolution (in/out swapped, taps
  *   mirrored), so dgrad is the same kernel as forward.
  * as_conv32_fwd: z = conv(x) + bias into the interior of PCL z.
- *   epilogue 0: raw output; if stat_mean != NULL also writes per-workgroup
- *               (mean, M2) partials [nblocks][32] for train-mode BatchNorm;
+ *   epilogue 0: raw output (+ residual[v][c] if given); if stat_mean != NULL also writes
+ *               BatchNorm partials: stat_mean/stat_m2 [parts][32], stat_cnt [parts] with
+ *               parts = as_conv32_stat_parts() (capacity as_conv32_num_blocks() always suffices);
  *   epilogue 1: z = lrelu(acc*ep_scale[c] + ep_shift[c]) (+ residual[v][c] if given):
  *               eval-mode BatchNorm + LeakyReLU (+ BasicBlock skip) fused.
- *   Returns the number of workgroups launched via *nblocks_out (may be NULL).
  * as_conv32_wgrad: dW[o][i][tap] (PyTorch layout) = sum_v x[v+tap][i] * gz[v][o];
  *   workspace must hold as_conv32_wgrad_workspace() floats. db (may be NULL) gets
  *   sum_v gz[v][o]. */
 int as_conv32_pack_weights(const float* w, float* packed, const as_conv_shape* s,
                            int transpose_flip, void* stream);
 int as_conv32_num_blocks(const as_pcl* gout);
+int as_conv32_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, const float* bias,
                   float* z, const as_pcl* gout, const as_conv_shape* s,
                   int epilogue, const float* ep_scale, const float* ep_shift, float slope,
-                  const float* residual, float* stat_mean, float* stat_m2, void* stream);
+                  const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
 int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
                     const as_conv_shape* s, float* dW, float* db, float* workspace, void* stream);
@@ -91,7 +92,7 @@ int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as
 /* ---- BatchNorm (train/eval) + LeakyReLU around the convolution --------------
  * nn.BatchNorm3d / nn.BatchNorm2d (eps, momentum as given) + nn.LeakyReLU(0.2)
  * (stereo_net.py:17,29,39,94,159).
- * as_bn_finalize: merges the conv's per-workgroup (mean,M2) partials (Chan, fp64),
+ * as_bn_finalize: merges the conv's (count, mean, M2) partials (Chan, fp64),
  *   writes save_mean/save_invstd, scale = gamma*invstd, shift = beta - mean*scale,
  *   and updates running_mean / running_var (unbiased) with `momentum`.
  * as_bn_eval_affine: scale/shift from the running statistics (eval mode).
@@ -100,7 +101,7 @@ int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as
  *   batch statistics (full BatchNorm backward), train=0 treats mean/invstd as constants.
  *   workspace: as_bn_bwd_workspace() floats. If g_res != NULL it receives nothing (the
  *   skip connection's gradient is g_a itself and is handled by the caller). */
-int as_bn_finalize(const float* stat_mean, const float* stat_m2, int nblocks, int64_t count,
+int as_bn_finalize(const float* stat_mean, const float* stat_m2, const float* stat_cnt, int nparts,
                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                    float momentum, float eps, float* save_mean, float* save_invstd,
                    float* scale, float* shift, void* stream);
@@ -156,7 +157,7 @@ int as_conv4_pack_weights(const float* w, int Cin, float* packed, const as_conv_
 int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* packed_w, const float* bias,
                  float* z, const as_pcl* gout, const as_conv_shape* s,
                  int epilogue, const float* ep_scale, const float* ep_shift, float slope,
-                 float* stat_mean, float* stat_m2, void* stream);
+                 float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
 int64_t as_conv4_wgrad_workspace(const as_pcl* gout, const as_conv_shape* s);
 int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,
                    const as_conv_shape* s, int Cin, float* dW, float* db, float* workspace, void* stream);

@@ -76,6 +76,11 @@ CONV_CASES = [
   (2, 1, 17, 37, ConvShape(1, 3, 3, 0, 1, 1, 1, 1), (0, 1, 1)),
   (1, 1, 21, 45, ConvShape(1, 3, 3, 0, 2, 2, 2, 1), (0, 8, 8)),
   (1, 1, 33, 40, ConvShape(1, 3, 3, 0, 8, 8, 8, 1), (0, 8, 8)),
+  # LDS-staged instance: several 128-pixel tiles per row with a ragged tail, more tiles than workgroups
+  (2, 1, 19, 300, ConvShape(1, 3, 3, 0, 1, 1, 1, 1), (0, 8, 8)),
+  (1, 1, 23, 257, ConvShape(1, 3, 3, 0, 4, 4, 4, 1), (0, 8, 8)),
+  (3, 1, 130, 131, ConvShape(1, 3, 3, 0, 8, 8, 8, 1), (0, 8, 8)),
+  (1, 1, 375, 1242, ConvShape(1, 3, 3, 0, 2, 2, 2, 1), (0, 8, 8)),
 ]
 
 
@@ -95,8 +100,7 @@ def test_conv32_fwd_dgrad_wgrad(B, D, H, W, shape, halo):
   xb = ops.ncdhw_to_pcl(x.detach().to(DEV), g)
   wd, bd = w.detach().to(DEV), b.detach().to(DEV)
   wp = ops.pack_weights(wd, shape, False)
-  nblk = nat.load().as_conv32_num_blocks(g)
-  stats = (torch.empty(nblk * 32, device=DEV), torch.empty(nblk * 32, device=DEV))
+  stats = ops.conv32_stat_parts(g, g, shape, DEV)
   zb = ops.conv32(xb, g, wp, bd, g, shape, stats=stats)
   # fp32 fma chain over K = 32*taps products of O(1/sqrt(K)) terms
   close(ops.pcl_to_ncdhw(zb, g), z_ref, 2e-5, 1e-5, "conv fwd")
@@ -107,7 +111,7 @@ def test_conv32_fwd_dgrad_wgrad(B, D, H, W, shape, halo):
   gamma, beta = rnd(32, seed=5) * 0.5 + 1.0, rnd(32, seed=6) * 0.2
   rm, rv = rnd(32, seed=7) * 0.1, rnd(32, seed=8).abs() + 0.5
   rm_d, rv_d = rm.to(DEV).clone(), rv.to(DEV).clone()
-  st = ops.bn_train_stats(stats, g.voxels(), gamma.to(DEV), beta.to(DEV), rm_d, rv_d, nblk)
+  st = ops.bn_train_stats(stats, gamma.to(DEV), beta.to(DEV), rm_d, rv_d)
   zr = z_ref.detach()
   mean_ref = zr.mean(dim=(0, 2, 3, 4))
   var_ref = zr.var(dim=(0, 2, 3, 4), unbiased=False)
@@ -123,11 +127,14 @@ def test_conv32_fwd_dgrad_wgrad(B, D, H, W, shape, halo):
   gxb = ops.conv32(gzb, g, wpt, None, g, shape)
   close(ops.pcl_to_ncdhw(gxb, g), x.grad, 3e-5, 1e-5, "conv dgrad")
 
-  # weight / bias gradient: sums over B*D*H*W voxels
+  # weight / bias gradient: fp32 sums over B*D*H*W voxels of O(1) terms (up to 465,750 of them): the
+  # summation order differs from oneDNN's, so the bar is relative to the result's scale
   dW, db = ops.conv32_wgrad(xb, g, gzb, g, shape)
-  n = g.voxels()
-  close(dW, w.grad, 2e-6 * n ** 0.5 + 1e-5, 2e-5, "conv wgrad")
-  close(db, b.grad, 2e-6 * n ** 0.5 + 1e-5, 2e-5, "conv bias grad")
+  for name, got, exp in (("conv wgrad", dW, w.grad), ("conv bias grad", db, b.grad)):
+    scale = float(exp.abs().max())
+    close(got, exp, 2e-4 * scale + 1e-5, 0, name)
+    rel = float((got.cpu().double() - exp.double()).norm() / exp.double().norm())
+    assert rel < 1e-4, "%s: relative L2 error %.2e" % (name, rel)
 
 
 def test_conv32_fused_eval_epilogue_and_residual():
@@ -359,7 +366,7 @@ def test_conv4_fwd_and_wgrad(B, H, W, Cin, k, stride, pad):
   nat.call("as_conv4_pack_weights", nat.ptr(wd), Cin, nat.ptr(wp), shape, nat.stream())
   z = ops.pcl_zeros(gout, DEV)
   nat.call("as_conv4_fwd", nat.ptr(x4), g4, nat.ptr(wp), nat.ptr(bd), nat.ptr(z), gout, shape, 0, None, None, 0.2,
-           None, None, nat.stream())
+           None, None, None, nat.stream())
   close(ops.pcl_to_ncdhw(z, gout)[:, :, 0], z_ref, 1e-5, 1e-5, "conv4 fwd")
   gzb = ops.ncdhw_to_pcl(gz.unsqueeze(2).to(DEV), gout)
   dW = torch.empty(32, Cin, k, k, device=DEV); db = torch.empty(32, device=DEV)

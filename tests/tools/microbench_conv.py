@@ -35,8 +35,7 @@ for name, g, shape in cases:
   b = torch.zeros(32, device=dev)
   wp = ops.pack_weights(w, shape, False)
   z = torch.zeros(g.numel(), device=dev)
-  nblk = nat.load().as_conv32_num_blocks(g)
-  stats = (torch.empty(nblk * 32, device=dev), torch.empty(nblk * 32, device=dev))
+  stats = ops.conv32_stat_parts(g, g, shape, dev)
   flops = 2.0 * g.voxels() * 1024 * taps
   t_f = timeit(lambda: ops.conv32(x, g, wp, b, g, shape, out=z, stats=stats))
   one = b + 1
@@ -51,7 +50,7 @@ for name, g, shape in cases:
   def bwd():
     gzz, _, _ = ops.bn_act_bwd(a, z, st, gam, g, True); ops.POOL.put(gzz, g)
   t_b = timeit(bwd)
-  t_fin = timeit(lambda: ops.bn_train_stats(stats, g.voxels(), gam, b, None, None, nblk))
+  t_fin = timeit(lambda: ops.bn_train_stats(stats, gam, b, None, None))
   byts = g.voxels() * 128
   print("%-22s fwd %8.1f us %6.1f TF | fused-ep %8.1f us %6.1f TF | wgrad %8.1f us %6.1f TF | bn_act %7.1f us %5.2f TB/s | bn_bwd %7.1f us %5.2f TB/s | finalize %6.1f us" % (
       name, t_f, flops / t_f / 1e6, t_fe, flops / t_fe / 1e6, t_w, flops / t_w / 1e6, t_a, 3 * byts / t_a / 1e6, t_b, 5 * byts / t_b / 1e6, t_fin), flush=True)
