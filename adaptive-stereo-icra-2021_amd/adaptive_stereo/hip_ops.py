@@ -302,67 +302,131 @@ class CostAggregationFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------
-# a1 trunk: six BasicBlocks + conv_alone of FeatureExtractorNetwork (stereo_net.py:70-77, 83-85)
+# a1: FeatureExtractorNetwork (stereo_net.py:54-85): k strided 5x5 convolutions (no activation in
+# between), six BasicBlocks, conv_alone — whole module in PCL, forward and hand-written backward
 # ----------------------------------------------------------------------------------------
-class FeatureTrunkFn(torch.autograd.Function):
-  """x [B,32,H,W] (NCHW, the output of the strided convolutions) -> features [B,32,H,W].
-  params: 6 x (conv w, conv b, bn w, bn b), then conv_alone (w, b)."""
+CONV5_S2 = ConvShape(1, 5, 5, 0, 2, 2, 1, 2)
+
+
+def _down(n):
+  return (n - 1) // 2 + 1
+
+
+class FeatureExtractorFn(torch.autograd.Function):
+  """rgb [B,3,H,W] -> features [B,32,Hc,Wc] (NCHW, the public layout).
+  params: k x (downsample w, b), 6 x (conv w, conv b, bn w, bn b), conv_alone (w, b)."""
 
   @staticmethod
-  def forward(ctx, x, train, bn_buffers, *params):
-    assert len(params) == 26
-    x = f32c(x)
+  def forward(ctx, rgb, k, train, bn_buffers, *params):
+    k = int(k)
+    assert len(params) == 2 * k + 26
+    rgb = f32c(rgb)
     params = [f32c(p) for p in params]
-    B, C, H, W = x.shape
-    dev = x.device
-    g = Pcl(B, 1, H, W, 0, 1, 1)
-    shape = conv_shape_2d(1)
+    B, C, H, W = rgb.shape
+    if C != 3:
+      raise RuntimeError("FeatureExtractorFn: expected an RGB image [B,3,H,W]")
+    dev = rgb.device
+    lib = nat.load()
     need_bwd = any(ctx.needs_input_grad)
-    x0 = POOL.get(g, dev)
-    pcl_interior(x0, g).copy_(x.permute(0, 2, 3, 1).unsqueeze(1))
-    xs, zs, sts = [x0], [], []
+
+    # head: level 0 = image (PCL4, halo 2); level i = output of downsample[i-1]
+    g4 = Pcl(B, 1, H, W, 0, 2, 2)
+    in4 = POOL.get(g4, dev, channels=4)
+    call("as_pack_in4", None, ptr(rgb), 3, ptr(in4), g4, stream())
+    geoms, levels = [], []
+    h, w = H, W
+    for i in range(k):
+      h, w = _down(h), _down(w)
+      halo = 2 if i + 1 < k else 1            # feeds another 5x5 stride-2 conv, or the 3x3 trunk
+      gi = Pcl(B, 1, h, w, 0, halo, halo)
+      out = POOL.get(gi, dev)
+      wd, bd = params[2 * i], params[2 * i + 1]
+      if i == 0:
+        wp = _empty(25 * 128, dev)
+        call("as_conv4_pack_weights", ptr(wd), 3, ptr(wp), CONV5_S2, stream())
+        call("as_conv4_fwd", ptr(in4), g4, ptr(wp), ptr(bd), ptr(out), gi, CONV5_S2, 0, None, None, LEAKY_SLOPE,
+             None, None, None, stream())
+      else:
+        conv32(levels[-1], geoms[-1], pack_weights(wd, CONV5_S2, False), bd, gi, CONV5_S2, out=out)
+      geoms.append(gi); levels.append(out)
+
+    g = geoms[-1]
+    shape = conv_shape_2d(1)
+    tp = params[2 * k:]
+    xs, zs, sts = [levels[-1]], [], []
     for l in range(6):
-      w, b, gamma, beta = params[4 * l:4 * l + 4]
+      wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
       rm, rv = bn_buffers[l]
-      z, a, st = block_forward(xs[-1], g, shape, w, b, gamma, beta, rm, rv, train, True, need_bwd)
+      z, a, st = block_forward(xs[-1], g, shape, wl, bl, gamma, beta, rm, rv, train, True, need_bwd)
       zs.append(z); sts.append(st); xs.append(a)
-    wp = pack_weights(params[24], shape, False)
-    out = conv32(xs[6], g, wp, params[25], g, shape)
+      if not need_bwd:
+        POOL.put(xs[-2], g)
+    out = conv32(xs[6], g, pack_weights(tp[24], shape, False), tp[25], g, shape)
     feats = pcl_interior(out, g)[:, 0].permute(0, 3, 1, 2).contiguous()
     POOL.put(out, g)
     if need_bwd:
-      ctx.g, ctx.train = g, bool(train)
+      ctx.k, ctx.g4, ctx.geoms, ctx.train = k, g4, geoms, bool(train)
+      ctx.in4, ctx.levels = in4, levels
       ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
       ctx.save_for_backward(*params)
     else:
-      for buf in xs:
-        POOL.put(buf, g)
+      POOL.put(xs[-1], g); POOL.put(in4, g4, channels=4)
+      for buf, gi in zip(levels[:-1], geoms[:-1]):
+        POOL.put(buf, gi)
     return feats
 
   @staticmethod
   def backward(ctx, g_feats):
+    if ctx.needs_input_grad[0]:
+      raise NotImplementedError("FeatureExtractorFn: gradient w.r.t. the image is not part of the adaptation path")
     params = ctx.saved_tensors
-    g, xs, zs, sts = ctx.g, ctx.xs, ctx.zs, ctx.sts
+    k, g4, geoms = ctx.k, ctx.g4, ctx.geoms
+    g = geoms[-1]
+    xs, zs, sts, levels = ctx.xs, ctx.zs, ctx.sts, ctx.levels
     dev = g_feats.device
+    lib = nat.load()
     shape = conv_shape_2d(1)
-    grads = [None] * 26
+    tp = params[2 * k:]
+    grads = [None] * len(params)
+
     g_out = POOL.get(g, dev)
-    pcl_interior(g_out, g).copy_(g_feats.permute(0, 2, 3, 1).unsqueeze(1))
+    pcl_interior(g_out, g).copy_(f32c(g_feats).permute(0, 2, 3, 1).unsqueeze(1))
     dW, db = conv32_wgrad(xs[6], g, g_out, g, shape)
-    grads[24], grads[25] = dW, db
-    g_a = conv32(g_out, g, pack_weights(params[24], shape, True), None, g, shape)
+    grads[2 * k + 24], grads[2 * k + 25] = dW, db
+    g_a = conv32(g_out, g, pack_weights(tp[24], shape, True), None, g, shape)
     POOL.put(g_out, g)
     for l in range(5, -1, -1):
-      w, b, gamma, beta = params[4 * l:4 * l + 4]
-      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], w, gamma, g, shape, ctx.train, True,
+      wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
+      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], wl, gamma, g, shape, ctx.train, True,
                                                     True)
-      grads[4 * l:4 * l + 4] = [dW, db, g_gamma, g_beta]
+      grads[2 * k + 4 * l:2 * k + 4 * l + 4] = [dW, db, g_gamma, g_beta]
       POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
       g_a = g_x
-    g_x = pcl_interior(g_a, g)[:, 0].permute(0, 3, 1, 2).contiguous() if ctx.needs_input_grad[0] else None
-    POOL.put(g_a, g); POOL.put(xs[0], g)
-    ctx.xs = ctx.zs = ctx.sts = None
-    return (g_x, None, None) + tuple(grads)
+
+    # head, last strided convolution first.  g_a is the gradient w.r.t. levels[k-1] (geometry geoms[k-1]).
+    for i in range(k - 1, -1, -1):
+      wd = params[2 * i]
+      gi = geoms[i]
+      if i == 0:
+        dW = torch.empty_like(wd); db = _empty(32, dev)
+        ws = _empty(lib.as_conv4_wgrad_workspace(gi, CONV5_S2), dev)
+        call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_a), gi, CONV5_S2, 3, ptr(dW), ptr(db), ptr(ws), stream())
+        grads[0], grads[1] = dW, db
+      else:
+        gprev = geoms[i - 1]
+        dW, db = conv32_wgrad(levels[i - 1], gprev, g_a, gi, CONV5_S2)
+        grads[2 * i], grads[2 * i + 1] = dW, db
+        g_prev = POOL.get(gprev, dev)
+        ws = _empty(lib.as_conv32_dgrad_s2_workspace(), dev)
+        call("as_conv32_dgrad_s2", ptr(g_a), gi, ptr(wd), ptr(g_prev), gprev, ptr(ws), stream())
+        POOL.put(g_a, gi)
+        g_a = g_prev
+    POOL.put(g_a, geoms[0])
+    POOL.put(ctx.in4, g4, channels=4)
+    for buf, gi in zip(levels, geoms):
+      POOL.put(buf, gi)
+    ctx.xs = ctx.zs = ctx.sts = ctx.levels = ctx.in4 = None
+    return (None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------

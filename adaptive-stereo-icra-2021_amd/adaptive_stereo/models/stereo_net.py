@@ -12,8 +12,8 @@ The modules below are parameter containers: their nested ModuleLists exist to re
 the reference's key names.  ``forward`` never calls an nn.Conv3d/BatchNorm3d: the cost
 volume, the 3-D aggregation, the soft-argmax, the up-sampling and their backward passes
 run as hand-written HIP kernels behind ``libadaptive_stereo_hip.so`` (hip_ops.py), and so do
-the edge-aware refinement (a7) and the feature extractor's residual trunk (a1).  Only the k
-strided 5x5 convolutions at the head of the feature extractor are still issued through MIOpen.
+the edge-aware refinement (a7) and the whole feature extractor (a1).  No MIOpen/rocBLAS call is
+issued anywhere on the path.
 There is no CPU path: tensors must be on the GPU and the HIP library must be built.
 """
 import torch
@@ -82,13 +82,13 @@ class FeatureExtractorNetwork(nn.Module):
 
   def forward(self, rgb_img):
     nat.require_gpu(rgb_img)
-    x = rgb_img
-    for conv in self.downsample:          # no activation between the strided convs (:81-82); MIOpen for now
-      x = conv(x)
+    params = []
+    for conv in self.downsample:          # no activation between the strided convs (:81-82)
+      params += [conv.weight, conv.bias]
     live = [b.live() for b in self.residual_blocks]
-    params, buffers = _block_params(live)
-    params += [self.conv_alone.weight, self.conv_alone.bias]
-    out = hip_ops.FeatureTrunkFn.apply(x, self.training, buffers, *params)
+    block_params, buffers = _block_params(live)
+    params += block_params + [self.conv_alone.weight, self.conv_alone.bias]
+    out = hip_ops.FeatureExtractorFn.apply(rgb_img, self.k, self.training, buffers, *params)
     if self.training:
       _count_batches(live)
     return out

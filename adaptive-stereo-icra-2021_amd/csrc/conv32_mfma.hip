@@ -33,8 +33,8 @@ struct ConvArgs {
   const float* wp;
   EpilogueArgs ep;
   PclDev gin, gout;
-  int M;          // B*D*H*W output voxels
-  int stride;
+  ConvMap map;
+  int M;          // output voxels of this launch
   int ntaps;
   int tap_off[AS_MAX_TAPS];   // voxel offsets in the INPUT geometry
 };
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
   const int v = tile * 32 + li;
   const bool valid = v < p.M;
   int in_vox, out_vox;
-  conv_decode(valid ? v : p.M - 1, p.gin, p.gout, p.stride, in_vox, out_vox);
+  conv_decode(valid ? v : p.M - 1, p.gin, p.gout, p.map, in_vox, out_vox);
 
   const float* xa = p.x + (long)in_vox * 32 + h * 16;
   const float* wb = p.wp + lane * 4;       // packed [tap][q][lane][4]: each wave load is one contiguous KB
@@ -291,6 +291,76 @@ static int check_conv(const as_pcl* gin, const as_pcl* gout, const as_conv_shape
   return AS_OK;
 }
 
+static int launch_conv32(const ConvArgs& a, hipStream_t st, const char* who) {
+  const dim3 grid(as_div_up(a.M, 128)), block(256);
+  switch (a.ntaps) {
+    case 27: hipLaunchKernelGGL(conv32_fwd_kernel<27>, grid, block, 0, st, a); break;
+    case 25: hipLaunchKernelGGL(conv32_fwd_kernel<25>, grid, block, 0, st, a); break;
+    case 9:  hipLaunchKernelGGL(conv32_fwd_kernel<9>, grid, block, 0, st, a); break;
+    case 6:  hipLaunchKernelGGL(conv32_fwd_kernel<6>, grid, block, 0, st, a); break;
+    case 4:  hipLaunchKernelGGL(conv32_fwd_kernel<4>, grid, block, 0, st, a); break;
+    default:
+      as_set_error("%s: no kernel instance for %d taps", who, a.ntaps);
+      return AS_ERR_ARG;
+  }
+  return AS_OK;
+}
+
+// ---- data gradient of the stride-2 5x5 convolution (downsample[1..k-1], stereo_net.py:61-69) --------
+// gx[yi][xi][ci] = sum over taps (j,l) with (yi+2-j), (xi+2-l) even of gz[(yi+2-j)/2][(xi+2-l)/2][co] * W[co][ci][j][l].
+// Split by the parity (py,px) of (yi,xi): each phase is an ordinary gather-convolution over gz with the
+// taps j = py, py+2(, py+4), l likewise (9/6/6/4 taps), writing every second output pixel.  gz's zero
+// halo (>= 1) supplies the bounds.  packed[t][q][lane=(h,j)][e] = w[o = 16h+4q+e][i = j][tap_t].
+struct TapSubset { int n; int idx[9]; };
+
+__global__ void pack_weights_subset_kernel(const float* __restrict__ w, float* __restrict__ packed, int T, TapSubset ts) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ts.n * 1024) return;
+  const int e = idx & 3, j = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, t = idx >> 10;
+  const int k = 16 * h + 4 * q + e;
+  packed[idx] = w[((long)k * 32 + j) * T + ts.idx[t]];
+}
+
+extern "C" int64_t as_conv32_dgrad_s2_workspace(void) { return 25 * 1024; }
+
+extern "C" int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const float* w, float* gx, const as_pcl* ggx,
+                                  float* workspace, void* stream) {
+  AS_CHECK_ARG(as_pcl_ok(ggz) && as_pcl_ok(ggx) && gz && w && gx && workspace, "as_conv32_dgrad_s2: bad argument");
+  AS_CHECK_ARG(ggz->D == 1 && ggx->D == 1 && ggz->B == ggx->B, "as_conv32_dgrad_s2: 2-D tensors of equal batch expected");
+  AS_CHECK_ARG(ggz->H == (ggx->H - 1) / 2 + 1 && ggz->W == (ggx->W - 1) / 2 + 1,
+               "as_conv32_dgrad_s2: gz extent is not that of a 5x5 stride-2 pad-2 convolution of gx's extent");
+  AS_CHECK_ARG(ggz->ph >= 1 && ggz->pw >= 1, "as_conv32_dgrad_s2: gz needs a zero halo of 1");
+  hipStream_t st = (hipStream_t)stream;
+  const int Wp = ggz->W + 2 * ggz->pw;
+  float* wp = workspace;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      const int Hl = (ggx->H - py + 1) / 2, Wl = (ggx->W - px + 1) / 2;
+      if (Hl <= 0 || Wl <= 0) continue;
+      ConvArgs a;
+      TapSubset ts; ts.n = 0;
+      for (int j = py; j < 5; j += 2)
+        for (int l = px; l < 5; l += 2) {
+          ts.idx[ts.n] = j * 5 + l;
+          // yi = 2y'+py: yo = y' + (py + 2 - j)/2 ; same for x
+          a.tap_off[ts.n] = ((py + 2 - j) / 2) * Wp + (px + 2 - l) / 2;
+          ++ts.n;
+        }
+      hipLaunchKernelGGL(pack_weights_subset_kernel, dim3(as_div_up(ts.n * 1024, 256)), dim3(256), 0, st, w, wp, 25, ts);
+      AS_CHECK_LAUNCH("as_conv32_dgrad_s2(pack)");
+      a.x = gz; a.wp = wp;
+      a.ep.bias = nullptr; a.ep.z = gx; a.ep.ep_scale = nullptr; a.ep.ep_shift = nullptr; a.ep.residual = nullptr;
+      a.ep.stat_mean = nullptr; a.ep.stat_m2 = nullptr; a.ep.stat_cnt = nullptr; a.ep.epilogue = 0; a.ep.slope = 0.f;
+      a.gin = as_make_dev(ggz); a.gout = as_make_dev(ggx);
+      a.map.Hl = Hl; a.map.Wl = Wl; a.map.in_stride = 1; a.map.out_stride = 2; a.map.out_oy = py; a.map.out_ox = px;
+      a.M = ggx->B * Hl * Wl; a.ntaps = ts.n;
+      if (int e = launch_conv32(a, st, "as_conv32_dgrad_s2")) return e;
+      AS_CHECK_LAUNCH("as_conv32_dgrad_s2");
+      wp += ts.n * 1024;
+    }
+  return AS_OK;
+}
+
 extern "C" int as_conv32_pack_weights(const float* w, float* packed, const as_conv_shape* s,
                                       int transpose_flip, void* stream) {
   AS_CHECK_ARG(w && packed && s, "as_conv32_pack_weights: null pointer");
@@ -333,19 +403,12 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
   a.ep.epilogue = epilogue; a.ep.slope = slope;
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
   const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;
-  a.M = (int)M; a.stride = s->stride; a.ntaps = s->kd * s->kh * s->kw;
+  a.M = (int)M; a.ntaps = s->kd * s->kh * s->kw;
+  a.map.Hl = gout->H; a.map.Wl = gout->W; a.map.in_stride = s->stride; a.map.out_stride = 1; a.map.out_oy = 0; a.map.out_ox = 0;
   if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_fwd")) return e;
   as_prof_mark(0, (hipStream_t)stream, 1, 0.0);
-  const dim3 grid(as_div_up(M, 128)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  switch (a.ntaps) {
-    case 27: hipLaunchKernelGGL(conv32_fwd_kernel<27>, grid, block, 0, st, a); break;
-    case 25: hipLaunchKernelGGL(conv32_fwd_kernel<25>, grid, block, 0, st, a); break;
-    case 9:  hipLaunchKernelGGL(conv32_fwd_kernel<9>, grid, block, 0, st, a); break;
-    default:
-      as_set_error("as_conv32_fwd: no kernel instance for %d taps (built: 3x3, 5x5, 3x3x3)", a.ntaps);
-      return AS_ERR_ARG;
-  }
+  if (int e = launch_conv32(a, st, "as_conv32_fwd")) return e;
   as_prof_mark(0, (hipStream_t)stream, 0, 2.0 * (double)M * 1024.0 * a.ntaps);
   AS_CHECK_LAUNCH("as_conv32_fwd");
   return AS_OK;

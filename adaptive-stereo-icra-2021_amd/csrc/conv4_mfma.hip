@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void conv4_fwd_kernel(Conv4Args p) {
   const int v = (blockIdx.x * 4 + wave) * 32 + li;
   const bool valid = v < p.M;
   int in_vox, out_vox;
-  conv_decode(valid ? v : p.M - 1, p.gin, p.gout, p.stride, in_vox, out_vox);
+  ConvMap m; m.Hl = p.gout.H; m.Wl = p.gout.W; m.in_stride = p.stride; m.out_stride = 1; m.out_oy = 0; m.out_ox = 0;
+  conv_decode(valid ? v : p.M - 1, p.gin, p.gout, m, in_vox, out_vox);
   const float* xa = p.x4 + (long)in_vox * 4;
   f32x16 acc;
   conv_init_acc(acc, p.ep.bias, li);

@@ -115,17 +115,24 @@ __device__ inline void stats_write(const EpilogueArgs& e, int part, const TileSt
   if (threadIdx.x == 0) e.stat_cnt[part] = ts.n;
 }
 
-// Output-voxel decode shared by the forward kernels: flattened index -> (b,d,y,x) -> PCL voxel
-// index of the output and of the (strided) input anchor.
-__device__ inline void conv_decode(int vc, const PclDev& gin, const PclDev& gout, int stride, int& in_vox, int& out_vox) {
-  const int W = gout.W, H = gout.H, D = gout.D;
+// Output-voxel decode shared by the forward kernels: flattened index over the launch's logical
+// extent (B, D, Hl, Wl) -> PCL voxel index of the output and of the input anchor.
+//   forward conv : input anchor = (y*in_stride, x*in_stride), output = (y, x)
+//   phase of a stride-2 data gradient: input anchor = (y, x), output = (y*out_stride+oy, x*out_stride+ox)
+struct ConvMap {
+  int Hl, Wl;                 // logical extent of this launch (H and W)
+  int in_stride, out_stride, out_oy, out_ox;
+};
+
+__device__ inline void conv_decode(int vc, const PclDev& gin, const PclDev& gout, const ConvMap& m, int& in_vox, int& out_vox) {
+  const int D = gout.D;
   int t = vc;
-  const int x = t % W; t /= W;
-  const int y = t % H; t /= H;
+  const int x = t % m.Wl; t /= m.Wl;
+  const int y = t % m.Hl; t /= m.Hl;
   const int d = t % D;
   const int b = t / D;
-  in_vox = (int)gin.vox(b, d, y * stride, x * stride);
-  out_vox = (int)gout.vox(b, d, y, x);
+  in_vox = (int)gin.vox(b, d, y * m.in_stride, x * m.in_stride);
+  out_vox = (int)gout.vox(b, d, y * m.out_stride + m.out_oy, x * m.out_stride + m.out_ox);
 }
 
 static inline int epilogue_args_ok(int epilogue, const float* sc, const float* sh, const float* sm, const float* s2,

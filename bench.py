@@ -205,7 +205,7 @@ def main():
                                -(-args.height // 2 ** args.k), -(-args.width // 2 ** args.k)),
                "pairs_per_gpu": B, "global_batch": world * B,
                "parallelism": "dp%d (per-replica BatchNorm statistics, one flat RCCL gradient all-reduce)" % world,
-               "kernels": "hand-written HIP for everything except the k strided 5x5 convs at the head of the feature extractor (MIOpen)"},
+               "kernels": "all hand-written HIP (no MIOpen/rocBLAS on the path)"},
     "fwd_pairs_per_s": round(pairs / t_fwd, 3),
     "fwd_ms_per_step": round(1e3 * t_fwd / args.steps, 3),
     "roofline": roofline,

@@ -85,6 +85,13 @@ int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, cons
                   float* z, const as_pcl* gout, const as_conv_shape* s,
                   int epilogue, const float* ep_scale, const float* ep_shift, float slope,
                   const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
+/* Data gradient of nn.Conv2d(32,32,5,stride=2,padding=2) (FeatureExtractorNetwork.downsample[1..k-1],
+ * stereo_net.py:61-69): four parity phases of a transposed convolution, each a gather over gz.
+ * gz: PCL of the convolution's output extent (halo >= 1); gx: PCL of its input extent; w: PyTorch
+ * [32][32][5][5]; workspace: as_conv32_dgrad_s2_workspace() floats. */
+int64_t as_conv32_dgrad_s2_workspace(void);
+int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const float* w, float* gx, const as_pcl* ggx,
+                       float* workspace, void* stream);
 int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
                     const as_conv_shape* s, float* dW, float* db, float* workspace, void* stream);

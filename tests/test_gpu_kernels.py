@@ -426,3 +426,24 @@ def test_conv32to1_2d_fused_tail(B, H, W):
   close(ops.pcl_to_ncdhw(g_a, g)[:, :, 0], a.grad, 5e-6, 1e-5, "tail dgrad")
   n = B * H * W
   close(g_w, w.grad, 2e-6 * n ** 0.5, 1e-5, "tail wgrad"); close(g_b, b.grad, 2e-6 * n ** 0.5, 1e-5, "tail bias grad")
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 9, 12), (2, 21, 30), (1, 47, 156), (1, 188, 621)])
+def test_conv32_dgrad_stride2(B, H, W):
+  """Data gradient of Conv2d(32,32,5,stride=2,padding=2): four parity phases of a transposed conv."""
+  x = rnd(B, 32, H, W, seed=1).requires_grad_(True)
+  w = rnd(32, 32, 5, 5, seed=2, scale=0.035)
+  z = F.conv2d(x, w, None, stride=2, padding=2)
+  gz = rnd(*z.shape, seed=3)
+  z.backward(gz)
+  Ho, Wo = z.shape[-2:]
+  ggz, ggx = Pcl(B, 1, Ho, Wo, 0, 1, 1), Pcl(B, 1, H, W, 0, 2, 2)
+  gzb = ops.ncdhw_to_pcl(gz.unsqueeze(2).to(DEV), ggz)
+  gxb = ops.pcl_zeros(ggx, DEV)
+  lib = nat.load()
+  wd = w.to(DEV)
+  ws = torch.empty(lib.as_conv32_dgrad_s2_workspace(), device=DEV)
+  nat.call("as_conv32_dgrad_s2", nat.ptr(gzb), ggz, nat.ptr(wd), nat.ptr(gxb), ggx, nat.ptr(ws), nat.stream())
+  close(ops.pcl_to_ncdhw(gxb, ggx)[:, :, 0], x.grad, 3e-5, 1e-5, "stride-2 dgrad")
+  full = ops.pcl_view(gxb, ggx).clone(); ops.pcl_interior(full, ggx).zero_()
+  assert float(full.abs().max()) == 0.0, "dgrad wrote into the halo"
