@@ -90,7 +90,8 @@ _SIGNATURES = {
   "as_masked_sum": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_sumsq_workspace": (c_i64, [c_i64]),
   "as_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
-  "as_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_float, c_float, c_float, c_float, c_int, c_vp]),
+  "as_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_float, c_float, c_float, c_float, c_int, c_vp,
+                           c_vp]),
   "as_prof_enable": (c_int, [c_int]),
   "as_prof_reset": (c_int, []),
   "as_prof_read": (c_int, [c_int, _P(c_i64), _P(ctypes.c_double), _P(ctypes.c_double)]),

@@ -77,6 +77,7 @@ class FusedClipAdam(object):
     self.exp_avg = torch.zeros_like(arena.params)
     self.exp_avg_sq = torch.zeros_like(arena.params)
     self.step_count = 0
+    self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)   # same count on the device (hipGraph replay)
     self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
     self.coef = torch.ones(1, dtype=torch.float32, device=dev)
     self.ws = torch.empty(nat.load().as_sumsq_workspace(arena.numel), dtype=torch.float32, device=dev)
@@ -84,6 +85,7 @@ class FusedClipAdam(object):
   def step(self, clip=True):
     a = self.arena
     self.step_count += 1
+    self.step_dev += 1.0
     for gi, (s, e) in enumerate(a.group_bounds):
       scale = None
       if clip and gi == self.clip_group:
@@ -93,7 +95,7 @@ class FusedClipAdam(object):
         scale = self.coef
       nat.call("as_adam_step", nat.ptr(a.params[s:e]), nat.ptr(a.grads[s:e]), nat.ptr(self.exp_avg[s:e]),
                nat.ptr(self.exp_avg_sq[s:e]), e - s, nat.ptr(scale), self.lr, self.betas[0], self.betas[1],
-               self.eps, self.step_count, nat.stream())
+               self.eps, self.step_count, nat.ptr(self.step_dev), nat.stream())
 
   def grad_norm(self):
     """Pre-clip L2 norm of the clipped group at the last step (device scalar)."""
@@ -119,6 +121,7 @@ class OnlineAdapter(object):
     self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
     dev = self.arena.params.device
     self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [count, loss_sum, fcs_sum, pairs]
+    self._graph = None
 
   # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
   @torch.no_grad()
@@ -131,6 +134,11 @@ class OnlineAdapter(object):
 
   # -- one adaptation step: adapt.py:304-396 (NONSTOP) --------------------------------------------
   def step(self, left, right):
+    if self._graph is not None:
+      return self._replay(left, right)
+    return self._step_eager(left, right)
+
+  def _step_eager(self, left, right):
     self.feature_net.train(); self.stereo_net.train()
     self.arena.rebind_grads()
     self.arena.zero_grads()
@@ -150,10 +158,45 @@ class OnlineAdapter(object):
       loss, fcs = self._distributed_backward(total, mask, fcs_map, left.shape[0])
 
     self.optimizer.step(clip=self.clip)
-    self.fcs_smoothed = fcs if self.fcs_smoothed is None else online_ema(self.fcs_smoothed, fcs,
-                                                                          self.fcs_ema_weight)
+    # FCS EMA (adapt.py:356-359), in place so that a captured graph keeps updating the same tensor
+    if self.fcs_smoothed is None:
+      self.fcs_smoothed = fcs.detach().clone()
+    else:
+      self.fcs_smoothed.mul_(self.fcs_ema_weight).add_(fcs.detach(), alpha=1.0 - self.fcs_ema_weight)
     out["left_warped/{}".format(self.scale)] = warped
     return {"loss": loss.detach(), "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
+
+  # -- hipGraph capture of the whole step ------------------------------------------------------------
+  def capture(self, left, right, warmup=3):
+    """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~540 kernel launches)
+    into a hipGraph and replays it from then on.  Every entry point of the C ABI only enqueues work on
+    the current stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the
+    device.  Inputs are copied into static buffers before each replay.  Single-GPU only: the RCCL
+    all-reduce is kept out of the graph."""
+    if self.world != 1:
+      raise RuntimeError("OnlineAdapter.capture: graph replay is implemented for world size 1")
+    self._static_left, self._static_right = left.clone(), right.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(max(1, warmup)):
+        self._step_eager(self._static_left, self._static_right)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    self.optimizer.step_count_at_capture = self.optimizer.step_count
+    with torch.cuda.graph(graph):
+      self._static_result = self._step_eager(self._static_left, self._static_right)
+    # capture only records: the python-side counter advanced, the device-side one did not
+    self.optimizer.step_count = self.optimizer.step_count_at_capture
+    self._graph = graph
+    return self
+
+  def _replay(self, left, right):
+    self._static_left.copy_(left); self._static_right.copy_(right)
+    self._graph.replay()
+    self.optimizer.step_count += 1          # host mirror of the device-side counter
+    return self._static_result
 
   def _distributed_backward(self, total, mask, fcs_map, pairs):
     m8 = mask.to(torch.uint8)

@@ -7,3 +7,8 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
                       float* z, const as_pcl* gout, const as_conv_shape* s,
                       int epilogue, const float* ep_scale, const float* ep_shift, float slope,
                       const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
+
+// LDS-staged weight gradient of the same instance (conv32_lds.hip); dispatched from as_conv32_wgrad.
+int conv32_wgrad_lds_slabs(const as_pcl* gout);        // number of partial slabs it writes
+int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
+                            const as_conv_shape* s, float* partial, float* partial_db, void* stream);

@@ -198,3 +198,177 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
   AS_CHECK_LAUNCH("as_conv32_fwd(lds)");
   return AS_OK;
 }
+
+// =====================================================================================================
+// Weight gradient, same instance:  dW[tap][ci][co] = sum_v X[v + off(tap)][ci] * G[v][co].
+// MFMA rows i = ci, columns j = co, reduction k = voxel.  The direct-load kernel (conv32_mfma.hip) issues
+// one 256-byte wave load per operand per MFMA (1.33 per MFMA with 3 taps per wave): the CU's vector-memory
+// instruction rate, not bytes, limited it to 58 TFLOP/s, and each tap group re-fetched its rows (2.9x the
+// algorithmic HBM bytes).  Here a persistent workgroup stages the three X rows and the G row of a
+// 128-pixel segment in LDS by DMA (same swizzle as the forward kernel), every wave takes 32 of the
+// segment's voxels for ALL NINE taps (9 independent accumulators = 144 registers, so the MFMA chain
+// never waits on itself), operands are conflict-free ds_read_b32 (32 lanes = the 32 channels of one
+// voxel line), and the accumulators live in registers across all of the workgroup's tiles: one slab per
+// workgroup, summed in fixed order by wgrad_reduce_kernel (deterministic, no float atomics).
+#define TLG_BYTES (128 * 128)                           // G row segment
+#define TLW_LDS_BYTES (TL_BUF_BYTES + TLG_BYTES)        // 71,680 B; two workgroups per CU
+
+struct WgradLdsArgs {
+  const float* x;
+  const float* gz;
+  float* partial;      // [wgs][9][32][32]
+  float* partial_db;   // [wgs][32]
+  PclDev gin, gout;
+  int dil, tiles_per_row, ntiles, tiles_per_band, wg_per_xcd;
+};
+
+__device__ inline void issue_wgrad_dma(const WgradLdsArgs& p, int tile, char* xbuf, char* gbuf, int wave, int lane) {
+  const int row = tile / p.tiles_per_row;
+  const int x0 = (tile - row * p.tiles_per_row) * 128;
+  const int b = row / p.gout.H, y = row - b * p.gout.H;
+  const int vl = lane >> 3, slot = lane & 7;
+  // X: three rows of 144 voxels; G: one row of 128 voxels (16 more instructions)
+  for (int idx = wave; idx < 3 * TL_DMA_PER_ROW + 16; idx += 4) {
+    const float* src; char* dst;
+    if (idx < 3 * TL_DMA_PER_ROW) {
+      const int r = idx / TL_DMA_PER_ROW, i = idx - r * TL_DMA_PER_ROW;
+      const int v = 8 * i + vl;
+      const int chunk = slot ^ ((v >> 1) & 7);
+      const long rowvox = ((long)b * p.gin.Hp + (y + p.gin.ph + (r - 1) * p.dil)) * p.gin.Wp;
+      const int px = min(x0 - 8 + p.gin.pw + v, p.gin.Wp - 1);
+      src = p.x + (rowvox + px) * 32 + chunk * 4;
+      dst = xbuf + (r * TL_W + 8 * i) * 128;
+    } else {
+      const int i = idx - 3 * TL_DMA_PER_ROW;
+      const int v = 8 * i + vl;
+      const int chunk = slot ^ ((v >> 1) & 7);
+      const long rowvox = ((long)b * p.gout.Hp + (y + p.gout.ph)) * p.gout.Wp;
+      const int px = min(x0 + p.gout.pw + v, p.gout.Wp - 1);   // beyond W: halo voxels, which are zero
+      src = p.gz + (rowvox + px) * 32 + chunk * 4;
+      dst = gbuf + (8 * i) * 128;
+    }
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+  }
+}
+
+// one float of voxel v's 128-byte line (swizzled): channel c
+__device__ inline float lds_chan(const char* rowbase, int v, int c) {
+  const int slot = (c >> 2) ^ ((v >> 1) & 7);
+  return *reinterpret_cast<const float*>(rowbase + v * 128 + slot * 16 + (c & 3) * 4);
+}
+
+__global__ __launch_bounds__(256, 2) void conv32_wgrad_lds_kernel(WgradLdsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xbuf = smem;
+  char* gbuf = smem + TL_BUF_BYTES;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, li = lane & 31;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int t_begin = xcd * p.tiles_per_band;
+  const int t_end = min(t_begin + p.tiles_per_band, p.ntiles);
+  for (int tile = t_begin + j; tile < t_end; tile += p.wg_per_xcd) {
+    issue_wgrad_dma(p, tile, xbuf, gbuf, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // this wave's 32 voxels of the segment: 16 steps of one voxel pair (lane half h picks the voxel)
+    float bv[2], av[2][9];
+    {
+      const int v = 32 * wave + h;
+      bv[0] = lds_chan(gbuf, v, li);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) av[0][t] = lds_chan(xbuf + (t / 3) * TL_ROW_BYTES, v + 8 + (t % 3 - 1) * p.dil, li);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) {
+        const int v = 32 * wave + 2 * (s + 1) + h;
+        bv[(s + 1) & 1] = lds_chan(gbuf, v, li);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          av[(s + 1) & 1][t] = lds_chan(xbuf + (t / 3) * TL_ROW_BYTES, v + 8 + (t % 3 - 1) * p.dil, li);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bsum += bv[s & 1];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][t], bv[s & 1], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();          // all waves are done with the tile before the next DMA overwrites it
+  }
+
+  // reduce the four waves' accumulators through LDS, three taps per round (fixed order w0+w1+w2+w3)
+  float* slab = reinterpret_cast<float*>(smem);           // [3 waves][3 taps][16][64] floats = 36,864 B
+  float* out = p.partial + (long)blockIdx.x * 9 * 1024;
+#pragma unroll
+  for (int round = 0; round < 3; ++round) {
+    if (wave > 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(((wave - 1) * 3 + g) * 16 + r) * 64 + lane] = acc[round * 3 + g][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[round * 3 + g][r];
+          v += slab[((0 * 3 + g) * 16 + r) * 64 + lane];
+          v += slab[((1 * 3 + g) * 16 + r) * 64 + lane];
+          v += slab[((2 * 3 + g) * 16 + r) * 64 + lane];
+          const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+          out[(round * 3 + g) * 1024 + ci * 32 + li] = v;
+        }
+    }
+    __syncthreads();
+  }
+  float* dbs = reinterpret_cast<float*>(smem);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) dbs[wave * 32 + li] = bsum;
+  __syncthreads();
+  if (threadIdx.x < 32) p.partial_db[blockIdx.x * 32 + li] = dbs[li] + dbs[32 + li] + dbs[64 + li] + dbs[96 + li];
+}
+
+int conv32_wgrad_lds_slabs(const as_pcl* gout) {
+  // every workgroup ends with a 36 KB slab (+ its share of the final reduce): give each at least 16 tiles
+  const int nt = lds_ntiles(gout);
+  int g = ((nt + 15) / 16 + 7) / 8 * 8;
+  if (g > 512) g = 512;
+  return g;
+}
+
+int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
+                            const as_conv_shape* s, float* partial, float* partial_db, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TLW_LDS_BYTES);
+    if (e != hipSuccess) {
+      as_set_error("conv32_wgrad_lds: cannot reserve %d bytes of LDS: %s", TLW_LDS_BYTES, hipGetErrorString(e));
+      return AS_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  WgradLdsArgs a;
+  a.x = x; a.gz = gz; a.partial = partial; a.partial_db = partial_db;
+  a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
+  a.dil = s->dil;
+  a.tiles_per_row = (gout->W + 127) / 128;
+  a.ntiles = lds_ntiles(gout);
+  const int grid = conv32_wgrad_lds_slabs(gout);
+  a.tiles_per_band = (a.ntiles + 7) / 8;
+  a.wg_per_xcd = grid / 8;
+  hipLaunchKernelGGL(conv32_wgrad_lds_kernel, dim3(grid), dim3(256), TLW_LDS_BYTES, (hipStream_t)stream, a);
+  AS_CHECK_LAUNCH("as_conv32_wgrad(lds)");
+  return AS_OK;
+}

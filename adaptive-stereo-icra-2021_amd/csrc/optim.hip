@@ -113,7 +113,11 @@ extern "C" int as_sumsq(const float* g, int64_t n, float* out, float* workspace,
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n,
                                                     const float* __restrict__ grad_scale, float lr, float b1, float b2,
-                                                    float eps, float bc1, float bc2_sqrt) {
+                                                    float eps, int step_host, const float* __restrict__ step_dev) {
+  // bias corrections from the step count: a host integer, or (hipGraph replay) a device counter
+  const double step = step_dev ? (double)step_dev[0] : (double)step_host;
+  const float bc1 = (float)(1.0 - pow((double)b1, step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, step));
   const float gs = grad_scale ? grad_scale[0] : 1.f;
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -128,14 +132,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 extern "C" int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                             const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
-                            int step, void* stream) {
-  AS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "as_adam_step: bad argument");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+                            int step, const float* step_dev, void* stream) {
+  AS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && (step >= 1 || step_dev), "as_adam_step: bad argument");
   long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
-                     (long)n, grad_scale_dev, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                     (long)n, grad_scale_dev, lr, beta1, beta2, eps, step, step_dev);
   AS_CHECK_LAUNCH("as_adam_step");
   return AS_OK;
 }

@@ -211,12 +211,14 @@ int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, float* out2, f
  * One flat fp32 arena holds params / grads / exp_avg / exp_avg_sq at equal offsets.
  * as_sumsq: out[0] = sum(g[0:n]^2) (deterministic two-stage).
  * as_adam_step: g is first multiplied by *grad_scale_dev (a device scalar, e.g. the clip
- * coefficient; NULL = 1), then the torch.optim.Adam update (no weight decay / amsgrad). */
+ * coefficient; NULL = 1), then the torch.optim.Adam update (no weight decay / amsgrad).  The step
+ * count for the bias corrections is `step`, or *step_dev (a device float) when step_dev != NULL —
+ * the latter lets a captured hipGraph replay successive steps. */
 int64_t as_sumsq_workspace(int64_t n);
 int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream);
 int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
-                 int step, void* stream);
+                 int step, const float* step_dev, void* stream);
 
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------
  * When enabled, as_conv32_fwd (kernel id 0) and as_conv32_wgrad (id 1) bracket their main

@@ -203,3 +203,30 @@ def test_full_size_properties_kitti():
     assert bool(mask.all())
     l_tot = monodepth_loss(torch.ones(B, 1, H, W, device=DEV), ld, ld, 1e-3)
     assert float(l_tot[1].abs().max()) == 0.0 and float(l_tot[2].abs().max()) < 1e-6   # identical images: L1 = SSIM dist = 0
+
+
+def test_graph_replay_equals_eager_steps():
+  """A captured hipGraph of the adaptation step must reproduce eager stepping bit for bit
+  (same kernels, same order; the Adam step count lives on the device)."""
+  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
+  H, W, B = 96, 256, 2
+  results = []
+  for use_graph in (False, True):
+    fnet, snet = build(meta)
+    adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+    batches = [syn.stereo_pair(B, H, W, seed=s) for s in (1, 2, 3, 4)]
+    batches = [(l.to(DEV), r.to(DEV)) for l, r in batches]
+    adapter.step(*batches[0])                       # step 1 (eager in both runs)
+    if use_graph:
+      adapter.capture(*batches[0], warmup=1)        # warm-up inside capture() advances the state by one step
+    else:
+      adapter.step(*batches[0])
+    losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
+    torch.cuda.synchronize()
+    results.append((losses, adapter.arena.params.clone(), adapter.optimizer.exp_avg_sq.clone(),
+                    int(snet.filter[0][0].bn.num_batches_tracked), adapter.optimizer.step_count,
+                    float(adapter.optimizer.step_dev)))
+  (l0, p0, v0, nb0, sc0, sd0), (l1, p1, v1, nb1, sc1, sd1) = results
+  assert l0 == l1, (l0, l1)
+  assert torch.equal(p0, p1) and torch.equal(v0, v1)
+  assert nb0 == nb1 == 5 and sc0 == sc1 == 5 and sd0 == sd1 == 5.0

@@ -334,7 +334,7 @@ def test_sumsq_and_adam_step():
   for step in (1, 2, 3):
     orc.adam_step(pr, g * 0.37, state, 5e-5)
     nat.call("as_adam_step", nat.ptr(pd), nat.ptr(gd), nat.ptr(m), nat.ptr(v), n, nat.ptr(coef), 5e-5, 0.9, 0.999,
-             1e-8, step, nat.stream())
+             1e-8, step, None, nat.stream())
   close(pd, pr, 1e-7, 1e-6, "adam params")
   close(m, state["exp_avg"], 1e-9, 1e-5, "adam m"); close(v, state["exp_avg_sq"], 1e-12, 1e-5, "adam v")
 
