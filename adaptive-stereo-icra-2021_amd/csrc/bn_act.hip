@@ -20,11 +20,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   __shared__ double red[32][33];
   __shared__ double smean[32], scount;
   const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  // branch-free and unrolled: the loads of 8 iterations are independent and in flight together
+  // (empty partials carry count 0, mean 0, M2 0)
   double s = 0.0, cn = 0.0;
+#pragma unroll 8
   for (int i = sl; i < nparts; i += 32) {
     const double nb = (double)stat_cnt[i];
     cn += nb;
-    if (nb > 0.0) s += nb * (double)stat_mean[i * 32 + c];
+    s += nb * (double)stat_mean[i * 32 + c];
   }
   red[sl][c] = s;
   __syncthreads();
@@ -45,12 +48,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   const double count = scount;
   const double mean = smean[c] / count;
   double q = 0.0;
+#pragma unroll 8
   for (int i = sl; i < nparts; i += 32) {
     const double nb = (double)stat_cnt[i];
-    if (nb > 0.0) {
-      const double dm = (double)stat_mean[i * 32 + c] - mean;
-      q += (double)stat_m2[i * 32 + c] + nb * dm * dm;
-    }
+    const double dm = (double)stat_mean[i * 32 + c] - mean;
+    q += (double)stat_m2[i * 32 + c] + nb * dm * dm;
   }
   __syncthreads();
   red[sl][c] = q;
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   __shared__ double red[4][64];
   const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
   double s = 0.0;
+#pragma unroll 8
   for (int i = sl; i < nblocks; i += 4) s += partial[(long)i * 64 + j];
   red[sl][j] = s;
   __syncthreads();

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
   TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
   const float bias_v = p.ep.bias ? p.ep.bias[li] : 0.f;
 
-  for (int tile = t_begin + j; tile < t_end; tile += p.wg_per_xcd) {
-    issue_tile_dma(p, tile, tile_buf, wave, lane);
+  int tile = t_begin + j;
+  if (tile < t_end) issue_tile_dma(p, tile, tile_buf, wave, lane);
+  for (int it = 0; tile < t_end; tile += p.wg_per_xcd, ++it) {
     int b, y, x0;
     tile_coords(p, tile, b, y, x0);
     const int x = x0 + 32 * wave + li;
@@ -120,11 +121,14 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias_v;
     f32x4 a[2][4], w[2][4];
-    glb_load_w(w[0], wb);
-    // this wave's share of the tile has landed; the barrier extends that to the whole workgroup
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Wait for this wave's share of the tile's DMA — but not for the previous tile's 16 output stores,
+    // which were issued AFTER that DMA: vmcnt counts stores too, and waiting for their HBM
+    // acknowledgement would expose a 1-2 us drain on every tile.  (vmcnt is in-order: "at most 16
+    // outstanding" means everything older than the 16 youngest operations has completed.)
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();
-
+    glb_load_w(w[0], wb);
     lds_load_a(a[0], tile_buf, 0, vbase - p.dil, h);
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
@@ -137,10 +141,15 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
       mfma16l(acc, a[tp & 1], w[tp & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // every wave has read its operands: the tile buffer is free.  Start the next tile's DMA BEFORE the
+    // epilogue's stores, so that it is older than they are in the vmcnt queue.
+    __syncthreads();
+    const int next_tile = tile + p.wg_per_xcd;
+    if (next_tile < t_end) issue_tile_dma(p, next_tile, tile_buf, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
     TileStats ts; ts.n = 0.f; ts.mean = 0.f; ts.m2 = 0.f;
-    conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.gout.W - x0), red, bmean, &ts);
+    conv_epilogue<true>(acc, p.ep, out_vox, valid, min(128, p.gout.W - x0), red, bmean, &ts);
     if (p.ep.stat_mean != nullptr && threadIdx.x < 32) stats_merge(run, ts);
-    __syncthreads();        // every wave is done with the tile (and with red/bmean) before the next DMA
   }
   stats_write(p.ep, blockIdx.x, run);
 }

@@ -247,20 +247,39 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
 }
 
 // dW[o][i][t] = sum_chunks partial[chunk][t][i][o];  db[o] = sum_chunks partial_db[chunk][o].
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
-                                    int nchunks, int T, float* __restrict__ dW, float* __restrict__ db) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// 1024 threads = 64 consecutive outputs x 16 slab slices: each thread sums every 16th slab (coalesced
+// 256-byte wave loads, 8 independent loads in flight), then the slices are added in fixed order through
+// LDS.  A single thread per output walking all slabs was a ~500-deep chain of dependent-latency loads.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                             const float* __restrict__ partial_db, int nchunks, int T,
+                                                             float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[16][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int total = T * 1024;
-  if (idx < total) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(long)c * total + idx];
-    const int o = idx & 31, i = (idx >> 5) & 31, t = idx >> 10;
-    dW[((long)o * 32 + i) * T + t] = s;
-  } else if (db != nullptr && idx < total + 32) {
-    const int o = idx - total;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial_db[c * 32 + o];
-    db[o] = s;
+  const int idx = blockIdx.x * 64 + o;
+  const bool is_w = idx < total, is_b = !is_w && db != nullptr && idx < total + 32;
+  float s = 0.f;
+  if (is_w) {
+    const float* src = partial + idx;
+#pragma unroll 8
+    for (int c = sl; c < nchunks; c += 16) s += src[(long)c * total];
+  } else if (is_b) {
+    const float* src = partial_db + (idx - total);
+#pragma unroll 8
+    for (int c = sl; c < nchunks; c += 16) s += src[c * 32];
+  }
+  red[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && (is_w || is_b)) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    if (is_w) {
+      const int oc = idx & 31, i = (idx >> 5) & 31, tp = idx >> 10;
+      dW[((long)oc * 32 + i) * T + tp] = t;
+    } else {
+      db[idx - total] = t;
+    }
   }
 }
 
@@ -475,7 +494,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
     as_prof_mark(1, st, 1, 0.0);
     if (int e = conv32_wgrad_lds_launch(x, gin, gz, gout, s, workspace, partial_db, stream)) return e;
     as_prof_mark(1, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
                        workspace, partial_db, slabs, T, dW, db);
     AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
     return AS_OK;
@@ -492,7 +511,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
   else launch_wgrad<1>(a, T, nchunks, st);
   as_prof_mark(1, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
   AS_CHECK_LAUNCH("as_conv32_wgrad");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
                      a.partial, a.partial_db, nchunks, T, dW, db);
   AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
   return AS_OK;

@@ -5,6 +5,9 @@
 #pragma once
 #include "as_common.h"
 
+// 64 floats that swallow the stores of invalid rows when a kernel needs an exact store count per wave
+static __device__ float as_store_dump[64];     // one copy per translation unit (no relocatable device code)
+
 struct EpilogueArgs {
   const float* bias;        // [32] or null — folded into the accumulator before the K loop
   float* z;                 // PCL output
@@ -38,6 +41,9 @@ __device__ inline void stats_merge(TileStats& run, const TileStats& t) {
 
 // red: [4][32] floats, bmean: [32] floats of LDS.  All 256 threads of the workgroup must call.
 // nvalid = number of valid voxels in this workgroup's tile.  ts (may be null) receives the tile's moments.
+// UNIFORM_STORES: every wave issues exactly 16 store instructions (invalid rows go to as_store_dump), so a
+// caller can leave them in flight behind a counted "s_waitcnt vmcnt(16)".
+template <bool UNIFORM_STORES = false>
 __device__ inline void conv_epilogue(const f32x16& acc, const EpilogueArgs& e, int out_vox, bool valid, int nvalid,
                                      float (*red)[32], float* bmean, TileStats* ts) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,7 +73,12 @@ __device__ inline void conv_epilogue(const f32x16& acc, const EpilogueArgs& e, i
     for (int r = 0; r < 16; ++r) {
       float yv = acc[r] * sc + sh;
       yv = yv > 0.f ? yv : yv * e.slope;
-      if (rv[r]) e.z[(long)ov[r] * 32 + li] = yv + res[r];
+      if (UNIFORM_STORES) {
+        float* dst = rv[r] ? e.z + (long)ov[r] * 32 + li : as_store_dump + lane;
+        *dst = yv + res[r];
+      } else if (rv[r]) {
+        e.z[(long)ov[r] * 32 + li] = yv + res[r];
+      }
     }
     return;
   }
@@ -75,7 +86,11 @@ __device__ inline void conv_epilogue(const f32x16& acc, const EpilogueArgs& e, i
   float s1 = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    if (rv[r]) {
+    if (UNIFORM_STORES) {
+      float* dst = rv[r] ? e.z + (long)ov[r] * 32 + li : as_store_dump + lane;
+      *dst = acc[r] + res[r];
+      s1 += rv[r] ? acc[r] : 0.f;
+    } else if (rv[r]) {
       e.z[(long)ov[r] * 32 + li] = acc[r] + res[r];
       s1 += acc[r];
     }
