@@ -201,9 +201,9 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
   a.tiles_per_band = (a.ntiles + 7) / 8;
   a.wg_per_xcd = grid / 8;
   hipStream_t st = (hipStream_t)stream;
-  as_prof_mark(0, st, 1, 0.0);
+  as_prof_mark(2, st, 1, 0.0);
   hipLaunchKernelGGL(conv32_lds_kernel, dim3(grid), dim3(256), TL_LDS_BYTES, st, a);
-  as_prof_mark(0, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
+  as_prof_mark(2, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
   AS_CHECK_LAUNCH("as_conv32_fwd(lds)");
   return AS_OK;
 }

@@ -164,7 +164,7 @@ def main():
   if not use_graph:
     t_adapt = min(t_adapt, t_adapt_eager)
   prof = []
-  for kid in (0, 1):
+  for kid in (0, 1, 2, 3):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     nat.call("as_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
     prof.append((n.value, ms.value, fl.value))
@@ -184,24 +184,31 @@ def main():
     return
 
   pairs = world * B * args.steps
-  # dominant hand-written kernel: the fp32-MFMA implicit-GEMM convolution (forward + data-gradient
-  # launches of the 3-D aggregation).  achieved = algorithmic FLOPs (2*voxels*32*32*27 per launch)
-  # / mean launch duration from HIP events recorded on the launch stream during the timed steps.
-  n0, ms0, fl0 = prof[0]
-  n1, ms1, fl1 = prof[1]
+  # Dominant kernel: conv32_lds_kernel, the LDS-staged fp32-MFMA 3x3 convolution of the full-resolution
+  # refinement layers (forward and data gradient).  achieved = algorithmic FLOPs per launch
+  # (2 * voxels * 32 * 32 * 9) / mean launch duration from HIP events recorded on the launch stream.
+  def entry(i, name):
+    n, ms, fl = prof[i]
+    if n == 0 or ms <= 0:
+      return None
+    return {"kernel": name, "achieved": round(fl / (ms * 1e-3) / 1e12, 3), "launches": n,
+            "avg_launch_us": round(1e3 * ms / n, 2), "flops_per_launch": fl / n}
+  dom = entry(2, "conv32_lds_kernel")
   roofline = None
-  if n0 > 0 and ms0 > 0:
-    achieved = fl0 / (ms0 * 1e-3) / 1e12
+  if dom is not None:
     traffic = None
-    pmc = os.path.join(REPO, "profiles", "pmc_conv32_fwd.json")
+    pmc = os.path.join(REPO, "profiles", "pmc_conv32_lds.json")
     if os.path.exists(pmc):
-      traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "conv32 forward/data-gradient family (conv32_lds_kernel, conv32_fwd_kernel<taps>)", "achieved": round(achieved, 3),
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "launches": n0, "avg_launch_us": round(1e3 * ms0 / n0, 2),
-                "flops_per_launch": fl0 / n0,
-                "wgrad_kernel": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 3) if ms1 > 0 else None,
-                                 "launches": n1, "avg_launch_us": round(1e3 * ms1 / max(n1, 1), 2)}}
+      rec = json.load(open(pmc))
+      if rec.get("pairs_per_launch") == B:
+        traffic = rec.get("hbm_bytes_per_launch")
+    roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
+                "flops_per_launch": dom["flops_per_launch"],
+                "other_mfma_kernels": [e for e in (entry(3, "conv32_wgrad_lds_kernel"),
+                                                   entry(0, "conv32_fwd_kernel<taps> (3-D, strided, small 2-D)"),
+                                                   entry(1, "conv32_wgrad_kernel<taps>")) if e is not None]}
 
   out = {
     "metric": "stereo pairs/sec (fwd+adapt-step), KITTI 1242x375 D=192",

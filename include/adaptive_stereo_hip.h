@@ -221,9 +221,11 @@ int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  int step, const float* step_dev, void* stream);
 
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------
- * When enabled, as_conv32_fwd (kernel id 0) and as_conv32_wgrad (id 1) bracket their main
- * kernel with HIP events on the launch stream and account its algorithmic FLOPs
- * (2 * voxels * 32 * 32 * taps).  as_prof_read synchronises on the recorded events.
+ * When enabled, as_conv32_fwd and as_conv32_wgrad bracket their main kernel with HIP events on the
+ * launch stream and account its algorithmic FLOPs (2 * voxels * 32 * 32 * taps).  Kernel ids:
+ * 0 conv32_fwd_kernel<taps> (direct-load forward/dgrad), 1 conv32_wgrad_kernel<..> (direct-load wgrad),
+ * 2 conv32_lds_kernel (LDS-staged 3x3 forward/dgrad), 3 conv32_wgrad_lds_kernel.
+ * as_prof_read synchronises on the recorded events.
  * Disabled by default; must stay disabled under hipGraph capture. */
 int as_prof_enable(int on);
 int as_prof_reset(void);
