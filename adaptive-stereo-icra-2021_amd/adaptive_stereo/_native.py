@@ -88,6 +88,8 @@ _SIGNATURES = {
                                     c_vp, c_vp, c_vp]),
   "as_masked_sum_workspace": (c_i64, [c_i64]),
   "as_masked_sum": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+  "as_eval_metrics_workspace": (c_i64, [c_i64]),
+  "as_eval_metrics": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_sumsq_workspace": (c_i64, [c_i64]),
   "as_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_float, c_float, c_float, c_float, c_int, c_vp,

@@ -101,6 +101,25 @@ class FusedClipAdam(object):
     """Pre-clip L2 norm of the clipped group at the last step (device scalar)."""
     return torch.sqrt(self.sumsq)
 
+  def state_dict(self):
+    """torch.optim.Adam-compatible layout (what the reference writes to adam.pth, train.py:136-137): one
+    entry per parameter that has received a gradient, param groups in arena order."""
+    state, groups, index = {}, [], 0
+    for gi, (s, e) in enumerate(self.arena.group_bounds):
+      ids = []
+      for mi, name, p, off, n in self.arena.entries:
+        if mi != gi:
+          continue
+        ids.append(index)
+        if self.step_count > 0 and float(self.exp_avg_sq[off:off + n].abs().sum()) > 0:
+          state[index] = {"step": torch.tensor(float(self.step_count)),
+                          "exp_avg": self.exp_avg[off:off + n].view(p.shape).detach().cpu().clone(),
+                          "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).detach().cpu().clone()}
+        index += 1
+      groups.append({"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                     "params": ids})
+    return {"state": state, "param_groups": groups}
+
 
 class OnlineAdapter(object):
   """feature_net + stereo_net + warper + optimiser bound together for the per-step sequence."""
@@ -165,6 +184,65 @@ class OnlineAdapter(object):
       self.fcs_smoothed.mul_(self.fcs_ema_weight).add_(fcs.detach(), alpha=1.0 - self.fcs_ema_weight)
     out["left_warped/{}".format(self.scale)] = warped
     return {"loss": loss.detach(), "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
+
+  # -- split step for the control plane (control.AdaptationLoop): the OOD gate sits between forward and backward
+  def forward_loss(self, left, right, train=True, replay=None, er_loss_weight=0.05):
+    """Forward + losses (+ FCS EMA).  With train=False the networks run in eval mode without gradients
+    (State.DONE, adapt.py:309-311).  ``replay`` = (left, right, gt) adds the experience-replay Khamis
+    term (adapt.py:339-349)."""
+    from .utils.loss_functions import khamis_robust_loss
+    self.feature_net.train(train); self.stereo_net.train(train)
+    if train:
+      self.arena.rebind_grads()
+      self.arena.zero_grads()
+    with torch.set_grad_enabled(train):
+      fl, fr = self.feature_net(left), self.feature_net(right)
+      out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+      pred = out["pred_disp_l/{}".format(self.scale)]
+      warped, mask = self.warper(right, pred, right_to_left=True)
+      total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+      loss = masked_mean(total, mask)
+      backprop = loss
+      replay_loss = None
+      if replay is not None:
+        rl, rr, rgt = replay
+        rfl, rfr = self.feature_net(rl), self.feature_net(rr)
+        rout = self.stereo_net(rl, rfl, rfr, "l", output_cost_volume=True)
+        replay_loss = khamis_robust_loss(rout["pred_disp_l/{}".format(self.scale)], rgt)
+        backprop = loss + er_loss_weight * replay_loss
+    fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)]).mean()
+    if self.world > 1:
+      # the OOD gate and the state machine must take the same decision on every rank: gate on the mean
+      fcs = fcs.clone()
+      dist.all_reduce(fcs, op=dist.ReduceOp.SUM, group=self.pg)
+      fcs /= self.world
+    if self.fcs_smoothed is None:
+      self.fcs_smoothed = fcs.detach().clone()
+    else:
+      self.fcs_smoothed.mul_(self.fcs_ema_weight).add_(fcs.detach(), alpha=1.0 - self.fcs_ema_weight)
+    out["left_warped/{}".format(self.scale)] = warped
+    return {"loss": loss.detach(), "replay_loss": None if replay_loss is None else replay_loss.detach(),
+            "backprop_loss": backprop, "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
+
+  def backward_update(self, result):
+    """backward + clip + Adam for a result of forward_loss(train=True) (adapt.py:381-394)."""
+    result["backprop_loss"].backward()
+    if self.world > 1:
+      allreduce_gradients(self.arena.grads.div_(self.world), self.pg)
+    self.optimizer.step(clip=self.clip)
+
+  @torch.no_grad()
+  def validation_loss(self, left, right):
+    """monodepth_single_loss in eval mode, as StateMachine.validate uses it (adapt.py:121-142)."""
+    was_f, was_s = self.feature_net.training, self.stereo_net.training
+    self.feature_net.eval(); self.stereo_net.eval()
+    fl, fr = self.feature_net(left), self.feature_net(right)
+    out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+    pred = out["pred_disp_l/{}".format(self.scale)]
+    warped, mask = self.warper(right, pred, right_to_left=True)
+    loss = masked_mean(monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0], mask)
+    self.feature_net.train(was_f); self.stereo_net.train(was_s)
+    return float(loss)
 
   # -- hipGraph capture of the whole step ------------------------------------------------------------
   def capture(self, left, right, warmup=3):

@@ -318,6 +318,58 @@ extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, co
   return AS_OK;
 }
 
+// ---- evaluation reductions: EPE and D1-all at 2/3/4/5 px (reference train.py:98-106) ------------------------------
+// out6 = [sum |pred-gt| over gt>0, count(gt>0), count(gt>0 & err>2), ... >3, >4, >5]
+__global__ __launch_bounds__(256) void eval_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                            long n, double* __restrict__ partial) {
+  __shared__ double red[6][4];
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = gt[i];
+    if (g > 0.f) {
+      const float e = fabsf(pred[i] - g);
+      s[0] += (double)e; s[1] += 1.0;
+      s[2] += e > 2.f ? 1.0 : 0.0; s[3] += e > 3.f ? 1.0 : 0.0;
+      s[4] += e > 4.f ? 1.0 : 0.0; s[5] += e > 5.f ? 1.0 : 0.0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    s[k] = wave_sum_d(s[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) partial[6 * blockIdx.x + threadIdx.x] =
+      red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+__global__ void eval_metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out6) {
+  const int k = threadIdx.x >> 6 ? -1 : 0;     // one wave
+  (void)k;
+  for (int m = 0; m < 6; ++m) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += partial[6 * i + m];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out6[m] = (float)s;
+  }
+}
+
+#define EM_BLOCKS 256
+extern "C" int64_t as_eval_metrics_workspace(int64_t n) { return n > 0 ? 12 * EM_BLOCKS : -1; }
+
+extern "C" int as_eval_metrics(const float* pred, const float* gt, int64_t n, float* out6, float* workspace, void* stream) {
+  AS_CHECK_ARG(pred && gt && out6 && workspace && n > 0, "as_eval_metrics: bad argument");
+  AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_eval_metrics: workspace must be 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  long nb = (n + 255) / 256;
+  if (nb > EM_BLOCKS) nb = EM_BLOCKS;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(eval_metrics_kernel, dim3((int)nb), dim3(256), 0, st, pred, gt, (long)n, partial);
+  AS_CHECK_LAUNCH("as_eval_metrics");
+  hipLaunchKernelGGL(eval_metrics_finalize_kernel, dim3(1), dim3(64), 0, st, partial, (int)nb, out6);
+  AS_CHECK_LAUNCH("as_eval_metrics(finalize)");
+  return AS_OK;
+}
+
 #define MS_BLOCKS 512
 extern "C" int64_t as_masked_sum_workspace(int64_t n) { return n > 0 ? 4 * MS_BLOCKS : -1; }
 

@@ -207,6 +207,12 @@ int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* 
 int64_t as_masked_sum_workspace(int64_t n);
 int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream);
 
+/* ---- evaluation reductions — train.py:98-106 ------------------------------------
+ * out6 = [sum |pred-gt| over gt>0, count(gt>0), count(gt>0 & |err|>2), >3, >4, >5]; EPE = out6[0]/out6[1],
+ * D1_all_tpx = out6[t]/out6[1].  pred, gt: any shape with n elements.  workspace: as_eval_metrics_workspace(n). */
+int64_t as_eval_metrics_workspace(int64_t n);
+int as_eval_metrics(const float* pred, const float* gt, int64_t n, float* out6, float* workspace, void* stream);
+
 /* ---- a12: clip_grad_norm_ + Adam, multi-tensor — adapt.py:208-210,391-393 ------
  * One flat fp32 arena holds params / grads / exp_avg / exp_avg_sq at equal offsets.
  * as_sumsq: out[0] = sum(g[0:n]^2) (deterministic two-stage).
