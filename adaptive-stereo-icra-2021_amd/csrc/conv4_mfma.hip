@@ -106,23 +106,35 @@ __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
     koff[nb] = p.tap_off[t] * 4 + (k & 3);
   }
   float bsum = 0.f;
+  // loads of 8 steps are issued as a group before their MFMAs (see conv32_wgrad_kernel)
+  constexpr int U = 8;
   const int nsteps = (W + 1) >> 1;
   for (int row = r0 + wave; row < r1; row += 4) {
     const int y = row % H, b = row / H;
     const float* xr = p.x4 + p.gin.vox(b, 0, y * p.stride, 0) * 4;
     const float* gr = p.gz + p.gout.vox(b, 0, y, 0) * 32 + li;
-    for (int s = 0; s < nsteps; ++s) {
-      const int xc = 2 * s + h;
-      const bool ok = xc < W;
-      const int xcl = ok ? xc : W - 1;
-      float bv = gr[xcl * 32];
-      bv = ok ? bv : 0.f;
-      bsum += bv;
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+      float bv[U], av[U][NB];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        float av = xr[xcl * p.stride * 4 + koff[nb]];
-        av = kok[nb] ? av : 0.f;
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+      for (int u = 0; u < U; ++u) {
+        const int xc = 2 * (s0 + u) + h;
+        const bool ok = xc < W;
+        const int xcl = ok ? xc : W - 1;
+        const float g0 = gr[xcl * 32];
+        bv[u] = ok ? g0 : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float a0 = xr[xcl * p.stride * 4 + koff[nb]];
+          av[u][nb] = kok[nb] ? a0 : 0.f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bsum += bv[u];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][nb], bv[u], acc[nb], 0, 0, 0);
       }
     }
   }

@@ -113,11 +113,15 @@ __global__ __launch_bounds__(256) void conv32to1_dgrad_kernel(OutConvBwdArgs p) 
   }
 }
 
-// g_w[c][t] = sum_v g_out[v] * a[v + off(t)][c];  g_bias = sum_v g_out[v].
+// g_w[c][t] = sum_v g_out[v] * a[v + off(t)][c]  =  sum_u a[u][c] * g_out[u - off(t)];  g_bias = sum_v g_out[v].
+// Input-centric form: every activation voxel u (a 128-byte line, 8 lanes x float4) is read ONCE and multiplied
+// by the NT gradient values that reach it; g_out is a 1-channel map (7 MB at 4 pairs) that stays in L2.  The
+// output-centric form re-read the 238 MB activation for every tap.
 template <int NT>
 __global__ __launch_bounds__(256) void conv32to1_wgrad_kernel(OutConvBwdArgs p) {
   __shared__ float red[32][33];
   const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
+  const int D = p.g.D, H = p.g.H, W = p.g.W;
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -125,16 +129,27 @@ __global__ __launch_bounds__(256) void conv32to1_wgrad_kernel(OutConvBwdArgs p) 
   const long stride = (long)gridDim.x * 32;
   for (long v = (long)blockIdx.x * 32 + vl; v < p.M; v += stride) {
     long t = v;
-    const int x = t % p.g.W; t /= p.g.W;
-    const int y = t % p.g.H; t /= p.g.H;
-    const int d = t % p.g.D;
-    const int b = t / p.g.D;
-    const float gl = p.g_out[v];
-    gsum += gl;
-    const float* base = p.a + p.g.vox(b, d, y, x) * 32 + c4 * 4;
+    const int x = t % W; t /= W;
+    const int y = t % H; t /= H;
+    const int d = t % D;
+    const int b = t / D;
+    gsum += p.g_out[v];
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.a + p.g.vox(b, d, y, x) * 32 + c4 * 4);
+    const float* gb = p.g_out + (long)b * D * H * W;
+    int tp = 0;
 #pragma unroll
-    for (int tp = 0; tp < NT; ++tp)
-      acc[tp] += gl * *reinterpret_cast<const f32x4*>(base + (long)p.k.tap_off[tp] * 32);
+    for (int kd = 0; kd < (NT == 27 ? 3 : 1); ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw, ++tp) {
+          // output voxel w = u - offset(tap)
+          const int wd = d - ((NT == 27 ? kd * p.k.dil : 0) - p.k.pad_d);
+          const int wy = y - (kh * p.k.dil - p.k.pad_h), wx = x - (kw * p.k.dil - p.k.pad_w);
+          const bool ok = wd >= 0 && wd < D && wy >= 0 && wy < H && wx >= 0 && wx < W;
+          const float gl = ok ? gb[((long)wd * H + wy) * W + wx] : 0.f;
+          acc[tp] += gl * a4;
+        }
   }
   float* out = p.partial + (long)blockIdx.x * (NT * 32 + 1);
 #pragma unroll
