@@ -54,27 +54,27 @@ _SIGNATURES = {
   "as_conv32_dgrad_s2_workspace": (c_i64, []),
   "as_conv32_dgrad_s2": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), c_vp, c_vp]),
   "as_conv32_wgrad_workspace": (c_i64, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
-  "as_conv32_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp]),
+  "as_conv32_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_bn_finalize": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp,
                              c_vp, c_vp]),
   "as_bn_eval_affine": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_bn_act_fwd": (c_int, [c_vp, c_vp, c_vp, c_float, c_vp, c_vp, _P(Pcl), c_vp]),
   "as_bn_bwd_workspace": (c_i64, [_P(Pcl)]),
-  "as_bn_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_vp,
+  "as_bn_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_int, c_vp,
                             _P(Pcl), c_vp]),
   "as_conv3d_out_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp]),
   "as_conv3d_out_bwd_workspace": (c_i64, [_P(Pcl)]),
-  "as_conv3d_out_bwd": (c_int, [c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  "as_conv3d_out_bwd": (c_int, [c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_conv32to1_fwd": (c_int, [c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_conv32to1_bwd_workspace": (c_i64, [_P(Pcl), _P(ConvShape)]),
-  "as_conv32to1_bwd": (c_int, [c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  "as_conv32to1_bwd": (c_int, [c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_pcl4_numel": (c_i64, [_P(Pcl)]),
   "as_pack_in4": (c_int, [c_vp, c_vp, c_int, c_vp, _P(Pcl), c_vp]),
   "as_conv4_pack_weights": (c_int, [c_vp, c_int, c_vp, _P(ConvShape), c_vp]),
   "as_conv4_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_float,
                            c_vp, c_vp, c_vp, c_vp]),
   "as_conv4_wgrad_workspace": (c_i64, [_P(Pcl), _P(ConvShape)]),
-  "as_conv4_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_vp, c_vp]),
+  "as_conv4_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_softargmax_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
   "as_softargmax_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
   "as_upsample_bilinear_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),

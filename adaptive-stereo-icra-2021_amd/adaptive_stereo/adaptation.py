@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native as nat
+from . import hip_ops
 from .hip_ops import masked_mean, MaskedMeanFn
 from .models.linear_warping import LinearWarping
 from .utils.loss_functions import monodepth_loss
@@ -56,6 +57,7 @@ class FlatArena(object):
         self.params[off:off + n].copy_(p.detach().reshape(-1))
         p.data = self.params[off:off + n].view(p.shape)
         p.grad = self.grads[off:off + n].view(p.shape)
+        p._as_grad_sink = True     # hip_ops.grad_sinks: backward kernels accumulate straight into the arena
 
   def rebind_grads(self):
     """Makes sure every ``p.grad`` is still the arena view (user code may have set it to None)."""

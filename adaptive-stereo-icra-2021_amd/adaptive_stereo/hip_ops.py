@@ -15,6 +15,36 @@ BN_MOMENTUM = 0.1
 
 CONV3D_333 = ConvShape(3, 3, 3, 1, 1, 1, 1, 1)
 
+# Direct gradient accumulation: for parameters that adaptation.FlatArena has re-homed (it tags them with
+# ``_as_grad_sink``; their .grad tensors are views of one flat buffer that is zeroed at the start of a step)
+# the backward kernels ADD parameter gradients straight into p.grad and the Functions return None for them —
+# autograd then issues no "grad += dW" kernel per tensor (~120 launches per step).  Parameters without the tag
+# (plain torch.optim / torch.autograd.grad use) keep ordinary autograd semantics.  The switch below turns the
+# mechanism off globally (parity tests compare both routes).
+_DIRECT_GRADS = True
+
+
+def set_direct_grad_accumulation(flag: bool):
+  global _DIRECT_GRADS
+  _DIRECT_GRADS = bool(flag)
+
+
+def grad_sinks(params):
+  """Per-parameter accumulation targets (or None where a parameter has no usable .grad)."""
+  if not (_DIRECT_GRADS and torch.is_grad_enabled()):
+    return None
+  out = []
+  for p in params:
+    g = getattr(p, "grad", None)
+    ok = (g is not None and getattr(p, "_as_grad_sink", False) and p.requires_grad and
+          g.dtype == torch.float32 and g.is_contiguous() and g.device == p.device and g.shape == p.shape)
+    out.append(g if ok else None)
+  return out
+
+
+def _sink(sinks, i):
+  return sinks[i] if sinks is not None else None
+
 
 # ----------------------------------------------------------------------------------------
 # PCL helpers (allocation + layout conversion; conversion is host plumbing used at the
@@ -110,17 +140,21 @@ def conv32_stat_parts(gin: Pcl, gout: Pcl, shape: ConvShape, device):
   return StatParts(nat.load().as_conv32_stat_parts(gin, gout, shape), device)
 
 
-def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True):
+def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, sink_w=None, sink_b=None):
+  """Returns (dW, db); an entry is None when it was accumulated into its sink instead."""
   lib = nat.load()
   dev = x.device
   ws = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
   taps = shape.taps()
+  if sink_w is not None and (sink_b is not None or not want_bias):
+    call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(sink_w), ptr(sink_b), 1, ptr(ws), stream())
+    return None, None
   if shape.kd > 1:
     dW = _empty(32 * 32 * taps, dev).view(32, 32, shape.kd, shape.kh, shape.kw)
   else:
     dW = _empty(32 * 32 * taps, dev).view(32, 32, shape.kh, shape.kw)
   db = _empty(32, dev) if want_bias else None
-  call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(dW), ptr(db), ptr(ws), stream())
+  call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(dW), ptr(db), 0, ptr(ws), stream())
   return dW, db
 
 
@@ -154,14 +188,18 @@ def bn_act(z, st: BnState, g: Pcl, residual=None, out=None):
   return a
 
 
-def bn_act_bwd(g_a, z, st: BnState, gamma, g: Pcl, train: bool):
+def bn_act_bwd(g_a, z, st: BnState, gamma, g: Pcl, train: bool, sink_gamma=None, sink_beta=None):
   lib = nat.load()
   dev = z.device
   g_z = POOL.get(g, dev)
-  g_gamma, g_beta = _empty(32, dev), _empty(32, dev)
   ws = _empty(lib.as_bn_bwd_workspace(g), dev)
+  if sink_gamma is not None and sink_beta is not None:
+    call("as_bn_act_bwd", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+         LEAKY_SLOPE, int(train), ptr(g_z), ptr(sink_gamma), ptr(sink_beta), 1, ptr(ws), g, stream())
+    return g_z, None, None
+  g_gamma, g_beta = _empty(32, dev), _empty(32, dev)
   call("as_bn_act_bwd", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-       LEAKY_SLOPE, int(train), ptr(g_z), ptr(g_gamma), ptr(g_beta), ptr(ws), g, stream())
+       LEAKY_SLOPE, int(train), ptr(g_z), ptr(g_gamma), ptr(g_beta), 0, ptr(ws), g, stream())
   return g_z, g_gamma, g_beta
 
 
@@ -197,11 +235,13 @@ def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train,
   return z, a, st
 
 
-def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx):
+def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx, sinks=None):
   """g_out: gradient w.r.t. the block output (PCL).  Returns (g_x or None, dW, db, g_gamma, g_beta).
-  With a skip connection g_x = g_out + dgrad(...) — the add is fused into the dgrad epilogue."""
-  g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train)
-  dW, db = conv32_wgrad(x, g, g_z, g, shape)
+  With a skip connection g_x = g_out + dgrad(...) — the add is fused into the dgrad epilogue.
+  ``sinks`` = (w, b, gamma, beta) accumulation targets; sunk gradients come back as None."""
+  sw, sb, sg, sbeta = sinks if sinks is not None else (None, None, None, None)
+  g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta)
+  dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
   g_x = None
   if need_dx:
     wp_t = pack_weights(w, shape, True)
@@ -219,7 +259,7 @@ class CostAggregationFn(torch.autograd.Function):
      outputs: logits [B,D,H,W], pred [B,H,W], argmax int32 [B,H,W], fcs [B,H,W]"""
 
   @staticmethod
-  def forward(ctx, fl, fr, num_disp, train, bn_buffers, *params):
+  def forward(ctx, fl, fr, num_disp, train, bn_buffers, sinks, *params):
     assert len(params) == 18
     fl, fr = f32c(fl), f32c(fr)
     params = [f32c(p) for p in params]
@@ -251,6 +291,7 @@ class CostAggregationFn(torch.autograd.Function):
     if need_bwd:
       ctx.g = g
       ctx.train = bool(train)
+      ctx.sinks = sinks
       ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
       ctx.save_for_backward(logits, *params)
     else:
@@ -274,19 +315,25 @@ class CostAggregationFn(torch.autograd.Function):
 
     grads = [None] * 18
     w_out = params[16]
+    sinks = ctx.sinks
     g_a = POOL.get(g, dev)
-    g_wout = torch.empty_like(w_out)
-    g_bout = _empty(1, dev)
     ws = _empty(lib.as_conv3d_out_bwd_workspace(g), dev)
-    call("as_conv3d_out_bwd", ptr(g_logits), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout),
-         ptr(ws), stream())
-    grads[16], grads[17] = g_wout, g_bout
+    if _sink(sinks, 16) is not None and _sink(sinks, 17) is not None:
+      call("as_conv3d_out_bwd", ptr(g_logits), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(sinks[16]), ptr(sinks[17]), 1,
+           ptr(ws), stream())
+    else:
+      g_wout = torch.empty_like(w_out)
+      g_bout = _empty(1, dev)
+      call("as_conv3d_out_bwd", ptr(g_logits), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout), 0,
+           ptr(ws), stream())
+      grads[16], grads[17] = g_wout, g_bout
 
     need_feat = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
     for l in range(3, -1, -1):
       w, b, gamma, beta = params[4 * l:4 * l + 4]
       g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], w, gamma, g, CONV3D_333, ctx.train,
-                                                    False, l > 0 or need_feat)
+                                                    False, l > 0 or need_feat,
+                                                    sinks[4 * l:4 * l + 4] if sinks is not None else None)
       grads[4 * l:4 * l + 4] = [dW, db, g_gamma, g_beta]
       POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
       g_a = g_x
@@ -298,7 +345,7 @@ class CostAggregationFn(torch.autograd.Function):
       POOL.put(g_a, g)
     POOL.put(xs[0], g)
     ctx.xs = ctx.zs = ctx.sts = None
-    return (g_fl, g_fr, None, None, None) + tuple(grads)
+    return (g_fl, g_fr, None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------
@@ -317,7 +364,7 @@ class FeatureExtractorFn(torch.autograd.Function):
   params: k x (downsample w, b), 6 x (conv w, conv b, bn w, bn b), conv_alone (w, b)."""
 
   @staticmethod
-  def forward(ctx, rgb, k, train, bn_buffers, *params):
+  def forward(ctx, rgb, k, train, bn_buffers, sinks, *params):
     k = int(k)
     assert len(params) == 2 * k + 26
     rgb = f32c(rgb)
@@ -366,6 +413,7 @@ class FeatureExtractorFn(torch.autograd.Function):
     POOL.put(out, g)
     if need_bwd:
       ctx.k, ctx.g4, ctx.geoms, ctx.train = k, g4, geoms, bool(train)
+      ctx.sinks = sinks
       ctx.in4, ctx.levels = in4, levels
       ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
       ctx.save_for_backward(*params)
@@ -389,16 +437,18 @@ class FeatureExtractorFn(torch.autograd.Function):
     tp = params[2 * k:]
     grads = [None] * len(params)
 
+    sinks = ctx.sinks
     g_out = POOL.get(g, dev)
     pcl_interior(g_out, g).copy_(f32c(g_feats).permute(0, 2, 3, 1).unsqueeze(1))
-    dW, db = conv32_wgrad(xs[6], g, g_out, g, shape)
+    dW, db = conv32_wgrad(xs[6], g, g_out, g, shape, True, _sink(sinks, 2 * k + 24), _sink(sinks, 2 * k + 25))
     grads[2 * k + 24], grads[2 * k + 25] = dW, db
     g_a = conv32(g_out, g, pack_weights(tp[24], shape, True), None, g, shape)
     POOL.put(g_out, g)
     for l in range(5, -1, -1):
       wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
-      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], wl, gamma, g, shape, ctx.train, True,
-                                                    True)
+      g_x, dW, db, g_gamma, g_beta = block_backward(
+          g_a, xs[l], zs[l], sts[l], wl, gamma, g, shape, ctx.train, True, True,
+          sinks[2 * k + 4 * l:2 * k + 4 * l + 4] if sinks is not None else None)
       grads[2 * k + 4 * l:2 * k + 4 * l + 4] = [dW, db, g_gamma, g_beta]
       POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
       g_a = g_x
@@ -408,13 +458,17 @@ class FeatureExtractorFn(torch.autograd.Function):
       wd = params[2 * i]
       gi = geoms[i]
       if i == 0:
-        dW = torch.empty_like(wd); db = _empty(32, dev)
         ws = _empty(lib.as_conv4_wgrad_workspace(gi, CONV5_S2), dev)
-        call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_a), gi, CONV5_S2, 3, ptr(dW), ptr(db), ptr(ws), stream())
-        grads[0], grads[1] = dW, db
+        if _sink(sinks, 0) is not None and _sink(sinks, 1) is not None:
+          call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_a), gi, CONV5_S2, 3, ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws),
+               stream())
+        else:
+          dW = torch.empty_like(wd); db = _empty(32, dev)
+          call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_a), gi, CONV5_S2, 3, ptr(dW), ptr(db), 0, ptr(ws), stream())
+          grads[0], grads[1] = dW, db
       else:
         gprev = geoms[i - 1]
-        dW, db = conv32_wgrad(levels[i - 1], gprev, g_a, gi, CONV5_S2)
+        dW, db = conv32_wgrad(levels[i - 1], gprev, g_a, gi, CONV5_S2, True, _sink(sinks, 2 * i), _sink(sinks, 2 * i + 1))
         grads[2 * i], grads[2 * i + 1] = dW, db
         g_prev = POOL.get(gprev, dev)
         ws = _empty(lib.as_conv32_dgrad_s2_workspace(), dev)
@@ -426,7 +480,7 @@ class FeatureExtractorFn(torch.autograd.Function):
     for buf, gi in zip(levels, geoms):
       POOL.put(buf, gi)
     ctx.xs = ctx.zs = ctx.sts = ctx.levels = ctx.in4 = None
-    return (None, None, None, None) + tuple(grads)
+    return (None, None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------
@@ -441,7 +495,7 @@ class EdgeRefineFn(torch.autograd.Function):
   params: conv2d_feature (w[32,4,3,3], b, bn w, bn b), 6 x (w[32,32,3,3], b, bn w, bn b), conv2d_out (w[1,32,3,3], b)."""
 
   @staticmethod
-  def forward(ctx, coarse, rgb, train, bn_buffers, *params):
+  def forward(ctx, coarse, rgb, train, bn_buffers, sinks, *params):
     assert len(params) == 30
     coarse, rgb = f32c(coarse), f32c(rgb)
     params = [f32c(p) for p in params]
@@ -504,6 +558,7 @@ class EdgeRefineFn(torch.autograd.Function):
 
     if need_bwd:
       ctx.g, ctx.g4, ctx.train = g, g4, bool(train)
+      ctx.sinks = sinks
       ctx.dims = (B, h, w, H, W, float(gain))
       ctx.in4, ctx.z0, ctx.st0 = in4, z0, st0
       ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
@@ -525,27 +580,37 @@ class EdgeRefineFn(torch.autograd.Function):
 
     g_pre = (f32c(g_out) * (out > 0)).contiguous()            # through the final ReLU (stereo_net.py:121)
     w_out = params[28]
+    sinks = ctx.sinks
     g_a = POOL.get(g, dev)
-    g_wout, g_bout = torch.empty_like(w_out), _empty(1, dev)
     ws = _empty(lib.as_conv32to1_bwd_workspace(g, s33), dev)
-    call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout), ptr(ws),
-         stream())
-    grads[28], grads[29] = g_wout, g_bout
+    if _sink(sinks, 28) is not None and _sink(sinks, 29) is not None:
+      call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(sinks[28]), ptr(sinks[29]), 1,
+           ptr(ws), stream())
+    else:
+      g_wout, g_bout = torch.empty_like(w_out), _empty(1, dev)
+      call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout), 0,
+           ptr(ws), stream())
+      grads[28], grads[29] = g_wout, g_bout
 
     for l in range(5, -1, -1):
       wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
       g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], wl, gamma, g,
-                                                    conv_shape_2d(REFINE_DILATIONS[l]), ctx.train, True, True)
+                                                    conv_shape_2d(REFINE_DILATIONS[l]), ctx.train, True, True,
+                                                    sinks[4 + 4 * l:8 + 4 * l] if sinks is not None else None)
       grads[4 + 4 * l:8 + 4 * l] = [dW, db, g_gamma, g_beta]
       POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
       g_a = g_x
 
     # conv2d_feature backward
     w0, b0, gamma0, beta0 = params[0:4]
-    g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train)
-    dW0 = torch.empty_like(w0); db0 = _empty(32, dev)
+    g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train, _sink(sinks, 2), _sink(sinks, 3))
     ws4 = _empty(lib.as_conv4_wgrad_workspace(g, s33), dev)
-    call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(dW0), ptr(db0), ptr(ws4), stream())
+    if _sink(sinks, 0) is not None and _sink(sinks, 1) is not None:
+      call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())
+      dW0 = db0 = None
+    else:
+      dW0 = torch.empty_like(w0); db0 = _empty(32, dev)
+      call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(dW0), ptr(db0), 0, ptr(ws4), stream())
     grads[0:4] = [dW0, db0, g_gamma0, g_beta0]
 
     g_coarse = None
@@ -561,7 +626,7 @@ class EdgeRefineFn(torch.autograd.Function):
       raise NotImplementedError("EdgeRefineFn: gradient w.r.t. the guidance image is not part of the adaptation path")
     POOL.put(g_z0, g); POOL.put(g_a, g); POOL.put(ctx.z0, g); POOL.put(xs[0], g); POOL.put(ctx.in4, g4, channels=4)
     ctx.xs = ctx.zs = ctx.sts = ctx.in4 = ctx.z0 = None
-    return (g_coarse, None, None, None) + tuple(grads)
+    return (g_coarse, None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // the per-channel coefficients of stage 3:  g_z = (g_y - k1 - (z-mean)*k2) * k3.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long count,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                               int train, float* g_gamma, float* g_beta, float* coef) {
+                                                               int train, float* g_gamma, float* g_beta, float* coef,
+                                                               int accumulate) {
   __shared__ double red[4][64];
   const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
   double s = 0.0;
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     const double sdy = red[0][c] + red[1][c] + red[2][c] + red[3][c];
     const double sdx = red[0][32 + c] + red[1][32 + c] + red[2][32 + c] + red[3][32 + c];
     const double is = (double)invstd[c];
-    g_gamma[c] = (float)(sdx * is);
-    g_beta[c] = (float)sdy;
+    g_gamma[c] = accumulate ? g_gamma[c] + (float)(sdx * is) : (float)(sdx * is);
+    g_beta[c] = accumulate ? g_beta[c] + (float)sdy : (float)sdy;
     coef[c] = train ? (float)(sdy / (double)count) : 0.f;
     coef[32 + c] = train ? (float)(sdx * is * is / (double)count) : 0.f;
     coef[64 + c] = invstd[c] * gamma[c];
@@ -275,7 +276,7 @@ extern "C" int64_t as_bn_bwd_workspace(const as_pcl* g) {
 
 extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const float* shift,
                              const float* save_mean, const float* save_invstd, const float* gamma,
-                             float slope, int train, float* g_z, float* g_gamma, float* g_beta,
+                             float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
                              float* workspace, const as_pcl* g, void* stream) {
   AS_CHECK_ARG(as_pcl_ok(g), "as_bn_act_bwd: bad geometry");
   AS_CHECK_ARG(g_a && z && scale && shift && save_mean && save_invstd && gamma && g_z && g_gamma && g_beta && workspace,
@@ -291,7 +292,7 @@ extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scal
                      partial, gd, M);
   AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nb, M, save_invstd, gamma, train,
-                     g_gamma, g_beta, coef);
+                     g_gamma, g_beta, coef, accumulate);
   AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(M)), dim3(256), 0, st, g_a, z, scale, shift,
                      save_mean, coef, slope, g_z, gd, M);

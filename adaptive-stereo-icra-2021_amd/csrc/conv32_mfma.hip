@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
 // LDS.  A single thread per output walking all slabs was a ~500-deep chain of dependent-latency loads.
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial,
                                                              const float* __restrict__ partial_db, int nchunks, int T,
-                                                             float* __restrict__ dW, float* __restrict__ db) {
+                                                             float* __restrict__ dW, float* __restrict__ db, int accumulate) {
   __shared__ float red[16][64];
   const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int total = T * 1024;
@@ -276,9 +276,10 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     for (int k = 0; k < 16; ++k) t += red[k][o];
     if (is_w) {
       const int oc = idx & 31, i = (idx >> 5) & 31, tp = idx >> 10;
-      dW[((long)oc * 32 + i) * T + tp] = t;
+      float* dst = dW + ((long)oc * 32 + i) * T + tp;
+      *dst = accumulate ? *dst + t : t;
     } else {
-      db[idx - total] = t;
+      db[idx - total] = accumulate ? db[idx - total] + t : t;
     }
   }
 }
@@ -482,7 +483,8 @@ static void launch_wgrad(const WgradArgs& a, int groups, int nchunks, hipStream_
 }
 
 extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
-                               const as_conv_shape* s, float* dW, float* db, float* workspace, void* stream) {
+                               const as_conv_shape* s, float* dW, float* db, int accumulate, float* workspace,
+                               void* stream) {
   if (int e = check_conv(gin, gout, s, "as_conv32_wgrad")) return e;
   AS_CHECK_ARG(x && gz && dW && workspace, "as_conv32_wgrad: null pointer");
   int tg, rpc, nchunks;
@@ -495,7 +497,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
     if (int e = conv32_wgrad_lds_launch(x, gin, gz, gout, s, workspace, partial_db, stream)) return e;
     as_prof_mark(3, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
-                       workspace, partial_db, slabs, T, dW, db);
+                       workspace, partial_db, slabs, T, dW, db, accumulate);
     AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
     return AS_OK;
   }
@@ -512,7 +514,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
   as_prof_mark(1, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
   AS_CHECK_LAUNCH("as_conv32_wgrad");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
-                     a.partial, a.partial_db, nchunks, T, dW, db);
+                     a.partial, a.partial_db, nchunks, T, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
   return AS_OK;
 }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
 // dW[co][c][t] = sum_chunks partial[chunk][k>>5][k&31][co], k = 4t + c
 __global__ void conv4_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
                                           int nchunks, int NB, int T, int Cin, float* __restrict__ dW,
-                                          float* __restrict__ db) {
+                                          float* __restrict__ db, int accumulate) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = 32 * Cin * T;
   if (idx < total) {
@@ -178,12 +178,12 @@ __global__ void conv4_wgrad_reduce_kernel(const float* __restrict__ partial, con
     const int k = 4 * t + c;
     float s = 0.f;
     for (int ch = 0; ch < nchunks; ++ch) s += partial[(((long)ch * NB + (k >> 5)) * 32 + (k & 31)) * 32 + co];
-    dW[idx] = s;
+    dW[idx] = accumulate ? dW[idx] + s : s;
   } else if (db != nullptr && idx < total + 32) {
     const int o = idx - total;
     float s = 0.f;
     for (int ch = 0; ch < nchunks; ++ch) s += partial_db[ch * 32 + o];
-    db[o] = s;
+    db[o] = accumulate ? db[o] + s : s;
   }
 }
 
@@ -282,7 +282,8 @@ static void launch4(const Wgrad4Args& a, int nchunks, hipStream_t st) {
 }
 
 extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,
-                              const as_conv_shape* s, int Cin, float* dW, float* db, float* workspace, void* stream) {
+                              const as_conv_shape* s, int Cin, float* dW, float* db, int accumulate, float* workspace,
+                              void* stream) {
   if (int e = check4(gin, gout, s, "as_conv4_wgrad")) return e;
   AS_CHECK_ARG(x4 && gz && dW && workspace && Cin >= 1 && Cin <= 4, "as_conv4_wgrad: bad argument");
   int nb, rpc, nchunks;
@@ -303,7 +304,7 @@ extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* g
   AS_CHECK_LAUNCH("as_conv4_wgrad");
   const int T = a.ntaps;
   hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up(32 * Cin * T + 32, 256)), dim3(256), 0, st, a.partial,
-                     a.partial_db, nchunks, nb, T, Cin, dW, db);
+                     a.partial_db, nchunks, nb, T, Cin, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv4_wgrad(reduce)");
   return AS_OK;
 }

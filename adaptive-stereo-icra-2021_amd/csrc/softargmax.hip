@@ -176,15 +176,16 @@ __global__ __launch_bounds__(256) void conv32to1_wgrad_kernel(OutConvBwdArgs p) 
 
 // one wave per output value: lanes stride over the slabs, shuffle-tree sum (fixed order)
 __global__ __launch_bounds__(256) void conv32to1_wgrad_reduce_kernel(const float* __restrict__ partial, int nblocks, int NT,
-                                                                      float* __restrict__ g_w, float* __restrict__ g_bias) {
+                                                                      float* __restrict__ g_w, float* __restrict__ g_bias,
+                                                                      int accumulate) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx > NT * 32) return;
   double s = 0.0;
   for (int i = lane; i < nblocks; i += 64) s += (double)partial[(long)i * (NT * 32 + 1) + idx];
   s = wave_sum_d(s);
   if (lane != 0) return;
-  if (idx == NT * 32) { if (g_bias) g_bias[0] = (float)s; }
-  else { const int t = idx >> 5, c = idx & 31; if (g_w) g_w[c * NT + t] = (float)s; }
+  if (idx == NT * 32) { if (g_bias) g_bias[0] = accumulate ? g_bias[0] + (float)s : (float)s; }
+  else { const int t = idx >> 5, c = idx & 31; if (g_w) g_w[c * NT + t] = accumulate ? g_w[c * NT + t] + (float)s : (float)s; }
 }
 
 // ---- soft-argmax ---------------------------------------------------------------------
@@ -279,7 +280,8 @@ extern "C" int64_t as_conv32to1_bwd_workspace(const as_pcl* g, const as_conv_sha
 }
 
 extern "C" int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl* g, const as_conv_shape* s,
-                                const float* w, float* g_a, float* g_w, float* g_bias, float* workspace, void* stream) {
+                                const float* w, float* g_a, float* g_w, float* g_bias, int accumulate, float* workspace,
+                                void* stream) {
   OutConvBwdArgs p;
   if (int e = fill_out_geom(g, s, &p.k, "as_conv32to1_bwd")) return e;
   AS_CHECK_ARG(g_out && a && w && workspace, "as_conv32to1_bwd: null pointer");
@@ -297,7 +299,7 @@ extern "C" int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl
     else hipLaunchKernelGGL(conv32to1_wgrad_kernel<9>, dim3((int)nb), dim3(256), 0, st, p);
     AS_CHECK_LAUNCH("as_conv32to1_bwd(wgrad)");
     hipLaunchKernelGGL(conv32to1_wgrad_reduce_kernel, dim3(as_div_up(p.k.ntaps * 32 + 1, 4)), dim3(256), 0, st,
-                       workspace, (int)nb, p.k.ntaps, g_w, g_bias);
+                       workspace, (int)nb, p.k.ntaps, g_w, g_bias, accumulate);
     AS_CHECK_LAUNCH("as_conv32to1_bwd(reduce)");
   }
   return AS_OK;
@@ -314,9 +316,9 @@ extern "C" int as_conv3d_out_fwd(const float* a, const as_pcl* g, const float* w
 extern "C" int64_t as_conv3d_out_bwd_workspace(const as_pcl* g) { return as_conv32to1_bwd_workspace(g, &k333); }
 
 extern "C" int as_conv3d_out_bwd(const float* g_logits, const float* a, const as_pcl* g, const float* w,
-                                 float* g_a, float* g_w, float* g_bias, float* workspace, void* stream) {
+                                 float* g_a, float* g_w, float* g_bias, int accumulate, float* workspace, void* stream) {
   AS_CHECK_ARG(g_a && g_w, "as_conv3d_out_bwd: null pointer");
-  return as_conv32to1_bwd(g_logits, a, g, &k333, w, g_a, g_w, g_bias, workspace, stream);
+  return as_conv32to1_bwd(g_logits, a, g, &k333, w, g_a, g_w, g_bias, accumulate, workspace, stream);
 }
 
 extern "C" int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,

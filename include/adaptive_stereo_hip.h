@@ -76,7 +76,9 @@ int as_cost_volume_bwd(const float* gvol, float* gL, float* gR, const as_pcl* g,
  *               eval-mode BatchNorm + LeakyReLU (+ BasicBlock skip) fused.
  * as_conv32_wgrad: dW[o][i][tap] (PyTorch layout) = sum_v x[v+tap][i] * gz[v][o];
  *   workspace must hold as_conv32_wgrad_workspace() floats. db (may be NULL) gets
- *   sum_v gz[v][o]. */
+ *   sum_v gz[v][o].  accumulate=1 adds into dW/db instead of overwriting them (all parameter-gradient
+ *   outputs of this library have this flag: it lets a caller point them at a flat gradient arena and
+ *   skip one "grad += dW" launch per parameter tensor). */
 int as_conv32_pack_weights(const float* w, float* packed, const as_conv_shape* s,
                            int transpose_flip, void* stream);
 int as_conv32_num_blocks(const as_pcl* gout);
@@ -94,7 +96,7 @@ int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const float* w, float
                        float* workspace, void* stream);
 int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
-                    const as_conv_shape* s, float* dW, float* db, float* workspace, void* stream);
+                    const as_conv_shape* s, float* dW, float* db, int accumulate, float* workspace, void* stream);
 
 /* ---- BatchNorm (train/eval) + LeakyReLU around the convolution --------------
  * nn.BatchNorm3d / nn.BatchNorm2d (eps, momentum as given) + nn.LeakyReLU(0.2)
@@ -120,7 +122,7 @@ int as_bn_act_fwd(const float* z, const float* scale, const float* shift, float 
 int64_t as_bn_bwd_workspace(const as_pcl* g);
 int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const float* shift,
                   const float* save_mean, const float* save_invstd, const float* gamma,
-                  float slope, int train, float* g_z, float* g_gamma, float* g_beta,
+                  float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
                   float* workspace, const as_pcl* g, void* stream);
 
 /* ---- a4 + a5 + a8: conv3d 32->1, soft-argmax, arg-max index, FCS ---------------
@@ -133,7 +135,7 @@ int as_conv3d_out_fwd(const float* a, const as_pcl* g, const float* w, const flo
                       float* logits, void* stream);
 int64_t as_conv3d_out_bwd_workspace(const as_pcl* g);
 int as_conv3d_out_bwd(const float* g_logits, const float* a, const as_pcl* g, const float* w,
-                      float* g_a, float* g_w, float* g_bias, float* workspace, void* stream);
+                      float* g_a, float* g_w, float* g_bias, int accumulate, float* workspace, void* stream);
 int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,
                       float* pred, int32_t* argmax, float* fcs, void* stream);
 /* g_logits[d] = p_d*(d - pred)*g_pred (+ g_logits_in[d] when not NULL). */
@@ -150,7 +152,8 @@ int as_conv32to1_fwd(const float* a, const as_pcl* g, const as_conv_shape* s, co
                      const float* bias, const float* add_src, int relu, float* out, void* stream);
 int64_t as_conv32to1_bwd_workspace(const as_pcl* g, const as_conv_shape* s);
 int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl* g, const as_conv_shape* s,
-                     const float* w, float* g_a, float* g_w, float* g_bias, float* workspace, void* stream);
+                     const float* w, float* g_a, float* g_w, float* g_bias, int accumulate, float* workspace,
+                     void* stream);
 
 /* ---- thin-input convolution: Cin <= 4 -> 32 on "PCL4" ([B][H+2ph][W+2pw][4], zero halo) -----
  * EdgeAwareRefinement.conv2d_feature = nn.Conv2d(4,32,3,padding=1) over cat([disparity, rgb])
@@ -167,7 +170,8 @@ int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* packed_w, cons
                  float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
 int64_t as_conv4_wgrad_workspace(const as_pcl* gout, const as_conv_shape* s);
 int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,
-                   const as_conv_shape* s, int Cin, float* dW, float* db, float* workspace, void* stream);
+                   const as_conv_shape* s, int Cin, float* dW, float* db, int accumulate, float* workspace,
+                   void* stream);
 
 /* ---- a6/a7 head: bilinear up-sampling, align_corners=False -------------------
  * F.interpolate(pred.unsqueeze(1), size=(H,W), mode="bilinear") * gain

@@ -230,3 +230,29 @@ def test_graph_replay_equals_eager_steps():
   assert l0 == l1, (l0, l1)
   assert torch.equal(p0, p1) and torch.equal(v0, v1)
   assert nb0 == nb1 == 5 and sc0 == sc1 == 5 and sd0 == sd1 == 5.0
+
+
+def test_direct_gradient_accumulation_equals_autograd_accumulation():
+  """Backward kernels that add parameter gradients straight into the flat arena (hip_ops.grad_sinks) must leave
+  the same bits there as autograd's own AccumulateGrad route (feature_net is used twice per step, so the
+  direct route really accumulates)."""
+  from adaptive_stereo import hip_ops
+  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
+  H, W, B = 96, 256, 2
+  results = []
+  try:
+    for direct in (False, True):
+      hip_ops.set_direct_grad_accumulation(direct)
+      fnet, snet = build(meta)
+      adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+      l, r = syn.stereo_pair(B, H, W, seed=11)
+      out = adapter.step(l.to(DEV), r.to(DEV))
+      torch.cuda.synchronize()
+      results.append((float(out["loss"]), adapter.arena.grads.clone(), adapter.arena.params.clone()))
+  finally:
+    hip_ops.set_direct_grad_accumulation(True)
+  (l0, g0, p0), (l1, g1, p1) = results
+  assert l0 == l1
+  assert float(g0.abs().max()) > 0
+  assert torch.equal(g0, g1), float((g0 - g1).abs().max())
+  assert torch.equal(p0, p1)

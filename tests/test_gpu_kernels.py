@@ -229,7 +229,7 @@ def test_out_conv_softargmax_fcs(B, D, H, W, gain):
   ws = torch.empty(lib.as_conv3d_out_bwd_workspace(g), device=DEV)
   gld = gl.to(DEV)
   nat.call("as_conv3d_out_bwd", nat.ptr(gld), nat.ptr(ab), g, nat.ptr(wd), nat.ptr(g_a), nat.ptr(g_w),
-           nat.ptr(g_b), nat.ptr(ws), nat.stream())
+           nat.ptr(g_b), 0, nat.ptr(ws), nat.stream())
   close(ops.pcl_to_ncdhw(g_a, g), a.grad, 2e-6 * max(1.0, gain), 1e-5, "out-conv dgrad")
   n = g.voxels()
   close(g_w, w.grad, 2e-6 * n ** 0.5, 1e-5, "out-conv wgrad")
@@ -371,7 +371,7 @@ def test_conv4_fwd_and_wgrad(B, H, W, Cin, k, stride, pad):
   gzb = ops.ncdhw_to_pcl(gz.unsqueeze(2).to(DEV), gout)
   dW = torch.empty(32, Cin, k, k, device=DEV); db = torch.empty(32, device=DEV)
   ws = torch.empty(lib.as_conv4_wgrad_workspace(gout, shape), device=DEV)
-  nat.call("as_conv4_wgrad", nat.ptr(x4), g4, nat.ptr(gzb), gout, shape, Cin, nat.ptr(dW), nat.ptr(db), nat.ptr(ws),
+  nat.call("as_conv4_wgrad", nat.ptr(x4), g4, nat.ptr(gzb), gout, shape, Cin, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws),
            nat.stream())
   n = B * Ho * Wo
   close(dW, w.grad, 2e-6 * n ** 0.5 + 1e-5, 2e-5, "conv4 wgrad")
@@ -422,7 +422,12 @@ def test_conv32to1_2d_fused_tail(B, H, W):
   g_a = ops.pcl_zeros(g, DEV); g_w = torch.empty_like(wd); g_b = torch.empty(1, device=DEV)
   ws = torch.empty(lib.as_conv32to1_bwd_workspace(g, shape), device=DEV)
   nat.call("as_conv32to1_bwd", nat.ptr(gpre), nat.ptr(ab), g, shape, nat.ptr(wd), nat.ptr(g_a), nat.ptr(g_w),
-           nat.ptr(g_b), nat.ptr(ws), nat.stream())
+           nat.ptr(g_b), 0, nat.ptr(ws), nat.stream())
+  # accumulate=1 adds on top of what is already there
+  g_w2 = g_w.clone(); g_b2 = g_b.clone()
+  nat.call("as_conv32to1_bwd", nat.ptr(gpre), nat.ptr(ab), g, shape, nat.ptr(wd), None, nat.ptr(g_w2),
+           nat.ptr(g_b2), 1, nat.ptr(ws), nat.stream())
+  close(g_w2, 2 * g_w, 1e-6, 1e-6, "tail wgrad accumulate"); close(g_b2, 2 * g_b, 1e-6, 1e-6, "tail bias accumulate")
   close(ops.pcl_to_ncdhw(g_a, g)[:, :, 0], a.grad, 5e-6, 1e-5, "tail dgrad")
   n = B * H * W
   close(g_w, w.grad, 2e-6 * n ** 0.5, 1e-5, "tail wgrad"); close(g_b, b.grad, 2e-6 * n ** 0.5, 1e-5, "tail bias grad")

@@ -42,7 +42,7 @@ for name, g, shape in cases:
   t_fe = timeit(lambda: ops.conv32(x, g, wp, b, g, shape, out=z, epilogue=1, scale=one, shift=b))
   ws = torch.empty(nat.load().as_conv32_wgrad_workspace(g, g, shape), device=dev)
   dW = torch.empty_like(w); db = torch.empty(32, device=dev)
-  t_w = timeit(lambda: nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(gz), g, shape, nat.ptr(dW), nat.ptr(db), nat.ptr(ws), nat.stream()))
+  t_w = timeit(lambda: nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(gz), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream()))
   st = ops.BnState(dev); st.mean.zero_(); st.invstd.fill_(1.0); st.scale.fill_(1.0); st.shift.zero_()
   a = torch.zeros(g.numel(), device=dev)
   t_a = timeit(lambda: ops.bn_act(z, st, g, residual=x, out=a))

@@ -20,6 +20,6 @@ ws = torch.empty(nat.load().as_conv32_wgrad_workspace(g, g, shape), device=dev)
 dW = torch.empty_like(w); db = torch.empty(32, device=dev)
 for _ in range(5):
   ops.conv32(x, g, wp, b, g, shape, out=z, stats=stats)
-  nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(z), g, shape, nat.ptr(dW), nat.ptr(db), nat.ptr(ws), nat.stream())
+  nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(z), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
 torch.cuda.synchronize()
 print("done")
