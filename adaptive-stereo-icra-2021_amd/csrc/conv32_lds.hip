@@ -37,42 +37,83 @@ struct ConvLdsArgs {
   EpilogueArgs ep;
   PclDev gin, gout;
   int dil, tiles_per_row, ntiles, tiles_per_band, wg_per_xcd;
+#ifdef AS_LDS_TRACE_BUILD
+  unsigned long long* trace;           // diagnostic build only: [wg][32 tiles][8] 100-MHz timestamps
+#endif
 };
+
+// Diagnostic build (make TRACE=1): wave 0 of every workgroup timestamps the phases of its first 32 tiles;
+// the launch selected by AS_LDS_TRACE=<n> dumps them to gpurun_out/lds_trace.bin (tests/tools/lds_trace_view.py).
+#ifdef AS_LDS_TRACE_BUILD
+#define AS_TRACE(slot) do { if (p.trace && threadIdx.x == 0 && it < 32) p.trace[((long)blockIdx.x * 32 + it) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define AS_TRACE(slot) do { } while (0)
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-__device__ inline void tile_coords(const ConvLdsArgs& p, int tile, int& b, int& y, int& x0) {
+// Row segment of a tile.  The last segment of a row is shifted LEFT to end exactly at W (x0 = W-128), so every
+// tile is 128 valid voxels wide: no ragged edge anywhere in the kernel.  The voxels it shares with its
+// neighbour ([x0, nominal start)) are computed twice and stored twice with identical values; only the
+// BatchNorm moments have to skip them (x_new = first voxel that is this tile's alone).
+__device__ inline void tile_coords(const ConvLdsArgs& p, int tile, int& b, int& y, int& x0, int& x_new) {
   const int row = tile / p.tiles_per_row;
-  x0 = (tile - row * p.tiles_per_row) * 128;
+  x_new = (tile - row * p.tiles_per_row) * 128;
+  x0 = min(x_new, p.gout.W - 128);
   b = row / p.gout.H;
   y = row - b * p.gout.H;
 }
 
-// Stage the three rows of `tile` into `buf` (LDS byte address).  54 wave instructions, 13-14 per wave.
-__device__ inline void issue_tile_dma(const ConvLdsArgs& p, int tile, char* buf, int wave, int lane) {
-  int b, y, x0;
-  tile_coords(p, tile, b, y, x0);
+// One 1-KB LDS-DMA instruction: 64 lanes x 16 B from  sbase + voff  to LDS byte  m0 + 16*lane.
+// Written as inline asm ON PURPOSE: with a visible global_load_lds in the kernel hipcc (ROCm 7.2) waits
+// vmcnt(0) before the first ds_read of every tile and at every use of an ordinary load — vmcnt is in-order,
+// so each of those also waits for the DMA of the NEXT tile and for the output stores.  Hidden, the compiler
+// counts only its own loads (its waits stay correct, merely conservative) and the DMA is retired by the
+// explicit counted waits in the kernel.
+__device__ inline void dma_1kb(const float* sbase, unsigned voff, unsigned m0) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+
+// Stage the three rows of `tile`: 54 wave instructions; wave w takes columns i = w, w+4, .. of every row
+// (i&1 == w&1, so the swizzled lane offset is one per-wave constant): scalar base per instruction, constant
+// lane offset, no vector ALU work.  (On this chip vector-ALU instructions of one wave do NOT overlap the
+// MFMAs of the other wave on the SIMD — measured: their times add — so every VALU instruction in the
+// per-tile path costs matrix-core time.)
+__device__ inline void issue_tile_dma(const ConvLdsArgs& p, int tile, unsigned lds0, int wave, unsigned lane_off) {
+  int b, y, x0, x_new;
+  tile_coords(p, tile, b, y, x0, x_new);
   const int Wp = p.gin.Wp;
-  const int px0 = x0 - 8 + p.gin.pw;             // padded x of LDS column 0
-  const int vl = lane >> 3, slot = lane & 7;
-  for (int idx = wave; idx < 3 * TL_DMA_PER_ROW; idx += 4) {
-    const int r = idx / TL_DMA_PER_ROW, i = idx - r * TL_DMA_PER_ROW;
-    const int v = 8 * i + vl;
-    const int chunk = slot ^ ((v >> 1) & 7);
-    const long rowvox = ((long)b * p.gin.Hp + (y + p.gin.ph + (r - 1) * p.dil)) * Wp;
-    const int px = min(px0 + v, Wp - 1);         // the last tile of a row may overhang: stay inside the buffer
-    const float* src = p.x + (rowvox + px) * 32 + chunk * 4;
-    char* dst = buf + (r * TL_W + 8 * i) * 128;  // wave-uniform; the hardware adds lane*16
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+  const long rowvox = ((long)b * p.gin.Hp + (y + p.gin.ph - p.dil)) * Wp + (x0 - 8 + p.gin.pw);
+  const float* row0 = p.x + rowvox * 32;                                 // wave-uniform
+  const long row_stride = (long)p.dil * Wp * 32;                         // floats
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float* srow = row0 + r * row_stride;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = wave + 4 * k;
+      if (i < TL_DMA_PER_ROW)                                            // wave-uniform
+        dma_1kb(srow + i * 256, lane_off, lds0 + (unsigned)((r * TL_W + 8 * i) * 128));
+    }
   }
 }
 
-__device__ inline void lds_load_a(f32x4 (&a)[4], const char* buf, int r, int v, int h) {
-  const int sw = (v >> 1) & 7;
-  const char* base = buf + (r * TL_W + v) * 128;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(base + (((4 * h + q) ^ sw) << 4));
+// Output / residual accesses of a wave tile: scalar base + one constant lane
+// offset + the row as an instruction immediate — no address arithmetic.  Inline asm for the same reason as the
+// DMA (the stores stay out of hipcc's vmcnt bookkeeping; the kernel's explicit waits retire them).
+template <int IMM> __device__ inline void store_imm(float* sbase, unsigned voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int IMM> __device__ inline void load_imm(float& v, const float* sbase, unsigned voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+#define AS_ROW_IMM(r) ((((r) & 3) + 8 * ((r) >> 2)) * 128)
+#define AS_FOR_ROWS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+
+__device__ inline f32x4 lds_chunk(const char* buf, int r, int v, int h, int q) {
+  return *reinterpret_cast<const f32x4*>(buf + (r * TL_W + v) * 128 + (((4 * h + q) ^ ((v >> 1) & 7)) << 4));
 }
 
 __device__ inline void glb_load_w(f32x4 (&r)[4], const float* p) {
@@ -82,76 +123,175 @@ __device__ inline void glb_load_w(f32x4 (&r)[4], const float* p) {
   r[3] = *reinterpret_cast<const f32x4*>(p + 768);
 }
 
-__device__ inline void mfma16l(f32x16& acc, const f32x4 (&a)[4], const f32x4 (&b)[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
-  }
-}
-
+// Kernel flavours (compile time, so that no path carries another one's waits):
+//   MODE 0: raw output + BatchNorm moments (training forward)   MODE 1: lrelu(acc*scale+shift) (eval forward)
+//   MODE 2: raw output, no moments (data gradients)             RES: + residual in the output geometry
+// Kernel flavours (compile time, so that no path carries another one's waits):
+//   MODE 0: raw output + BatchNorm moments (training forward)   MODE 1: lrelu(acc*scale+shift) (eval forward)
+//   MODE 2: raw output, no moments (data gradients)             RES: + residual in the output geometry
+template <int MODE, bool RES>
 __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tile_buf = smem;
-  float (*red)[32] = reinterpret_cast<float (*)[32]>(smem + TL_BUF_BYTES);
-  float* bmean = reinterpret_cast<float*>(smem + TL_BUF_BYTES + 512);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_ptr_t)tile_buf));
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, li = lane & 31;
   const float* wb = p.wq + lane * 4;
+  const unsigned io_off = (unsigned)(512 * h + 4 * li);   // byte offset of (row 4h, channel li) in a wave tile
 
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int t_begin = xcd * p.tiles_per_band;
   const int t_end = min(t_begin + p.tiles_per_band, p.ntiles);
-  TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
   const float bias_v = p.ep.bias ? p.ep.bias[li] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (MODE == 1) { sc = p.ep.ep_scale[li]; sh = p.ep.ep_shift[li]; }
+  // BatchNorm moments: every lane keeps shifted sums of ITS elements over all of the workgroup's tiles
+  // (3 VALU per element, no barrier, no LDS in the tile loop); shift = the lane's first element, so the sums
+  // stay small and  M2 = s2 - s1^2/n  loses nothing.  One Chan merge per workgroup at the end.
+  float st_n = 0.f, st_c = 0.f, st_s1 = 0.f, st_s2 = 0.f;
+  // DMA lane constant: voxel vl of an 8-voxel group, channel chunk swizzled by the voxel (see file header)
+  const unsigned dma_lane_off =
+      (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) << 4);
+
+  // B fragments of taps 0..RESIDENT-1 stay in registers for the whole launch; the others do not fit next to
+  // the rest of the working set and are re-read from L2 every tile, 48 MFMAs before their use.
+  constexpr int RESIDENT = RES ? 7 : (MODE == 0 ? 8 : 9);              // the residual tile needs 16 registers of its own
+  constexpr int W_LEAD = 12;                          // streamed taps are requested 12 chunks (48 MFMAs) ahead
+  f32x4 w[9][4];
+#pragma unroll
+  for (int tp = 0; tp < RESIDENT; ++tp) glb_load_w(w[tp], wb + tp * 1024);
 
   int tile = t_begin + j;
-  if (tile < t_end) issue_tile_dma(p, tile, tile_buf, wave, lane);
-  for (int it = 0; tile < t_end; tile += p.wg_per_xcd, ++it) {
-    int b, y, x0;
-    tile_coords(p, tile, b, y, x0);
-    const int x = x0 + 32 * wave + li;
-    const bool valid = x < p.gout.W;
-    const int out_vox = (int)p.gout.vox(b, 0, y, valid ? x : p.gout.W - 1);
+  if (tile < t_end) issue_tile_dma(p, tile, lds0, wave, dma_lane_off);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AS_LDS_TRACE_BUILD
+  int it = -1;
+#endif
+  for (; tile < t_end; tile += p.wg_per_xcd) {
+#ifdef AS_LDS_TRACE_BUILD
+    ++it;
+#endif
+    int b, y, x0, x_new;
+    tile_coords(p, tile, b, y, x0, x_new);
+    const int xw = x0 + 32 * wave;                      // wave-uniform
+    const long vox0 = p.gout.vox(b, 0, y, xw);
     const int vbase = 32 * wave + li + 8;
+    float* z_base = p.ep.z + vox0 * 32;                 // wave-uniform
+    const float* res_base = RES ? p.ep.residual + vox0 * 32 : nullptr;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias_v;
-    f32x4 a[2][4], w[2][4];
-    // Wait for this wave's share of the tile's DMA — but not for the previous tile's 16 output stores,
-    // which were issued AFTER that DMA: vmcnt counts stores too, and waiting for their HBM
-    // acknowledgement would expose a 1-2 us drain on every tile.  (vmcnt is in-order: "at most 16
-    // outstanding" means everything older than the 16 youngest operations has completed.)
-    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    f32x4 a[4];                        // ring of A chunks, prefetch distance 3 (= 12 MFMAs = 768 cycles)
+    float res[16];
+    AS_TRACE(0);
+    // Retire this tile's DMA (issued before the previous tile's epilogue) but NOT that epilogue's 16 output
+    // stores, which are younger: vmcnt counts loads, stores and LDS-DMA together in issue order, so "at most
+    // 16 outstanding" = everything older than the 16 stores has landed.  Every wave issues exactly 16 stores
+    // per tile.  (First tile: everything was retired before the loop, the wait falls through.)
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    AS_TRACE(1);
     __syncthreads();
-    glb_load_w(w[0], wb);
-    lds_load_a(a[0], tile_buf, 0, vbase - p.dil, h);
+    AS_TRACE(2);
+    int offs = RESIDENT * 1024;
+    asm volatile("" : "+s"(offs));                      // keep hipcc from hoisting (and then spilling) the addresses
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      if (tp + 1 < 9) {
-        const int r = (tp + 1) / 3, kx = (tp + 1) % 3;
-        lds_load_a(a[(tp + 1) & 1], tile_buf, r, vbase + (kx - 1) * p.dil, h);
-        glb_load_w(w[(tp + 1) & 1], wb + (tp + 1) * 1024);
+    for (int tp = RESIDENT; tp < 9; ++tp)
+      if (4 * tp - W_LEAD <= 0) glb_load_w(w[tp], wb + offs + (tp - RESIDENT) * 1024);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a[c] = lds_chunk(tile_buf, 0, vbase - p.dil, h, c);
+#pragma unroll
+    for (int c = 0; c < 36; ++c) {
+      if (c + 3 < 36) {
+        const int tp = (c + 3) >> 2;
+        a[(c + 3) & 3] = lds_chunk(tile_buf, tp / 3, vbase + (tp % 3 - 1) * p.dil, h, (c + 3) & 3);
+      }
+#pragma unroll
+      for (int tp = RESIDENT; tp < 9; ++tp)
+        if (4 * tp - W_LEAD == c && c > 0) glb_load_w(w[tp], wb + offs + (tp - RESIDENT) * 1024);
+      if (RES && c == 22) {            // the residual tile, fetched while 14 chunks of MFMA work remain
+#define AS_LD(r) load_imm<AS_ROW_IMM(r)>(res[r], res_base, io_off);
+        AS_FOR_ROWS(AS_LD)
+#undef AS_LD
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma16l(acc, a[tp & 1], w[tp & 1]);
+      const f32x4 av = a[c & 3], bv = w[c >> 2][c & 3];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // every wave has read its operands: the tile buffer is free.  Start the next tile's DMA BEFORE the
-    // epilogue's stores, so that it is older than they are in the vmcnt queue.
-    __syncthreads();
+    // Everything this wave loaded into registers (weights, residual) must be home BEFORE the next DMA goes
+    // out: a later wait for it would, vmcnt being in-order, also wait for that DMA.  The residual registers
+    // are operands of the wait so that no use of them can be scheduled above it.
+    AS_TRACE(3);
+    if (RES) {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]),
+                     "+v"(res[7]), "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]),
+                     "+v"(res[13]), "+v"(res[14]), "+v"(res[15]) :: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                   // every wave has read its operands: the tile buffer is free
+    AS_TRACE(4);
     const int next_tile = tile + p.wg_per_xcd;
-    if (next_tile < t_end) issue_tile_dma(p, next_tile, tile_buf, wave, lane);
+    if (next_tile < t_end) issue_tile_dma(p, next_tile, lds0, wave, dma_lane_off);
     __builtin_amdgcn_sched_barrier(0);
-    TileStats ts; ts.n = 0.f; ts.mean = 0.f; ts.m2 = 0.f;
-    conv_epilogue<true>(acc, p.ep, out_vox, valid, min(128, p.gout.W - x0), red, bmean, &ts);
-    if (p.ep.stat_mean != nullptr && threadIdx.x < 32) stats_merge(run, ts);
+    AS_TRACE(5);
+
+    // ---- epilogue: exactly 16 store instructions per wave, nothing that waits on vector memory ----
+#define AS_ST(r) { float v = acc[r];                                                        \
+                   if (MODE == 1) { v = v * sc + sh; v = fmaxf(v, v * p.ep.slope); }         \
+                   if (RES) v += res[r];                                                      \
+                   store_imm<AS_ROW_IMM(r)>(z_base, io_off, v); }
+    AS_FOR_ROWS(AS_ST)
+#undef AS_ST
+    if (MODE == 0) {
+      const int dup = x_new - xw;      // wave-uniform: rows below `dup` also belong to the neighbouring tile
+      if (dup <= 0) {
+        st_c = st_n == 0.f ? acc[0] : st_c;   // data-dependent on purpose: an iteration-count test makes hipcc peel the loop
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[r] - st_c; st_s1 += d; st_s2 = fmaf(d, d, st_s2); }
+        st_n += 16.f;
+      } else if (dup < 32) {
+        st_c = st_n == 0.f ? acc[15] : st_c;  // row 27 + 4h: new whenever the wave has any new row of this half
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float d = row >= dup ? acc[r] - st_c : 0.f;
+          st_s1 += d; st_s2 = fmaf(d, d, st_s2); st_n += row >= dup ? 1.f : 0.f;
+        }
+      }
+    }
+    AS_TRACE(6);
+#ifdef AS_LDS_TRACE_BUILD
+    if (p.trace && threadIdx.x == 0 && it == 0) p.trace[((long)blockIdx.x * 32) * 8 + 7] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
   }
-  stats_write(p.ep, blockIdx.x, run);
+  if (MODE == 0 && p.ep.stat_mean != nullptr) {
+    // lane sums -> (n, mean, M2) -> one partial per workgroup: 8 (wave, half) partials per channel, merged in
+    // fixed order (deterministic).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // the tile buffer is no longer in use
+    float* part = reinterpret_cast<float*>(smem);      // [8][32][3]
+    const float mean_l = st_n > 0.f ? st_c + st_s1 / st_n : 0.f;
+    const float m2_l = st_n > 0.f ? fmaxf(st_s2 - st_s1 * st_s1 / st_n, 0.f) : 0.f;
+    float* mine = part + ((wave * 2 + h) * 32 + li) * 3;
+    mine[0] = st_n; mine[1] = mean_l; mine[2] = m2_l;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
+      for (int q = 0; q < 8; ++q) {
+        TileStats t;
+        t.n = part[(q * 32 + li) * 3]; t.mean = part[(q * 32 + li) * 3 + 1]; t.m2 = part[(q * 32 + li) * 3 + 2];
+        stats_merge(run, t);
+      }
+      stats_write(p.ep, blockIdx.x, run);
+    }
+  }
 }
 
 // ---- host ---------------------------------------------------------------------------------------
@@ -161,6 +301,7 @@ bool conv32_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_
   if (s->dil < 1 || s->dil > 8 || s->pad_h != s->dil || s->pad_w != s->dil) return false;
   if (gin->H != gout->H || gin->W != gout->W) return false;
   if (gin->pw < 8 || gin->ph < s->dil) return false;      // the staged tile always spans x0-8 .. x0+135
+  if (gout->W < 128) return false;                        // every tile is a full 128-voxel row segment
   return true;
 }
 
@@ -177,16 +318,6 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
                       float* z, const as_pcl* gout, const as_conv_shape* s,
                       int epilogue, const float* ep_scale, const float* ep_shift, float slope,
                       const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES);
-    if (e != hipSuccess) {
-      as_set_error("conv32_lds: cannot reserve %d bytes of LDS: %s", TL_LDS_BYTES, hipGetErrorString(e));
-      return AS_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
   ConvLdsArgs a;
   a.x = x; a.wq = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = residual;
@@ -201,8 +332,43 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
   a.tiles_per_band = (a.ntiles + 7) / 8;
   a.wg_per_xcd = grid / 8;
   hipStream_t st = (hipStream_t)stream;
+  const int mode = epilogue == 1 ? 1 : (a.ep.stat_mean != nullptr ? 0 : 2);
+  const void* fn = nullptr;
+#define AS_LDS_PICK(M, R) (R ? reinterpret_cast<const void*>(conv32_lds_kernel<M, true>) : reinterpret_cast<const void*>(conv32_lds_kernel<M, false>))
+  const bool has_res = residual != nullptr;
+  fn = mode == 0 ? AS_LDS_PICK(0, has_res) : mode == 1 ? AS_LDS_PICK(1, has_res) : AS_LDS_PICK(2, has_res);
+#undef AS_LDS_PICK
+  static bool attr_set[6] = {false, false, false, false, false, false};
+  const int fi = mode * 2 + (has_res ? 1 : 0);
+  if (!attr_set[fi]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES);
+    if (e != hipSuccess) {
+      as_set_error("conv32_lds: cannot reserve %d bytes of LDS: %s", TL_LDS_BYTES, hipGetErrorString(e));
+      return AS_ERR_LAUNCH;
+    }
+    attr_set[fi] = true;
+  }
+#ifdef AS_LDS_TRACE_BUILD
+  static int trace_countdown = -2;
+  static unsigned long long* trace_buf = nullptr;
+  if (trace_countdown == -2) { const char* e = getenv("AS_LDS_TRACE"); trace_countdown = e ? atoi(e) : -1; }
+  a.trace = nullptr;
+  const size_t trace_bytes = (size_t)TL_MAX_WG * 32 * 8 * 8;
+  if (trace_countdown > 0 && --trace_countdown == 0) {
+    hipMalloc(&trace_buf, trace_bytes); hipMemset(trace_buf, 0, trace_bytes); a.trace = trace_buf;
+  }
+#endif
   as_prof_mark(2, st, 1, 0.0);
-  hipLaunchKernelGGL(conv32_lds_kernel, dim3(grid), dim3(256), TL_LDS_BYTES, st, a);
+  void* kargs[] = {&a};
+  hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, TL_LDS_BYTES, st);
+  if (le != hipSuccess) { as_set_error("as_conv32_fwd(lds): launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
+#ifdef AS_LDS_TRACE_BUILD
+  if (a.trace) {
+    hipStreamSynchronize(st);
+    void* hbuf = malloc(trace_bytes); hipMemcpy(hbuf, trace_buf, trace_bytes, hipMemcpyDeviceToHost);
+    FILE* f = fopen("gpurun_out/lds_trace.bin", "wb"); if (f) { fwrite(hbuf, 1, trace_bytes, f); fclose(f); } free(hbuf);
+  }
+#endif
   as_prof_mark(2, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
   AS_CHECK_LAUNCH("as_conv32_fwd(lds)");
   return AS_OK;
