@@ -380,11 +380,17 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
 // one 256-byte wave load per operand per MFMA (1.33 per MFMA with 3 taps per wave): the CU's vector-memory
 // instruction rate, not bytes, limited it to 58 TFLOP/s, and each tap group re-fetched its rows (2.9x the
 // algorithmic HBM bytes).  Here a persistent workgroup stages the three X rows and the G row of a
-// 128-pixel segment in LDS by DMA (same swizzle as the forward kernel), every wave takes 32 of the
-// segment's voxels for ALL NINE taps (9 independent accumulators = 144 registers, so the MFMA chain
-// never waits on itself), operands are conflict-free ds_read_b32 (32 lanes = the 32 channels of one
-// voxel line), and the accumulators live in registers across all of the workgroup's tiles: one slab per
-// workgroup, summed in fixed order by wgrad_reduce_kernel (deterministic, no float atomics).
+// 128-pixel segment in LDS by DMA, every wave takes 32 of the segment's voxels for ALL NINE taps
+// (9 independent accumulators = 144 registers), and the accumulators live in registers across all of the
+// workgroup's tiles: one slab per workgroup, summed in fixed order by wgrad_reduce_kernel (deterministic,
+// no float atomics).
+// The per-tile path carries almost no vector-ALU work (it would cost matrix-core time, see issue_tile_dma):
+//   * LDS image = plain copy of the rows (no swizzle): an operand read is a ds_read_b32 of one voxel's 32
+//     channels by 32 lanes (+ the next voxel by the other 32) = 64 consecutive banks, conflict-free as is;
+//     the address of step s is  base(kx, lane) + row*18432 + s*256  — all immediates;
+//   * DMA source = scalar base + lane*16; the ragged end of a row is handled by clamping the SCALAR base of
+//     an 8-voxel group: X groups stay inside the padded row (what they then fetch only ever multiplies zero
+//     G), G groups at or beyond W read the row's right halo, which is zero (needs pw >= 8).
 #define TLG_BYTES (128 * 128)                           // G row segment
 #define TLW_LDS_BYTES (TL_BUF_BYTES + TLG_BYTES)        // 71,680 B; two workgroups per CU
 
@@ -397,47 +403,42 @@ struct WgradLdsArgs {
   int dil, tiles_per_row, ntiles, tiles_per_band, wg_per_xcd;
 };
 
-__device__ inline void issue_wgrad_dma(const WgradLdsArgs& p, int tile, char* xbuf, char* gbuf, int wave, int lane) {
+__device__ inline void issue_wgrad_dma(const WgradLdsArgs& p, int tile, unsigned lds_x, unsigned lds_g, int wave,
+                                       unsigned lane16) {
   const int row = tile / p.tiles_per_row;
   const int x0 = (tile - row * p.tiles_per_row) * 128;
   const int b = row / p.gout.H, y = row - b * p.gout.H;
-  const int vl = lane >> 3, slot = lane & 7;
-  // X: three rows of 144 voxels; G: one row of 128 voxels (16 more instructions)
-  for (int idx = wave; idx < 3 * TL_DMA_PER_ROW + 16; idx += 4) {
-    const float* src; char* dst;
-    if (idx < 3 * TL_DMA_PER_ROW) {
-      const int r = idx / TL_DMA_PER_ROW, i = idx - r * TL_DMA_PER_ROW;
-      const int v = 8 * i + vl;
-      const int chunk = slot ^ ((v >> 1) & 7);
-      const long rowvox = ((long)b * p.gin.Hp + (y + p.gin.ph + (r - 1) * p.dil)) * p.gin.Wp;
-      const int px = min(x0 - 8 + p.gin.pw + v, p.gin.Wp - 1);
-      src = p.x + (rowvox + px) * 32 + chunk * 4;
-      dst = xbuf + (r * TL_W + 8 * i) * 128;
-    } else {
-      const int i = idx - 3 * TL_DMA_PER_ROW;
-      const int v = 8 * i + vl;
-      const int chunk = slot ^ ((v >> 1) & 7);
-      const long rowvox = ((long)b * p.gout.Hp + (y + p.gout.ph)) * p.gout.Wp;
-      const int px = min(x0 + p.gout.pw + v, p.gout.Wp - 1);   // beyond W: halo voxels, which are zero
-      src = p.gz + (rowvox + px) * 32 + chunk * 4;
-      dst = gbuf + (8 * i) * 128;
+  const int Wp = p.gin.Wp;
+  const float* xrow0 = p.x + ((long)b * p.gin.Hp + (y + p.gin.ph - p.dil)) * Wp * 32;      // wave-uniform
+  const long row_stride = (long)p.dil * Wp * 32;
+  const int px0 = x0 - 8 + p.gin.pw;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float* srow = xrow0 + r * row_stride;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = wave + 4 * k;
+      if (i < TL_DMA_PER_ROW)
+        dma_1kb(srow + (long)min(px0 + 8 * i, Wp - 8) * 32, lane16, lds_x + (unsigned)((r * TL_W + 8 * i) * 128));
     }
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
   }
-}
-
-// one float of voxel v's 128-byte line (swizzled): channel c
-__device__ inline float lds_chan(const char* rowbase, int v, int c) {
-  const int slot = (c >> 2) ^ ((v >> 1) & 7);
-  return *reinterpret_cast<const float*>(rowbase + v * 128 + slot * 16 + (c & 3) * 4);
+  const float* grow = p.gz + (((long)b * p.gout.Hp + (y + p.gout.ph)) * p.gout.Wp + p.gout.pw) * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = wave + 4 * k;
+    dma_1kb(grow + (long)min(x0 + 8 * i, p.gout.W) * 32, lane16, lds_g + (unsigned)(8 * i * 128));
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void conv32_wgrad_lds_kernel(WgradLdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xbuf = smem;
   char* gbuf = smem + TL_BUF_BYTES;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned lds_x = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_ptr_t)xbuf));
+  const unsigned lds_g = lds_x + TL_BUF_BYTES;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, li = lane & 31;
+  const unsigned lane16 = (unsigned)lane * 16u;
 
   f32x16 acc[9];
 #pragma unroll
@@ -446,29 +447,31 @@ __global__ __launch_bounds__(256, 2) void conv32_wgrad_lds_kernel(WgradLdsArgs p
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
+  // operand addresses of step 0 (tile-invariant): voxel 32*wave + h (+8 + (kx-1)*dil in the staged X rows)
+  const char* gaddr = gbuf + (32 * wave + h) * 128 + li * 4;
+  const char* xaddr[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) xaddr[kx] = xbuf + (32 * wave + h + 8 + (kx - 1) * p.dil) * 128 + li * 4;
+
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int t_begin = xcd * p.tiles_per_band;
   const int t_end = min(t_begin + p.tiles_per_band, p.ntiles);
   for (int tile = t_begin + j; tile < t_end; tile += p.wg_per_xcd) {
-    issue_wgrad_dma(p, tile, xbuf, gbuf, wave, lane);
+    issue_wgrad_dma(p, tile, lds_x, lds_g, wave, lane16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // this wave's 32 voxels of the segment: 16 steps of one voxel pair (lane half h picks the voxel)
     float bv[2], av[2][9];
-    {
-      const int v = 32 * wave + h;
-      bv[0] = lds_chan(gbuf, v, li);
+    bv[0] = *reinterpret_cast<const float*>(gaddr);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) av[0][t] = lds_chan(xbuf + (t / 3) * TL_ROW_BYTES, v + 8 + (t % 3 - 1) * p.dil, li);
-    }
+    for (int t = 0; t < 9; ++t) av[0][t] = *reinterpret_cast<const float*>(xaddr[t % 3] + (t / 3) * TL_ROW_BYTES);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       if (s + 1 < 16) {
-        const int v = 32 * wave + 2 * (s + 1) + h;
-        bv[(s + 1) & 1] = lds_chan(gbuf, v, li);
+        bv[(s + 1) & 1] = *reinterpret_cast<const float*>(gaddr + (s + 1) * 256);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
-          av[(s + 1) & 1][t] = lds_chan(xbuf + (t / 3) * TL_ROW_BYTES, v + 8 + (t % 3 - 1) * p.dil, li);
+          av[(s + 1) & 1][t] = *reinterpret_cast<const float*>(xaddr[t % 3] + (t / 3) * TL_ROW_BYTES + (s + 1) * 256);
       }
       __builtin_amdgcn_sched_barrier(0);
       bsum += bv[s & 1];

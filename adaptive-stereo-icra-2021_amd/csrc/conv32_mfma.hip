@@ -464,7 +464,7 @@ static int wgrad_plan(const as_pcl* gout, const as_conv_shape* s, int* tg, int* 
 }
 
 static bool wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
-  return conv32_lds_applicable(gin, gout, s) && gout->pw >= 1;
+  return conv32_lds_applicable(gin, gout, s) && gout->pw >= 8;   // G groups beyond W read 8 zero halo voxels
 }
 
 extern "C" int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
