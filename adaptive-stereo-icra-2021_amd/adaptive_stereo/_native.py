@@ -47,6 +47,7 @@ _SIGNATURES = {
   "as_cost_volume_fwd": (c_int, [c_vp, c_vp, c_vp, _P(Pcl), c_vp]),
   "as_cost_volume_bwd": (c_int, [c_vp, c_vp, c_vp, _P(Pcl), c_vp]),
   "as_conv32_pack_weights": (c_int, [c_vp, c_vp, _P(ConvShape), c_int, c_vp]),
+  "as_conv32_pack_weights_batch": (c_int, [c_vp, c_int, c_int, c_vp]),
   "as_conv32_num_blocks": (c_int, [_P(Pcl)]),
   "as_conv32_stat_parts": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_float,

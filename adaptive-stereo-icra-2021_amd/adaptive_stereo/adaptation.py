@@ -143,6 +143,7 @@ class OnlineAdapter(object):
     dev = self.arena.params.device
     self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [count, loss_sum, fcs_sum, pairs]
     self._graph = None
+    self.plan = hip_ops.StepPlan()     # one-launch weight packing / batch counters (recorded on the first step)
 
   # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
   @torch.no_grad()
@@ -163,20 +164,23 @@ class OnlineAdapter(object):
     self.feature_net.train(); self.stereo_net.train()
     self.arena.rebind_grads()
     self.arena.zero_grads()
+    self.plan.begin()
+    try:
+      fl, fr = self.feature_net(left), self.feature_net(right)
+      out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+      pred = out["pred_disp_l/{}".format(self.scale)]
+      warped, mask = self.warper(right, pred, right_to_left=True)
+      total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+      fcs_map = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
 
-    fl, fr = self.feature_net(left), self.feature_net(right)
-    out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
-    pred = out["pred_disp_l/{}".format(self.scale)]
-    warped, mask = self.warper(right, pred, right_to_left=True)
-    total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
-    fcs_map = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
-
-    if self.world == 1:
-      loss = masked_mean(total, mask)
-      fcs = fcs_map.mean()
-      loss.backward()
-    else:
-      loss, fcs = self._distributed_backward(total, mask, fcs_map, left.shape[0])
+      if self.world == 1:
+        loss = masked_mean(total, mask)
+        fcs = fcs_map.mean()
+        loss.backward()
+      else:
+        loss, fcs = self._distributed_backward(total, mask, fcs_map, left.shape[0])
+    finally:
+      self.plan.end()
 
     self.optimizer.step(clip=self.clip)
     # FCS EMA (adapt.py:356-359), in place so that a captured graph keeps updating the same tensor
@@ -197,21 +201,27 @@ class OnlineAdapter(object):
     if train:
       self.arena.rebind_grads()
       self.arena.zero_grads()
-    with torch.set_grad_enabled(train):
-      fl, fr = self.feature_net(left), self.feature_net(right)
-      out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
-      pred = out["pred_disp_l/{}".format(self.scale)]
-      warped, mask = self.warper(right, pred, right_to_left=True)
-      total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
-      loss = masked_mean(total, mask)
-      backprop = loss
-      replay_loss = None
-      if replay is not None:
-        rl, rr, rgt = replay
-        rfl, rfr = self.feature_net(rl), self.feature_net(rr)
-        rout = self.stereo_net(rl, rfl, rfr, "l", output_cost_volume=True)
-        replay_loss = khamis_robust_loss(rout["pred_disp_l/{}".format(self.scale)], rgt)
-        backprop = loss + er_loss_weight * replay_loss
+    if train:
+      self.plan.begin()
+    try:
+      with torch.set_grad_enabled(train):
+        fl, fr = self.feature_net(left), self.feature_net(right)
+        out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+        pred = out["pred_disp_l/{}".format(self.scale)]
+        warped, mask = self.warper(right, pred, right_to_left=True)
+        total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+        loss = masked_mean(total, mask)
+        backprop = loss
+        replay_loss = None
+        if replay is not None:
+          rl, rr, rgt = replay
+          rfl, rfr = self.feature_net(rl), self.feature_net(rr)
+          rout = self.stereo_net(rl, rfl, rfr, "l", output_cost_volume=True)
+          replay_loss = khamis_robust_loss(rout["pred_disp_l/{}".format(self.scale)], rgt)
+          backprop = loss + er_loss_weight * replay_loss
+    finally:
+      if train:
+        self.plan.end(final=False)
     fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)]).mean()
     if self.world > 1:
       # the OOD gate and the state machine must take the same decision on every rank: gate on the mean
@@ -228,7 +238,11 @@ class OnlineAdapter(object):
 
   def backward_update(self, result):
     """backward + clip + Adam for a result of forward_loss(train=True) (adapt.py:381-394)."""
-    result["backprop_loss"].backward()
+    self.plan.begin(resume=True)  # backward re-packs the (unchanged) weights: one launch
+    try:
+      result["backprop_loss"].backward()
+    finally:
+      self.plan.end()
     if self.world > 1:
       allreduce_gradients(self.arena.grads.div_(self.world), self.pg)
     self.optimizer.step(clip=self.clip)

@@ -110,9 +110,129 @@ POOL = PclPool()
 # ----------------------------------------------------------------------------------------
 def pack_weights(w, shape: ConvShape, transpose_flip: bool):
   w = f32c(w)
+  plan = _ACTIVE_PLAN
+  if plan is not None:
+    hit = plan.packed(w, shape, transpose_flip)
+    if hit is not None:
+      return hit
   packed = _empty(shape.taps() * 1024, w.device)
   call("as_conv32_pack_weights", ptr(w), ptr(packed), shape, int(transpose_flip), stream())
   return packed
+
+
+class StepPlan(object):
+  """Batches a step's many tiny launches.  The first step it sees runs normally and is RECORDED (which weights
+  get packed in which orientation, which BatchNorm layers count a batch, how often); from then on
+    * begin()  packs every recorded weight with ONE kernel (as_conv32_pack_weights_batch) into persistent
+               buffers that pack_weights() hands out, and
+    * end()    bumps all num_batches_tracked counters with ONE add on an int64 arena
+  instead of ~55 + ~23 launches.  Valid only while the weights do not change between begin() and end()
+  (adaptation.OnlineAdapter: they change in the optimizer step, after end()).  Anything not seen while
+  recording falls back to the ordinary per-call path, so a different control flow stays correct."""
+
+  def __init__(self, enabled=True):
+    self.enabled = enabled     # False: begin()/end() do nothing (every call takes the ordinary path)
+    self.ready = False
+    self._rec_pack = {}        # (data_ptr, taps, flip) -> (weight tensor, ConvShape)
+    self._rec_bn = {}          # id(bn module) -> [bn module, count]
+    self._views = {}
+    self._jobs = None
+    self._bn_index = {}
+    self._pending = None
+
+  # -- weights ---------------------------------------------------------------------------------------
+  def packed(self, w, shape, flip):
+    key = (w.data_ptr(), shape.taps(), bool(flip))
+    if not self.ready:
+      self._rec_pack[key] = (w, shape)
+      return None
+    return self._views.get(key)
+
+  # -- batch counters --------------------------------------------------------------------------------
+  def count(self, bn):
+    """Returns True when the plan takes care of this layer's counter."""
+    if not self.ready:
+      self._rec_bn.setdefault(id(bn), [bn, 0])[1] += 1
+      return False
+    i = self._bn_index.get(id(bn))
+    if i is None:
+      return False
+    self._pending[i] += 1
+    return True
+
+  def begin(self, resume=False):
+    """``resume=True``: the backward section of a step whose forward section ended with end(final=False)."""
+    global _ACTIVE_PLAN
+    if not self.enabled:
+      return
+    _ACTIVE_PLAN = self
+    if not self.ready and not resume:
+      for rec in self._rec_bn.values():
+        rec[1] = 0               # counts are per step: an earlier forward-only recording does not add up
+    if self.ready:
+      if self._jobs is not None:
+        call("as_conv32_pack_weights_batch", ptr(self._jobs), self._njobs, self._max_taps, stream())
+      self._pending = [0] * len(self._bn_index)
+
+  def end(self, final=True):
+    """``final=False``: a forward-only section ends, the recording (if any) goes on into the backward section."""
+    global _ACTIVE_PLAN
+    if not self.enabled:
+      return
+    _ACTIVE_PLAN = None
+    if not self.ready:
+      if final:
+        self._build()
+      else:
+        self._flush_recorded_counts()
+      return
+    if self._pending and any(self._pending):
+      if self._pending == self._inc_host:
+        self._nbt.add_(self._inc)
+      else:
+        self._nbt.add_(torch.tensor(self._pending, dtype=torch.int64).to(self._nbt.device))
+    self._pending = None
+
+  def _flush_recorded_counts(self):
+    pass   # while recording, count_batch() already bumped the counters the ordinary way
+
+  def _build(self):
+    import struct
+    if self._rec_pack:
+      dev = next(iter(self._rec_pack.values()))[0].device
+      total = sum(k[1] * 1024 for k in self._rec_pack)
+      self._buf = torch.empty(total, dtype=torch.float32, device=dev)
+      blob, off = b"", 0
+      for key, (w, shape) in self._rec_pack.items():
+        view = self._buf[off:off + key[1] * 1024]
+        self._views[key] = view
+        blob += struct.pack("<QQii", w.data_ptr(), view.data_ptr(), key[1], int(key[2]))
+        off += key[1] * 1024
+      self._weights = [w for w, _ in self._rec_pack.values()]     # keep the storages alive
+      self._jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+      self._njobs = len(self._rec_pack)
+      self._max_taps = max(k[1] for k in self._rec_pack)
+    if self._rec_bn:
+      mods = [m for m, _ in self._rec_bn.values()]
+      dev = mods[0].num_batches_tracked.device
+      self._nbt = torch.stack([m.num_batches_tracked.to(torch.int64).reshape(()) for m in mods]).to(dev)
+      for i, m in enumerate(mods):
+        m._buffers["num_batches_tracked"] = self._nbt[i]           # same state_dict key, now an arena view
+        self._bn_index[id(m)] = i
+      self._inc_host = [c for _, c in self._rec_bn.values()]
+      self._inc = torch.tensor(self._inc_host, dtype=torch.int64).to(dev)
+    self.ready = True
+
+
+_ACTIVE_PLAN = None
+
+
+def count_batch(bn):
+  """``bn.num_batches_tracked += 1`` (nn.BatchNorm in training mode), batched when a StepPlan is active."""
+  plan = _ACTIVE_PLAN
+  if plan is not None and plan.count(bn):
+    return
+  bn.num_batches_tracked += 1
 
 
 def conv32(x, gin: Pcl, packed_w, bias, gout: Pcl, shape: ConvShape, out=None, epilogue=0, scale=None,

@@ -68,7 +68,7 @@ def _block_params(blocks):
 
 def _count_batches(blocks):
   for cb in blocks:
-    cb.bn.num_batches_tracked += 1
+    hip_ops.count_batch(cb.bn)
 
 
 class FeatureExtractorNetwork(nn.Module):
@@ -155,7 +155,7 @@ class StereoNet(nn.Module):
         *params)
     if self.training:
       for f in self.filter:
-        f[0].bn.num_batches_tracked += 1
+        hip_ops.count_batch(f[0].bn)
 
     # By-products of the fused soft-argmax kernel; feature_contrast_mean() picks the FCS up
     # from the logits tensor instead of sorting the volume again.

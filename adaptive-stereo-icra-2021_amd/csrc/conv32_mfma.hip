@@ -405,6 +405,27 @@ extern "C" int as_conv32_pack_weights(const float* w, float* packed, const as_co
   return AS_OK;
 }
 
+// All of a step's weight packings in ONE launch: the job table lives in device memory (the weights sit in a
+// flat arena and the packed buffers are persistent, so the table is built once).
+__global__ void pack_weights_batch_kernel(const as_pack_job* __restrict__ jobs) {
+  const as_pack_job job = jobs[blockIdx.y];
+  const int T = job.taps;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * 1024) return;
+  const int e = idx & 3, j = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, t = idx >> 10;
+  const int k = 16 * h + 4 * q + e;
+  job.packed[idx] = job.transpose_flip ? job.w[((long)k * 32 + j) * T + (T - 1 - t)] : job.w[((long)j * 32 + k) * T + t];
+}
+
+extern "C" int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, int max_taps, void* stream) {
+  AS_CHECK_ARG(jobs && njobs >= 1 && njobs <= 65535, "as_conv32_pack_weights_batch: bad job table");
+  AS_CHECK_ARG(max_taps >= 1 && max_taps <= AS_MAX_TAPS, "as_conv32_pack_weights_batch: %d taps unsupported", max_taps);
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(as_div_up(max_taps * 1024, 256), njobs), dim3(256), 0,
+                     (hipStream_t)stream, jobs);
+  AS_CHECK_LAUNCH("as_conv32_pack_weights_batch");
+  return AS_OK;
+}
+
 extern "C" int as_conv32_num_blocks(const as_pcl* gout) {
   if (!as_pcl_ok(gout)) return AS_ERR_ARG;
   const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;

@@ -168,23 +168,26 @@ __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
 }
 
 // dW[co][c][t] = sum_chunks partial[chunk][k>>5][k&31][co], k = 4t + c
+// 32 lanes per output element: lane q sums chunks q, q+32, ..., then a fixed-order butterfly (deterministic).
 __global__ void conv4_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
                                           int nchunks, int NB, int T, int Cin, float* __restrict__ dW,
                                           float* __restrict__ db, int accumulate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int q = threadIdx.x & 31;
   const int total = 32 * Cin * T;
+  float s = 0.f;
   if (idx < total) {
     const int t = idx % T, c = (idx / T) % Cin, co = idx / (T * Cin);
     const int k = 4 * t + c;
-    float s = 0.f;
-    for (int ch = 0; ch < nchunks; ++ch) s += partial[(((long)ch * NB + (k >> 5)) * 32 + (k & 31)) * 32 + co];
-    dW[idx] = accumulate ? dW[idx] + s : s;
+    for (int ch = q; ch < nchunks; ch += 32) s += partial[(((long)ch * NB + (k >> 5)) * 32 + (k & 31)) * 32 + co];
   } else if (db != nullptr && idx < total + 32) {
-    const int o = idx - total;
-    float s = 0.f;
-    for (int ch = 0; ch < nchunks; ++ch) s += partial_db[ch * 32 + o];
-    db[o] = accumulate ? db[o] + s : s;
+    for (int ch = q; ch < nchunks; ch += 32) s += partial_db[ch * 32 + (idx - total)];
   }
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 32);
+  if (q != 0) return;
+  if (idx < total) dW[idx] = accumulate ? dW[idx] + s : s;
+  else if (db != nullptr && idx < total + 32) db[idx - total] = accumulate ? db[idx - total] + s : s;
 }
 
 // ---- host -------------------------------------------------------------------------------------------------
@@ -303,7 +306,7 @@ extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* g
   }
   AS_CHECK_LAUNCH("as_conv4_wgrad");
   const int T = a.ntaps;
-  hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up(32 * Cin * T + 32, 256)), dim3(256), 0, st, a.partial,
+  hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up((32 * Cin * T + 32) * 32, 256)), dim3(256), 0, st, a.partial,
                      a.partial_db, nchunks, nb, T, Cin, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv4_wgrad(reduce)");
   return AS_OK;

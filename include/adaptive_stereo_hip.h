@@ -81,6 +81,16 @@ int as_cost_volume_bwd(const float* gvol, float* gL, float* gR, const as_pcl* g,
  *   skip one "grad += dW" launch per parameter tensor). */
 int as_conv32_pack_weights(const float* w, float* packed, const as_conv_shape* s,
                            int transpose_flip, void* stream);
+
+/* One launch for many packings (every 32->32 convolution weight of a step, both orientations).
+ * `jobs` is a DEVICE array; each job is one as_conv32_pack_weights call (taps = kd*kh*kw <= max_taps). */
+typedef struct as_pack_job {
+  const float* w;
+  float* packed;
+  int32_t taps;
+  int32_t transpose_flip;
+} as_pack_job;
+int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, int max_taps, void* stream);
 int as_conv32_num_blocks(const as_pcl* gout);
 int as_conv32_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, const float* bias,

@@ -256,3 +256,40 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
   assert float(g0.abs().max()) > 0
   assert torch.equal(g0, g1), float((g0 - g1).abs().max())
   assert torch.equal(p0, p1)
+
+
+def test_step_plan_equals_per_call_launches():
+  """The StepPlan (one batched weight-packing launch, one add for all num_batches_tracked) must leave exactly
+  the state the ordinary per-call path leaves — over the recorded first step and the planned ones after it,
+  for the fused step and for the split forward_loss / backward_update step of the control plane."""
+  from adaptive_stereo import hip_ops
+  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
+  H, W, B = 96, 256, 2
+  batches = [syn.stereo_pair(B, H, W, seed=s) for s in (21, 22, 23, 24)]
+  batches = [(l.to(DEV), r.to(DEV)) for l, r in batches]
+  results = []
+  for enabled in (False, True):
+    fnet, snet = build(meta)
+    adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+    adapter.plan = hip_ops.StepPlan(enabled=enabled)
+    losses = []
+    for i, (l, r) in enumerate(batches):
+      if i % 2 == 0:
+        losses.append(float(adapter.step(l, r)["loss"]))
+      else:
+        res = adapter.forward_loss(l, r, train=True)
+        adapter.backward_update(res)
+        losses.append(float(res["loss"]))
+    torch.cuda.synchronize()
+    assert adapter.plan.ready == enabled
+    sd = {k: v.clone() for k, v in list(fnet.state_dict().items()) + list(snet.state_dict().items())
+          if k.endswith("num_batches_tracked")}
+    results.append((losses, adapter.arena.params.clone(), sd))
+  (l0, p0, n0), (l1, p1, n1) = results
+  assert l0 == l1, (l0, l1)
+  assert torch.equal(p0, p1)
+  assert n0.keys() == n1.keys() and len(n0) > 0
+  for k in n0:
+    assert int(n0[k]) == int(n1[k]), k
+  # stereo_net layers: 4 steps; feature_net layers: two images per step; BasicBlock.conv2 (never run): 0
+  assert {int(v) for v in n0.values()} == {0, 4, 8}
