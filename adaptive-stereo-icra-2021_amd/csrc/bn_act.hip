@@ -89,30 +89,75 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
   shift[c] = beta[c] - rm[c] * sc;
 }
 
+// ---- element-wise passes: row chunks ---------------------------------------------------
+// The PCL interior is B*D*H contiguous rows of W voxels (128 B each).  A workgroup takes "row chunks" of 128
+// voxels = 1024 float4: thread t owns float4 t, t+256, t+512, t+768 of the chunk (always channel group t&7),
+// so one scalar decode per chunk replaces a 64-bit div/mod per element and every thread has four
+// independent 16-byte loads per tensor in flight.
+#define BN_CHUNK_VOX 128
+struct RowChunk { long base; int nf4; };     // float offset of the chunk's first voxel; valid float4 count
+
+__device__ inline RowChunk row_chunk(const PclDev& g, int chunk, int chunks_per_row) {
+  const int rowi = chunk / chunks_per_row, cx = chunk - rowi * chunks_per_row;
+  const int y = rowi % g.H, t = rowi / g.H;
+  const int d = t % g.D, b = t / g.D;
+  const int x0 = cx * BN_CHUNK_VOX;
+  RowChunk rc;
+  rc.base = g.vox(b, d, y, x0) * 32;
+  rc.nf4 = min(BN_CHUNK_VOX, g.W - x0) * 8;
+  return rc;
+}
+
+// Traversal that follows a conv32 LDS producer back to front.  That kernel walks its row segments (the same
+// 128-voxel chunks, same numbering) in 8 contiguous bands, one per XCD, all bands advancing together; what
+// it wrote last — the tail of every band — is what L2 and the memory-side cache still hold when the consumer
+// starts.  Position p of the consumer's schedule -> chunk (band p&7, p>>3 from that band's end).
+__device__ inline int band_tail_order(int p, int nchunks) {
+  const int tpb = (nchunks + 7) >> 3;
+  const int ch = (p & 7) * tpb + (tpb - 1 - (p >> 3));
+  return ch;        // may be >= nchunks in the last band (caller skips)
+}
+
+__device__ inline f32x4 lrelu4(f32x4 y, f32x4 v, float slope) {   // v where y > 0, v*slope elsewhere
+  f32x4 r;
+  r.x = y.x > 0.f ? v.x : v.x * slope; r.y = y.y > 0.f ? v.y : v.y * slope;
+  r.z = y.z > 0.f ? v.z : v.z * slope; r.w = y.w > 0.f ? v.w : v.w * slope;
+  return r;
+}
+
 // ---- a = lrelu(z*scale + shift) (+ residual), interior only -------------------------
+template <bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, float slope,
                                                           const float* __restrict__ residual, float* __restrict__ a,
-                                                          PclDev g, long M) {
+                                                          PclDev g, int nchunks, int chunks_per_row) {
   const int c4 = threadIdx.x & 7;
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
-  const long stride = (long)gridDim.x * 32;
-  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < M; v += stride) {
-    long t = v;
-    const int x = t % g.W; t /= g.W;
-    const int y = t % g.H; t /= g.H;
-    const int d = t % g.D;
-    const int b = t / g.D;
-    const long off = g.vox(b, d, y, x) * 32 + c4 * 4;
-    f32x4 q = *reinterpret_cast<const f32x4*>(z + off);
-    q = q * sc + sh;
-    q.x = q.x > 0.f ? q.x : q.x * slope;
-    q.y = q.y > 0.f ? q.y : q.y * slope;
-    q.z = q.z > 0.f ? q.z : q.z * slope;
-    q.w = q.w > 0.f ? q.w : q.w * slope;
-    if (residual) q += *reinterpret_cast<const f32x4*>(residual + off);
-    *reinterpret_cast<f32x4*>(a + off) = q;
+  const int npos = ((nchunks + 7) >> 3) << 3;
+  for (int p = blockIdx.x; p < npos; p += gridDim.x) {
+    const int ch = band_tail_order(p, nchunks);
+    if (ch >= nchunks) continue;
+    const RowChunk rc = row_chunk(g, ch, chunks_per_row);
+    f32x4 q[4], r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = threadIdx.x + 256 * k;
+      if (f < rc.nf4) {
+        q[k] = *reinterpret_cast<const f32x4*>(z + rc.base + f * 4);
+        if (RES) r[k] = *reinterpret_cast<const f32x4*>(residual + rc.base + f * 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = threadIdx.x + 256 * k;
+      if (f < rc.nf4) {
+        f32x4 y = q[k] * sc + sh;
+        y = lrelu4(y, y, slope);
+        if (RES) y += r[k];
+        *reinterpret_cast<f32x4*>(a + rc.base + f * 4) = y;
+      }
+    }
   }
 }
 
@@ -122,30 +167,37 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g_a, const float* __restrict__ z,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, float slope,
-                                                             double* __restrict__ partial, PclDev g, long M) {
+                                                             double* __restrict__ partial, PclDev g, int nchunks,
+                                                             int chunks_per_row) {
   __shared__ double red[2][32][33];
   const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
   const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
   f32x4 s_dy = {0.f, 0.f, 0.f, 0.f}, s_dx = {0.f, 0.f, 0.f, 0.f};
-  const long stride = (long)gridDim.x * 32;
-  for (long v = (long)blockIdx.x * 32 + vl; v < M; v += stride) {
-    long t = v;
-    const int x = t % g.W; t /= g.W;
-    const int y = t % g.H; t /= g.H;
-    const int d = t % g.D;
-    const int b = t / g.D;
-    const long off = g.vox(b, d, y, x) * 32 + c4 * 4;
-    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + off);
-    f32x4 gy = *reinterpret_cast<const f32x4*>(g_a + off);
-    const f32x4 yy = zz * sc + sh;
-    gy.x = yy.x > 0.f ? gy.x : gy.x * slope;
-    gy.y = yy.y > 0.f ? gy.y : gy.y * slope;
-    gy.z = yy.z > 0.f ? gy.z : gy.z * slope;
-    gy.w = yy.w > 0.f ? gy.w : gy.w * slope;
-    s_dy += gy;
-    s_dx += gy * (zz - mu);
+  const int npos = ((nchunks + 7) >> 3) << 3;
+  for (int p = blockIdx.x; p < npos; p += gridDim.x) {
+    const int ch = band_tail_order(p, nchunks);      // g_a comes straight from the data-gradient convolution
+    if (ch >= nchunks) continue;
+    const RowChunk rc = row_chunk(g, ch, chunks_per_row);
+    f32x4 zz[4], gy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = threadIdx.x + 256 * k;
+      if (f < rc.nf4) {
+        zz[k] = *reinterpret_cast<const f32x4*>(z + rc.base + f * 4);
+        gy[k] = *reinterpret_cast<const f32x4*>(g_a + rc.base + f * 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = threadIdx.x + 256 * k;
+      if (f < rc.nf4) {
+        const f32x4 gg = lrelu4(zz[k] * sc + sh, gy[k], slope);
+        s_dy += gg;
+        s_dx += gg * (zz[k] - mu);
+      }
+    }
   }
   for (int i = 0; i < 4; ++i) {
     red[0][vl][c4 * 4 + i] = (double)s_dy[i];
@@ -189,7 +241,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g_a, const float* __restrict__ z,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ coef,
-                                                            float slope, float* __restrict__ g_z, PclDev g, long M) {
+                                                            float slope, float* __restrict__ g_z, PclDev g, int nchunks,
+                                                            int chunks_per_row) {
   const int c4 = threadIdx.x & 7;
   const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
   const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
@@ -197,31 +250,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + c4 * 4);
   const f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + 32 + c4 * 4);
   const f32x4 k3 = *reinterpret_cast<const f32x4*>(coef + 64 + c4 * 4);
-  const long stride = (long)gridDim.x * 32;
-  for (long v = (long)blockIdx.x * 32 + (threadIdx.x >> 3); v < M; v += stride) {
-    long t = v;
-    const int x = t % g.W; t /= g.W;
-    const int y = t % g.H; t /= g.H;
-    const int d = t % g.D;
-    const int b = t / g.D;
-    const long off = g.vox(b, d, y, x) * 32 + c4 * 4;
-    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + off);
-    f32x4 gy = *reinterpret_cast<const f32x4*>(g_a + off);
-    const f32x4 yy = zz * sc + sh;
-    gy.x = yy.x > 0.f ? gy.x : gy.x * slope;
-    gy.y = yy.y > 0.f ? gy.y : gy.y * slope;
-    gy.z = yy.z > 0.f ? gy.z : gy.z * slope;
-    gy.w = yy.w > 0.f ? gy.w : gy.w * slope;
-    const f32x4 dx = (zz - mu) * k2;
-    *reinterpret_cast<f32x4*>(g_z + off) = (gy - k1 - dx) * k3;
+  const int npos = ((nchunks + 7) >> 3) << 3;
+  for (int p = blockIdx.x; p < npos; p += gridDim.x) {
+    // stage 1's schedule, last position first: what it streamed last is still cached
+    const int ch = band_tail_order(npos - 1 - p, nchunks);
+    if (ch >= nchunks) continue;
+    const RowChunk rc = row_chunk(g, ch, chunks_per_row);
+    f32x4 zz[4], gy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = threadIdx.x + 256 * k;
+      if (f < rc.nf4) {
+        zz[k] = *reinterpret_cast<const f32x4*>(z + rc.base + f * 4);
+        gy[k] = *reinterpret_cast<const f32x4*>(g_a + rc.base + f * 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = threadIdx.x + 256 * k;
+      if (f < rc.nf4) {
+        const f32x4 gg = lrelu4(zz[k] * sc + sh, gy[k], slope);
+        const f32x4 dx = (zz[k] - mu) * k2;
+        *reinterpret_cast<f32x4*>(g_z + rc.base + f * 4) = (gg - k1 - dx) * k3;
+      }
+    }
   }
 }
 
 // ---- host ------------------------------------------------------------------------------
-static inline int elementwise_blocks(long M) {
-  long nb = (M + 31) / 32;
-  if (nb > 4096) nb = 4096;   // grid-stride beyond ~16 workgroups per CU
-  return (int)nb;
+static inline int chunks_per_row(const as_pcl* g) { return (g->W + BN_CHUNK_VOX - 1) / BN_CHUNK_VOX; }
+static inline long row_chunks(const as_pcl* g) { return (long)g->B * g->D * g->H * chunks_per_row(g); }
+static inline int elementwise_blocks(long nchunks) {
+  return (int)(nchunks > 16384 ? 16384 : nchunks);   // grid-stride beyond 64 workgroups per CU
 }
 
 extern "C" int as_bn_finalize(const float* stat_mean, const float* stat_m2, const float* stat_cnt, int nparts,
@@ -254,15 +314,20 @@ extern "C" int as_bn_act_fwd(const float* z, const float* scale, const float* sh
                              const float* residual, float* a, const as_pcl* g, void* stream) {
   AS_CHECK_ARG(as_pcl_ok(g), "as_bn_act_fwd: bad geometry");
   AS_CHECK_ARG(z && scale && shift && a, "as_bn_act_fwd: null pointer");
-  const long M = (long)g->B * g->D * g->H * g->W;
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(elementwise_blocks(M)), dim3(256), 0, (hipStream_t)stream, z, scale,
-                     shift, slope, residual, a, as_make_dev(g), M);
+  const long nch = row_chunks(g);
+  AS_CHECK_ARG(nch < (1L << 31), "as_bn_act_fwd: volume too large");
+  if (residual)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elementwise_blocks(nch)), dim3(256), 0, (hipStream_t)stream, z,
+                       scale, shift, slope, residual, a, as_make_dev(g), (int)nch, chunks_per_row(g));
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elementwise_blocks(nch)), dim3(256), 0, (hipStream_t)stream, z,
+                       scale, shift, slope, residual, a, as_make_dev(g), (int)nch, chunks_per_row(g));
   AS_CHECK_LAUNCH("as_bn_act_fwd");
   return AS_OK;
 }
 
-static int bnb_blocks(long M) {
-  long nb = (M + 2047) / 2048;      // ~64 voxels per thread-row
+static int bnb_blocks(long nchunks) {
+  long nb = (nchunks + 3) / 4;      // at least four row chunks (512 voxels) per workgroup
   if (nb > BNB_BLOCKS) nb = BNB_BLOCKS;
   if (nb < 1) nb = 1;
   return (int)nb;
@@ -283,19 +348,21 @@ extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scal
                "as_bn_act_bwd: null pointer");
   AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_bn_act_bwd: workspace must be 8-byte aligned");
   const long M = (long)g->B * g->D * g->H * g->W;
-  const int nb = bnb_blocks(M);
+  const long nch = row_chunks(g);
+  AS_CHECK_ARG(nch < (1L << 31), "as_bn_act_bwd: volume too large");
+  const int nb = bnb_blocks(nch), cpr = chunks_per_row(g);
   double* partial = reinterpret_cast<double*>(workspace);
   float* coef = workspace + (int64_t)BNB_BLOCKS * 128;
   hipStream_t st = (hipStream_t)stream;
   const PclDev gd = as_make_dev(g);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g_a, z, scale, shift, save_mean, slope,
-                     partial, gd, M);
+                     partial, gd, (int)nch, cpr);
   AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nb, M, save_invstd, gamma, train,
                      g_gamma, g_beta, coef, accumulate);
   AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(M)), dim3(256), 0, st, g_a, z, scale, shift,
-                     save_mean, coef, slope, g_z, gd, M);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(nch)), dim3(256), 0, st, g_a, z, scale, shift,
+                     save_mean, coef, slope, g_z, gd, (int)nch, cpr);
   AS_CHECK_LAUNCH("as_bn_act_bwd(apply)");
   return AS_OK;
 }
