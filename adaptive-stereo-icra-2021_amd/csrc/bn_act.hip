@@ -316,12 +316,14 @@ extern "C" int as_bn_act_fwd(const float* z, const float* scale, const float* sh
   AS_CHECK_ARG(z && scale && shift && a, "as_bn_act_fwd: null pointer");
   const long nch = row_chunks(g);
   AS_CHECK_ARG(nch < (1L << 31), "as_bn_act_fwd: volume too large");
+  as_prof_mark(4, (hipStream_t)stream, 1, 0.0);
   if (residual)
     hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elementwise_blocks(nch)), dim3(256), 0, (hipStream_t)stream, z,
                        scale, shift, slope, residual, a, as_make_dev(g), (int)nch, chunks_per_row(g));
   else
     hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elementwise_blocks(nch)), dim3(256), 0, (hipStream_t)stream, z,
                        scale, shift, slope, residual, a, as_make_dev(g), (int)nch, chunks_per_row(g));
+  as_prof_mark(4, (hipStream_t)stream, 0, (residual ? 3.0 : 2.0) * 128.0 * (double)g->B * g->D * g->H * g->W);
   AS_CHECK_LAUNCH("as_bn_act_fwd");
   return AS_OK;
 }
@@ -355,6 +357,7 @@ extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scal
   float* coef = workspace + (int64_t)BNB_BLOCKS * 128;
   hipStream_t st = (hipStream_t)stream;
   const PclDev gd = as_make_dev(g);
+  as_prof_mark(5, st, 1, 0.0);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g_a, z, scale, shift, save_mean, slope,
                      partial, gd, (int)nch, cpr);
   AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
@@ -363,6 +366,7 @@ extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scal
   AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(nch)), dim3(256), 0, st, g_a, z, scale, shift,
                      save_mean, coef, slope, g_z, gd, (int)nch, cpr);
+  as_prof_mark(5, st, 0, 5.0 * 128.0 * (double)M);
   AS_CHECK_LAUNCH("as_bn_act_bwd(apply)");
   return AS_OK;
 }

@@ -164,7 +164,7 @@ def main():
   if not use_graph:
     t_adapt = min(t_adapt, t_adapt_eager)
   prof = []
-  for kid in (0, 1, 2, 3):
+  for kid in (0, 1, 2, 3, 4, 5):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     nat.call("as_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
     prof.append((n.value, ms.value, fl.value))
@@ -196,19 +196,36 @@ def main():
   dom = entry(2, "conv32_lds_kernel")
   roofline = None
   if dom is not None:
-    traffic = None
+    # HBM bytes per launch from the committed PMC passes (profiles/pmc_conv32_lds.json; FETCH_SIZE / WRITE_SIZE
+    # corrected as MI355X_MICROARCH.md prescribes).  A step launches the kernel as 6 training forwards
+    # (<0,false>: read x, write z) and 6 data gradients with the skip connection (<2,true>: + read residual):
+    # `traffic` is the mean over that mix, like `achieved`.
+    traffic, traffic_detail = None, None
     pmc = os.path.join(REPO, "profiles", "pmc_conv32_lds.json")
     if os.path.exists(pmc):
       rec = json.load(open(pmc))
-      if rec.get("pairs_per_launch") == B:
-        traffic = rec.get("hbm_bytes_per_launch")
+      ks = rec.get("kernels", {})
+      if rec.get("pairs_per_launch") == B and "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<2, true>" in ks:
+        a, b = ks["conv32_lds_kernel<0, false>"], ks["conv32_lds_kernel<2, true>"]
+        traffic = int((a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"]) / 2)
+        traffic_detail = {"forward": {"hbm_bytes": a["hbm_bytes_per_launch"], "algorithmic_bytes": a["algorithmic_bytes_per_launch"]},
+                          "dgrad_with_skip": {"hbm_bytes": b["hbm_bytes_per_launch"], "algorithmic_bytes": b["algorithmic_bytes_per_launch"]}}
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
-                "flops_per_launch": dom["flops_per_launch"],
+                "flops_per_launch": dom["flops_per_launch"], "traffic_detail": traffic_detail,
                 "other_mfma_kernels": [e for e in (entry(3, "conv32_wgrad_lds_kernel"),
                                                    entry(0, "conv32_fwd_kernel<taps> (3-D, strided, small 2-D)"),
                                                    entry(1, "conv32_wgrad_kernel<taps>")) if e is not None]}
+    # the HBM-bound passes of the step, against the 8 TB/s HBM3E peak (algorithmic bytes / HIP-event time)
+    def hbm_entry(i, name):
+      n, ms, by = prof[i]
+      if n == 0 or ms <= 0:
+        return None
+      return {"kernel": name, "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+              "frac": round(by / (ms * 1e-3) / 8e12, 4), "launches": n, "avg_launch_us": round(1e3 * ms / n, 2)}
+    roofline["hbm_bound_kernels"] = [e for e in (hbm_entry(4, "bn_act_fwd_kernel"),
+                                                 hbm_entry(5, "bn_bwd_reduce + finalize + apply")) if e is not None]
 
   out = {
     "metric": "stereo pairs/sec (fwd+adapt-step), KITTI 1242x375 D=192",

@@ -245,6 +245,8 @@ int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * launch stream and account its algorithmic FLOPs (2 * voxels * 32 * 32 * taps).  Kernel ids:
  * 0 conv32_fwd_kernel<taps> (direct-load forward/dgrad), 1 conv32_wgrad_kernel<..> (direct-load wgrad),
  * 2 conv32_lds_kernel (LDS-staged 3x3 forward/dgrad), 3 conv32_wgrad_lds_kernel.
+ * HBM-bound passes account algorithmic BYTES in the same slot: 4 as_bn_act_fwd (2 or 3 tensors x interior
+ * bytes), 5 as_bn_act_bwd (its three kernels together: 5 tensor passes).
  * as_prof_read synchronises on the recorded events.
  * Disabled by default; must stay disabled under hipGraph capture. */
 int as_prof_enable(int on);

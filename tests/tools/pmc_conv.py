@@ -18,8 +18,11 @@ z = torch.zeros(g.numel(), device=dev)
 stats = ops.conv32_stat_parts(g, g, shape, dev)
 ws = torch.empty(nat.load().as_conv32_wgrad_workspace(g, g, shape), device=dev)
 dW = torch.empty_like(w); db = torch.empty(32, device=dev)
+wpt = ops.pack_weights(w, shape, True)
+gx = torch.zeros(g.numel(), device=dev)
 for _ in range(5):
-  ops.conv32(x, g, wp, b, g, shape, out=z, stats=stats)
+  ops.conv32(x, g, wp, b, g, shape, out=z, stats=stats)              # conv32_lds_kernel<0,false>: training forward
+  ops.conv32(z, g, wpt, None, g, shape, out=gx, residual=x)           # conv32_lds_kernel<2,true>: data gradient + skip
   nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(z), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
 torch.cuda.synchronize()
 print("done")
