@@ -107,7 +107,7 @@ def test_adaptation_loop_on_gpu_nonstop_equals_plain_steps_and_er_adds_replay_gr
   fl2, fr2 = orc.feature_extractor(fp, left[1:], K, True), orc.feature_extractor(fp, right[1:], K, True)
   out2 = orc.stereo_forward(sp, left[1:], fl2, fr2, K, 0, MAXDISP, "l", True, True)
   rep = orc.khamis_robust_loss(out2["pred_disp_l/0"], gt)
-  assert abs(float(res["loss"]) - float(mono)) < 2e-5
+  assert abs(float(res["loss"].detach()) - float(mono.detach())) < 2e-5
   assert abs(float(res["replay_loss"]) - float(rep)) < 1e-3 * max(1.0, float(rep))
   (mono + 0.05 * rep).backward()
   gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sp.values() if p.requires_grad and p.grad is not None))
