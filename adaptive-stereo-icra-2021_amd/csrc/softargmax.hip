@@ -188,6 +188,206 @@ __global__ __launch_bounds__(256) void conv32to1_wgrad_reduce_kernel(const float
   else { const int t = idx >> 5, c = idx & 31; if (g_w) g_w[c * NT + t] = accumulate ? g_w[c * NT + t] + (float)s : (float)s; }
 }
 
+// =====================================================================================================
+// 2-D 3x3 (dilation 1) fast paths of the thin convolutions: the refinement's output layer and the data
+// gradient of its 4->32 input layer run on full-resolution maps (238 MB per tensor at 4 pairs), where the
+// generic kernels above spend their time on per-voxel 64-bit index arithmetic and on re-reading every
+// 128-byte activation line once per tap through L1.
+//
+// Forward (32->1): "project, then gather".  out[v] = sum_t sum_c a[v+off_t][c] w[c][t], so every input voxel
+// u is read ONCE and projected onto the nine taps, P_t[u] = sum_c a[u][c] w[c][t] (288 FMAs, one lane per
+// voxel: no cross-lane reduction), the nine planes of a 16x32 voxel patch go to LDS, and each output of the
+// patch's 14x30 interior sums nine scalars.  HBM/L2 reads: 1.22x the activation (patch halo), L1: once.
+#define TC_PR 16                 // patch rows (with the one-voxel halo)
+#define TC_PC 32                 // patch columns
+#define TC_OR (TC_PR - 2)
+#define TC_OC (TC_PC - 2)
+
+struct Thin2dFwdArgs {
+  const float* a;        // PCL
+  const float* w;        // [32][9]
+  const float* bias;     // [1] or null
+  const float* add_src;  // dense [B][H][W] or null
+  float* out;            // dense [B][H][W]
+  int relu;
+  PclDev g;
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void conv32to1_2d_fwd_kernel(Thin2dFwdArgs p) {
+  __shared__ float sp[9][TC_PR][TC_PC + 1];
+  __shared__ float sw[32 * 9];
+  for (int i = threadIdx.x; i < 288; i += 256) sw[i] = p.w[i];
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+  const int y0 = ty * TC_OR, x0 = tx * TC_OC;          // first output of the patch
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int idx = threadIdx.x + 256 * pass;
+    const int r = idx >> 5, c = idx & 31;
+    const int yi = y0 - 1 + r, xi = x0 - 1 + c;         // image coordinates of the staged voxel (-1 .. H, -1 .. W)
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    if (yi <= p.g.H && xi <= p.g.W) {                   // inside the PCL (halo row/column H, W included); others unused
+      const float* src = p.a + (((long)b * p.g.Hp + (yi + p.g.ph)) * p.g.Wp + (xi + p.g.pw)) * 32;
+      f32x4 q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          acc[k] = fmaf(q[j].x, sw[(4 * j + 0) * 9 + k], acc[k]);
+          acc[k] = fmaf(q[j].y, sw[(4 * j + 1) * 9 + k], acc[k]);
+          acc[k] = fmaf(q[j].z, sw[(4 * j + 2) * 9 + k], acc[k]);
+          acc[k] = fmaf(q[j].w, sw[(4 * j + 3) * 9 + k], acc[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sp[k][r][c] = acc[k];
+  }
+  __syncthreads();
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  for (int o = threadIdx.x; o < TC_OR * TC_OC; o += 256) {
+    const int ry = o / TC_OC, cx = o - ry * TC_OC;
+    const int y = y0 + ry, x = x0 + cx;
+    if (y >= p.g.H || x >= p.g.W) continue;
+    float s = bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) s += sp[ky * 3 + kx][ry + ky][cx + kx];
+    const long v = ((long)b * p.g.H + y) * p.g.W + x;
+    if (p.add_src) s += p.add_src[v];
+    if (p.relu) s = s > 0.f ? s : 0.f;
+    p.out[v] = s;
+  }
+}
+
+// Backward of the same layer over 128-voxel row chunks (thread t owns float4 t, t+256, .. of the chunk: always
+// channel group t&7), with the three rows of the 1-channel gradient map that a chunk needs staged in LDS
+// (zero outside the image): no per-voxel index arithmetic, no bounds tests in the tap loops.
+struct Thin2dBwdArgs {
+  const float* g_out;    // dense [B][H][W]
+  const float* a;        // PCL (wgrad)
+  const float* w;        // [32][9] (dgrad)
+  float* g_a;            // PCL (dgrad)
+  float* partial;        // [blocks][289] (wgrad)
+  PclDev g;
+  int nchunks, chunks_per_row;
+};
+
+__device__ inline void thin_stage_g(const Thin2dBwdArgs& p, float (*sg)[132], int b, int y, int x0) {
+  // sg[r][i] = g_out[b][y-1+r][x0-1+i], i = 0..129
+  for (int i = threadIdx.x; i < 3 * 130; i += 256) {
+    const int r = i / 130, c = i - r * 130;
+    const int yy = y - 1 + r, xx = x0 - 1 + c;
+    sg[r][c] = (yy >= 0 && yy < p.g.H && xx >= 0 && xx < p.g.W) ? p.g_out[((long)b * p.g.H + yy) * p.g.W + xx] : 0.f;
+  }
+}
+
+// g_a[v][c] = sum_t g_out[v - off_t] w[c][t]
+__global__ __launch_bounds__(256) void conv32to1_2d_dgrad_kernel(Thin2dBwdArgs p) {
+  __shared__ float sg[3][132];
+  const int c4 = threadIdx.x & 7;
+  f32x4 wv[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+    wv[k] = (f32x4){p.w[(c4 * 4 + 0) * 9 + k], p.w[(c4 * 4 + 1) * 9 + k], p.w[(c4 * 4 + 2) * 9 + k], p.w[(c4 * 4 + 3) * 9 + k]};
+  for (int ch = blockIdx.x; ch < p.nchunks; ch += gridDim.x) {
+    const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
+    const int y = rowi % p.g.H, b = rowi / p.g.H, x0 = cx * 128;
+    const int nf4 = min(128, p.g.W - x0) * 8;
+    __syncthreads();
+    thin_stage_g(p, sg, b, y, x0);
+    __syncthreads();
+    float* dst = p.g_a + (((long)b * p.g.Hp + (y + p.g.ph)) * p.g.Wp + (x0 + p.g.pw)) * 32;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int f = threadIdx.x + 256 * k4;
+      if (f < nf4) {
+        const int vx = f >> 3;                         // voxel within the chunk
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // tap (ky,kx) reaches v from the output voxel v - off = (y - (ky-1), x - (kx-1))
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc += sg[2 - ky][vx + 2 - kx] * wv[ky * 3 + kx];
+        *reinterpret_cast<f32x4*>(dst + f * 4) = acc;
+      }
+    }
+  }
+}
+
+// g_w[c][t] = sum_u a[u][c] g_out[u - off_t];  g_bias = sum g_out.  One partial slab per workgroup.
+__global__ __launch_bounds__(256) void conv32to1_2d_wgrad_kernel(Thin2dBwdArgs p) {
+  __shared__ float sg[3][132];
+  __shared__ float red[32][33];
+  const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
+  f32x4 acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float gsum = 0.f;
+  for (int ch = blockIdx.x; ch < p.nchunks; ch += gridDim.x) {
+    const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
+    const int y = rowi % p.g.H, b = rowi / p.g.H, x0 = cx * 128;
+    const int nf4 = min(128, p.g.W - x0) * 8;
+    __syncthreads();
+    thin_stage_g(p, sg, b, y, x0);
+    __syncthreads();
+    const float* src = p.a + (((long)b * p.g.Hp + (y + p.g.ph)) * p.g.Wp + (x0 + p.g.pw)) * 32;
+    f32x4 a4[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int f = threadIdx.x + 256 * k4;
+      if (f < nf4) a4[k4] = *reinterpret_cast<const f32x4*>(src + f * 4);
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int f = threadIdx.x + 256 * k4;
+      if (f < nf4) {
+        const int vx = f >> 3;
+        if (c4 == 0) gsum += sg[1][vx + 1];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += sg[2 - ky][vx + 2 - kx] * a4[k4];
+      }
+    }
+  }
+  float* out = p.partial + (long)blockIdx.x * (9 * 32 + 1);
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    __syncthreads();
+    red[vl][c4 * 4 + 0] = acc[tp].x; red[vl][c4 * 4 + 1] = acc[tp].y;
+    red[vl][c4 * 4 + 2] = acc[tp].z; red[vl][c4 * 4 + 3] = acc[tp].w;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float s = 0.f;
+      for (int j = 0; j < 32; ++j) s += red[j][threadIdx.x];
+      out[tp * 32 + threadIdx.x] = s;
+    }
+  }
+  __syncthreads();
+  if (c4 == 0) red[vl][0] = gsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < 32; ++j) s += red[j][0];
+    out[9 * 32] = s;
+  }
+}
+
+static bool thin2d_applicable(const as_pcl* g, const as_conv_shape* s) {
+  return g->D == 1 && s->kd == 1 && s->kh == 3 && s->kw == 3 && s->dil == 1 && s->stride == 1 && s->pad_h == 1 &&
+         s->pad_w == 1 && g->ph >= 1 && g->pw >= 1 && (long)g->B * g->H * ((g->W + 127) / 128) < (1L << 31);
+}
+
 // ---- soft-argmax ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softargmax_fwd_kernel(const float* __restrict__ logits, int B, int D, long HW,
                                                               float* __restrict__ pred, int32_t* __restrict__ argmax,
@@ -260,13 +460,21 @@ static inline int out_blocks(long M) {
   if (nb > 4096) nb = 4096;
   return (int)nb;
 }
-#define OUTW_BLOCKS 512
+#define OUTW_BLOCKS 2048
 
 extern "C" int as_conv32to1_fwd(const float* a, const as_pcl* g, const as_conv_shape* s, const float* w,
                                 const float* bias, const float* add_src, int relu, float* out, void* stream) {
   OutConvArgs p;
   if (int e = fill_out_geom(g, s, &p.k, "as_conv32to1_fwd")) return e;
   AS_CHECK_ARG(a && w && out, "as_conv32to1_fwd: null pointer");
+  if (thin2d_applicable(g, s)) {
+    Thin2dFwdArgs q;
+    q.a = a; q.w = w; q.bias = bias; q.add_src = add_src; q.out = out; q.relu = relu; q.g = as_make_dev(g);
+    q.tiles_x = (g->W + TC_OC - 1) / TC_OC; q.tiles_y = (g->H + TC_OR - 1) / TC_OR;
+    hipLaunchKernelGGL(conv32to1_2d_fwd_kernel, dim3(g->B * q.tiles_x * q.tiles_y), dim3(256), 0, (hipStream_t)stream, q);
+    AS_CHECK_LAUNCH("as_conv32to1_fwd(2d)");
+    return AS_OK;
+  }
   p.a = a; p.w = w; p.bias = bias; p.add_src = add_src; p.out = out; p.relu = relu; p.g = as_make_dev(g);
   p.M = (long)g->B * g->D * g->H * g->W;
   hipLaunchKernelGGL(conv32to1_fwd_kernel, dim3(out_blocks(p.M)), dim3(256), 0, (hipStream_t)stream, p);
@@ -288,6 +496,25 @@ extern "C" int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl
   p.g_out = g_out; p.a = a; p.w = w; p.g_a = g_a; p.partial = workspace; p.g = as_make_dev(g);
   p.M = (long)g->B * g->D * g->H * g->W;
   hipStream_t st = (hipStream_t)stream;
+  if (thin2d_applicable(g, s)) {
+    Thin2dBwdArgs q;
+    q.g_out = g_out; q.a = a; q.w = w; q.g_a = g_a; q.partial = workspace; q.g = as_make_dev(g);
+    q.chunks_per_row = (g->W + 127) / 128; q.nchunks = g->B * g->H * q.chunks_per_row;
+    if (g_a) {
+      hipLaunchKernelGGL(conv32to1_2d_dgrad_kernel, dim3(q.nchunks > 16384 ? 16384 : q.nchunks), dim3(256), 0, st, q);
+      AS_CHECK_LAUNCH("as_conv32to1_bwd(2d dgrad)");
+    }
+    if (g_w || g_bias) {
+      int nb = (q.nchunks + 3) / 4;
+      if (nb > OUTW_BLOCKS) nb = OUTW_BLOCKS;
+      hipLaunchKernelGGL(conv32to1_2d_wgrad_kernel, dim3(nb), dim3(256), 0, st, q);
+      AS_CHECK_LAUNCH("as_conv32to1_bwd(2d wgrad)");
+      hipLaunchKernelGGL(conv32to1_wgrad_reduce_kernel, dim3(as_div_up(9 * 32 + 1, 4)), dim3(256), 0, st,
+                         workspace, nb, 9, g_w, g_bias, accumulate);
+      AS_CHECK_LAUNCH("as_conv32to1_bwd(reduce)");
+    }
+    return AS_OK;
+  }
   if (g_a) {
     hipLaunchKernelGGL(conv32to1_dgrad_kernel, dim3(out_blocks(p.M)), dim3(256), 0, st, p);
     AS_CHECK_LAUNCH("as_conv32to1_bwd(dgrad)");
