@@ -642,7 +642,7 @@ class EdgeRefineFn(torch.autograd.Function):
     wp4 = _empty(9 * 128, dev)
     call("as_conv4_pack_weights", ptr(w0), 4, ptr(wp4), s33, stream())
     if train:
-      stats = StatParts(lib.as_conv32_num_blocks(g), dev)
+      stats = StatParts(lib.as_conv4_stat_parts(g4, g, s33), dev)
       z0 = POOL.get(g, dev)
       call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(z0), g, s33, 0, None, None, LEAKY_SLOPE,
            ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stream())

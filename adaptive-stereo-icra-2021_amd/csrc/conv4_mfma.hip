@@ -48,6 +48,168 @@ __global__ __launch_bounds__(256) void conv4_fwd_kernel(Conv4Args p) {
   stats_write(p.ep, blockIdx.x, ts);
 }
 
+// ---- 3x3 stride-1 instance over row segments (the refinement's 4->32 input layer, full resolution) -------------
+// Same tile discipline as conv32_lds.hip: a wave owns 32 consecutive voxels of a row, the last segment of a row
+// is shifted left to end at W (duplicates are stored twice, skipped in the moments), vector-memory accesses are
+// scalar base + constant lane offset + immediate (inline asm, counted waits), BatchNorm moments are per-lane
+// shifted sums, one partial per workgroup.  Waves are independent: no barrier in the tile loop.
+// Input: the three 34-pixel rows a wave tile needs are fetched as three 1-KB LDS-DMA instructions (64 pixels
+// each) into the wave's private, double-buffered LDS rows; pending data therefore never sits in registers the
+// compiler might copy.  A row's window is clamped (scalar) to stay inside the padded row and its LDS
+// destination shifted by the same amount, so pixel xw-1 always lands at slot C4_SLOT0.
+// A operand: lane (voxel li, k-half h) reads channels h and 2+h of pixel li+kx: ds_read_b32 at a constant
+// lane address + immediates (no select instructions).
+// Per tile a wave issues exactly 3 DMAs and 16 stores; the next tile's DMAs go out before this tile's MFMAs,
+// so "s_waitcnt vmcnt(19)" = this tile's rows have landed (vmcnt is in-order; the 16 stores of the previous
+// tile and the 3 DMAs of the next one are the only younger operations).
+#define C4_SLOT0 30
+#define C4_ROW_BYTES 1536            // (30 + 64) pixels x 16 B, padded
+#define C4_WAVE_BYTES (2 * 3 * C4_ROW_BYTES)
+
+struct Conv4RowsArgs {
+  const float* x4;
+  const float* wp;        // [9][2][64]
+  EpilogueArgs ep;
+  PclDev gin, gout;       // gin: PCL4
+  int wtiles_per_row, nwtiles;
+};
+
+__device__ inline void c4_dma(const float* sbase, unsigned voff, unsigned m0) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+template <int IMM> __device__ inline void c4_store(float* sbase, unsigned voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+
+__device__ inline void c4_tile_coords(const Conv4RowsArgs& p, int wt, int& b, int& y, int& xw, int& x_new) {
+  const int row = wt / p.wtiles_per_row;
+  x_new = (wt - row * p.wtiles_per_row) * 32;
+  xw = min(x_new, p.gout.W - 32);
+  b = row / p.gout.H;
+  y = row - b * p.gout.H;
+}
+
+__device__ inline void c4_issue_dma(const Conv4RowsArgs& p, int wt, unsigned lds_buf, unsigned lane16) {
+  int b, y, xw, x_new;
+  c4_tile_coords(p, wt, b, y, xw, x_new);
+  const int ps = xw - 1 + p.gin.pw;                       // padded column of the tile's first input pixel
+  const int pc = min(ps, p.gin.Wp - 64);                  // 64-pixel window clamped into the padded row
+  const unsigned dst = lds_buf + (unsigned)((C4_SLOT0 - (ps - pc)) * 16);
+  const float* r0 = p.x4 + (((long)b * p.gin.Hp + (y + p.gin.ph - 1)) * p.gin.Wp + pc) * 4;
+  c4_dma(r0, lane16, dst);
+  c4_dma(r0 + (long)p.gin.Wp * 4, lane16, dst + C4_ROW_BYTES);
+  c4_dma(r0 + (long)p.gin.Wp * 8, lane16, dst + 2 * C4_ROW_BYTES);
+}
+
+#define C4_ROW_IMM(r) ((((r) & 3) + 8 * ((r) >> 2)) * 128)
+#define C4_FOR_ROWS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+
+// MODE 0: raw + moments, 1: lrelu(acc*scale+shift), 2: raw
+template <int MODE>
+__global__ __launch_bounds__(256) void conv4_rows_kernel(Conv4RowsArgs p) {
+  __shared__ __attribute__((aligned(16))) char rows[4 * C4_WAVE_BYTES];
+  __shared__ float part[8][32][3];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned io_off = (unsigned)(512 * h + 4 * li);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_ptr_t)rows)) + wave * C4_WAVE_BYTES;
+  const char* rd_base = rows + wave * C4_WAVE_BYTES + (C4_SLOT0 + li) * 16 + 4 * h;     // this lane's (pixel li, channel h)
+  float bw[9][2];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) { bw[tp][0] = p.wp[(tp * 2 + 0) * 64 + lane]; bw[tp][1] = p.wp[(tp * 2 + 1) * 64 + lane]; }
+  const float bias_v = p.ep.bias ? p.ep.bias[li] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (MODE == 1) { sc = p.ep.ep_scale[li]; sh = p.ep.ep_shift[li]; }
+  float st_n = 0.f, st_c = 0.f, st_s1 = 0.f, st_s2 = 0.f;
+
+  const int nw = gridDim.x * 4;
+  int wt = blockIdx.x * 4 + wave;
+  if (wt < p.nwtiles) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight / bias loads above
+    c4_issue_dma(p, wt, lds_wave, lane16);
+    // 16 dummy stores so that the first tile sees the same queue as every other one
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c4_store<0>(as_store_dump, (unsigned)(lane * 4), 0.f);
+  }
+  int cur = 0;
+  for (; wt < p.nwtiles; wt += nw, cur ^= 1) {
+    const int nxt = min(wt + nw, p.nwtiles - 1);          // past the end: re-fetch a valid tile (keeps the count uniform)
+    int b, y, xw, x_new;
+    c4_tile_coords(p, wt, b, y, xw, x_new);
+    float* z_base = p.ep.z + p.gout.vox(b, 0, y, xw) * 32;
+    c4_issue_dma(p, nxt, lds_wave + (unsigned)((cur ^ 1) * 3 * C4_ROW_BYTES), lane16);
+    asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+    const char* rd = rd_base + cur * 3 * C4_ROW_BYTES;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias_v;
+    float a[9][2];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      a[tp][0] = *reinterpret_cast<const float*>(rd + (tp / 3) * C4_ROW_BYTES + (tp % 3) * 16);
+      a[tp][1] = *reinterpret_cast<const float*>(rd + (tp / 3) * C4_ROW_BYTES + (tp % 3) * 16 + 8);
+    }
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tp][0], bw[tp][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tp][1], bw[tp][1], acc, 0, 0, 0);
+    }
+#define C4_ST(r) { float v = acc[r];                                                  \
+                   if (MODE == 1) { v = v * sc + sh; v = fmaxf(v, v * p.ep.slope); }   \
+                   c4_store<C4_ROW_IMM(r)>(z_base, io_off, v); }
+    C4_FOR_ROWS(C4_ST)
+#undef C4_ST
+    if (MODE == 0) {
+      const int dup = x_new - xw;
+      if (dup <= 0) {
+        st_c = st_n == 0.f ? acc[0] : st_c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = acc[r] - st_c; st_s1 += d; st_s2 = fmaf(d, d, st_s2); }
+        st_n += 16.f;
+      } else {
+        st_c = st_n == 0.f ? acc[15] : st_c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float d = row >= dup ? acc[r] - st_c : 0.f;
+          st_s1 += d; st_s2 = fmaf(d, d, st_s2); st_n += row >= dup ? 1.f : 0.f;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (MODE == 0 && p.ep.stat_mean != nullptr) {
+    const float mean_l = st_n > 0.f ? st_c + st_s1 / st_n : 0.f;
+    const float m2_l = st_n > 0.f ? fmaxf(st_s2 - st_s1 * st_s1 / st_n, 0.f) : 0.f;
+    part[wave * 2 + h][li][0] = st_n; part[wave * 2 + h][li][1] = mean_l; part[wave * 2 + h][li][2] = m2_l;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
+      for (int q = 0; q < 8; ++q) {
+        TileStats t; t.n = part[q][li][0]; t.mean = part[q][li][1]; t.m2 = part[q][li][2];
+        stats_merge(run, t);
+      }
+      stats_write(p.ep, blockIdx.x, run);
+    }
+  }
+}
+
+static bool conv4_rows_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  return s->kh == 3 && s->kw == 3 && s->stride == 1 && s->dil == 1 && s->pad_h == 1 && s->pad_w == 1 &&
+         gin->H == gout->H && gin->W == gout->W && gout->W >= 32 && gin->ph >= 1 && gin->pw >= 1 &&
+         gin->W + 2 * gin->pw >= 64 &&                      // a 64-pixel DMA window fits into a padded row
+         (long)gout->B * gout->H * ((gout->W + 31) / 32) < (1L << 31);
+}
+static int conv4_rows_grid(const as_pcl* gout) {
+  const long nwt = (long)gout->B * gout->H * ((gout->W + 31) / 32);
+  long g = (nwt + 3) / 4;
+  if (g > 1024) g = 1024;      // 36 KB of LDS per workgroup: four resident per CU, all of them at once
+  return (int)g;
+}
+
 // packed[t][j][h][co] = w[co][c = 2j+h][t]  (0 for c >= Cin)
 __global__ void conv4_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int T, int Cin) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,6 +401,13 @@ extern "C" int as_conv4_pack_weights(const float* w, int Cin, float* packed, con
   return AS_OK;
 }
 
+// Number of BatchNorm partials as_conv4_fwd writes for this configuration.
+extern "C" int as_conv4_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!gin || !gout || !s || !as_pcl_ok(gout)) return AS_ERR_ARG;
+  if (conv4_rows_applicable(gin, gout, s)) return conv4_rows_grid(gout);
+  return as_div_up((int64_t)gout->B * gout->H * gout->W, 128);
+}
+
 extern "C" int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* packed_w, const float* bias,
                             float* z, const as_pcl* gout, const as_conv_shape* s,
                             int epilogue, const float* ep_scale, const float* ep_shift, float slope,
@@ -246,6 +415,24 @@ extern "C" int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* pac
   if (int e = check4(gin, gout, s, "as_conv4_fwd")) return e;
   AS_CHECK_ARG(x4 && packed_w && z, "as_conv4_fwd: null pointer");
   AS_CHECK_ARG(epilogue_args_ok(epilogue, ep_scale, ep_shift, stat_mean, stat_m2, stat_cnt), "as_conv4_fwd: bad epilogue arguments");
+  if (conv4_rows_applicable(gin, gout, s)) {
+    Conv4RowsArgs r;
+    r.x4 = x4; r.wp = packed_w;
+    r.ep.bias = bias; r.ep.z = z; r.ep.ep_scale = ep_scale; r.ep.ep_shift = ep_shift; r.ep.residual = nullptr;
+    r.ep.stat_mean = epilogue == 0 ? stat_mean : nullptr; r.ep.stat_m2 = epilogue == 0 ? stat_m2 : nullptr;
+    r.ep.stat_cnt = epilogue == 0 ? stat_cnt : nullptr;
+    r.ep.epilogue = epilogue; r.ep.slope = slope;
+    r.gin = as_make_dev(gin); r.gout = as_make_dev(gout);
+    r.wtiles_per_row = (gout->W + 31) / 32;
+    r.nwtiles = gout->B * gout->H * r.wtiles_per_row;
+    const int grid = conv4_rows_grid(gout);
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue == 1) hipLaunchKernelGGL(conv4_rows_kernel<1>, dim3(grid), dim3(256), 0, st, r);
+    else if (r.ep.stat_mean) hipLaunchKernelGGL(conv4_rows_kernel<0>, dim3(grid), dim3(256), 0, st, r);
+    else hipLaunchKernelGGL(conv4_rows_kernel<2>, dim3(grid), dim3(256), 0, st, r);
+    AS_CHECK_LAUNCH("as_conv4_fwd(rows)");
+    return AS_OK;
+  }
   Conv4Args a;
   a.x4 = x4; a.wp = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = nullptr;

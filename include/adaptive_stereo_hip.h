@@ -174,6 +174,8 @@ int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl* g, const 
 int64_t as_pcl4_numel(const as_pcl* g);
 int as_pack_in4(const float* ch0, const float* img, int C, float* x4, const as_pcl* g, void* stream);
 int as_conv4_pack_weights(const float* w, int Cin, float* packed, const as_conv_shape* s, void* stream);
+/* Number of (mean, M2, count) partials as_conv4_fwd writes for this configuration (size of stat_*). */
+int as_conv4_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* packed_w, const float* bias,
                  float* z, const as_pcl* gout, const as_conv_shape* s,
                  int epilogue, const float* ep_scale, const float* ep_shift, float slope,

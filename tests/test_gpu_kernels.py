@@ -341,6 +341,7 @@ def test_sumsq_and_adam_step():
 
 # ----------------------------------------------------------------------------- thin-input conv (Cin <= 4)
 @pytest.mark.parametrize("B,H,W,Cin,k,stride,pad", [(1, 9, 13, 4, 3, 1, 1), (2, 37, 53, 4, 3, 1, 1),
+                                                    (2, 20, 131, 4, 3, 1, 1), (1, 7, 32, 4, 3, 1, 1),
                                                     (1, 21, 30, 3, 5, 2, 2), (2, 75, 131, 3, 5, 2, 2)])
 def test_conv4_fwd_and_wgrad(B, H, W, Cin, k, stride, pad):
   x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
@@ -368,6 +369,28 @@ def test_conv4_fwd_and_wgrad(B, H, W, Cin, k, stride, pad):
   nat.call("as_conv4_fwd", nat.ptr(x4), g4, nat.ptr(wp), nat.ptr(bd), nat.ptr(z), gout, shape, 0, None, None, 0.2,
            None, None, None, nat.stream())
   close(ops.pcl_to_ncdhw(z, gout)[:, :, 0], z_ref, 1e-5, 1e-5, "conv4 fwd")
+  # BatchNorm moments written by the epilogue: exact merge of the partials must give the layer's mean / M2
+  nparts = lib.as_conv4_stat_parts(g4, gout, shape)
+  sm = torch.zeros(nparts * 32, device=DEV); s2 = torch.zeros(nparts * 32, device=DEV); sc = torch.zeros(nparts, device=DEV)
+  z2 = ops.pcl_zeros(gout, DEV)
+  nat.call("as_conv4_fwd", nat.ptr(x4), g4, nat.ptr(wp), nat.ptr(bd), nat.ptr(z2), gout, shape, 0, None, None, 0.2,
+           nat.ptr(sm), nat.ptr(s2), nat.ptr(sc), nat.stream())
+  assert torch.equal(z2, z), "moments must not change the output"
+  cnt = sc.double().cpu(); mean_i = sm.view(nparts, 32).double().cpu(); m2_i = s2.view(nparts, 32).double().cpu()
+  n_tot = cnt.sum()
+  assert int(n_tot) == B * Ho * Wo
+  mean = (cnt[:, None] * mean_i).sum(0) / n_tot
+  m2 = (m2_i + cnt[:, None] * (mean_i - mean) ** 2).sum(0)
+  zr = z_ref.detach().double().permute(1, 0, 2, 3).reshape(32, -1)
+  close(mean.float(), zr.mean(1).float(), 1e-5, 1e-5, "conv4 moments: mean")
+  close((m2 / n_tot).float(), zr.var(1, unbiased=False).float(), 1e-5, 1e-4, "conv4 moments: variance")
+  # fused eval epilogue: lrelu(z*scale + shift)
+  scl = rnd(32, seed=7).abs().to(DEV) + 0.5; shf = rnd(32, seed=8).to(DEV)
+  z3 = ops.pcl_zeros(gout, DEV)
+  nat.call("as_conv4_fwd", nat.ptr(x4), g4, nat.ptr(wp), nat.ptr(bd), nat.ptr(z3), gout, shape, 1, nat.ptr(scl), nat.ptr(shf),
+           0.2, None, None, None, nat.stream())
+  ref3 = F.leaky_relu(z_ref.detach() * scl.cpu().view(1, 32, 1, 1) + shf.cpu().view(1, 32, 1, 1), 0.2)
+  close(ops.pcl_to_ncdhw(z3, gout)[:, :, 0], ref3, 1e-5, 1e-5, "conv4 fused epilogue")
   gzb = ops.ncdhw_to_pcl(gz.unsqueeze(2).to(DEV), gout)
   dW = torch.empty(32, Cin, k, k, device=DEV); db = torch.empty(32, device=DEV)
   ws = torch.empty(lib.as_conv4_wgrad_workspace(gout, shape), device=DEV)
