@@ -329,6 +329,81 @@ __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
   }
 }
 
+// ---- weight gradient, 3x3 stride-1 instance, on the vector ALUs ---------------------------------------------
+// With K = 36 useful rows out of 64 and two pixels per v_mfma_f32_32x32x2_f32 the matrix core needs 64 cycles
+// per pixel here; the plain FMA formulation needs 1152 FMAs per pixel = 18 wave-cycles per pixel-SIMD and no
+// operand gather.  Eight lanes share a pixel (float4 of G = 4 output channels each) and keep dW[36 rows][4 co]
+// in registers over all of the workgroup's row chunks; a pixel's nine taps are nine 16-byte loads that the
+// eight lanes share.  One slab per workgroup in the layout conv4_wgrad_reduce_kernel reads (NB = 2).
+struct Wgrad4RowsArgs {
+  const float* x4;
+  const float* gz;
+  float* partial;      // [blocks][2][32][32]
+  float* partial_db;   // [blocks][32]
+  PclDev gin, gout;
+  int nchunks, chunks_per_row;
+};
+
+__global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p) {
+  __shared__ float red[32][33];
+  const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
+  f32x4 acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  for (int ch = blockIdx.x; ch < p.nchunks; ch += gridDim.x) {
+    const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
+    const int y = rowi % p.gout.H, b = rowi / p.gout.H, x0 = cx * 128;
+    const int nf4 = min(128, p.gout.W - x0) * 8;
+    const float* grow = p.gz + p.gout.vox(b, 0, y, x0) * 32;
+    const float* xrow = p.x4 + (((long)b * p.gin.Hp + (y + p.gin.ph - 1)) * p.gin.Wp + (x0 + p.gin.pw - 1)) * 4;
+    const long rs = (long)p.gin.Wp * 4;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int f = threadIdx.x + 256 * k4;
+      if (f < nf4) {
+        const int vx = f >> 3;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(grow + f * 4);
+        f32x4 px[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) px[t] = *reinterpret_cast<const f32x4*>(xrow + (t / 3) * rs + (vx + t % 3) * 4);
+        bsum += g4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          acc[4 * t + 0] += px[t].x * g4; acc[4 * t + 1] += px[t].y * g4;
+          acc[4 * t + 2] += px[t].z * g4; acc[4 * t + 3] += px[t].w * g4;
+        }
+      }
+    }
+  }
+  float* out = p.partial + (long)blockIdx.x * 2048;
+#pragma unroll
+  for (int k = 0; k < 37; ++k) {
+    const f32x4 v = k < 36 ? acc[k < 36 ? k : 0] : bsum;
+    __syncthreads();
+    red[vl][c4 * 4 + 0] = v.x; red[vl][c4 * 4 + 1] = v.y; red[vl][c4 * 4 + 2] = v.z; red[vl][c4 * 4 + 3] = v.w;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float sum = 0.f;
+      for (int j = 0; j < 32; ++j) sum += red[j][threadIdx.x];
+      if (k < 36) out[k * 32 + threadIdx.x] = sum;
+      else p.partial_db[blockIdx.x * 32 + threadIdx.x] = sum;
+    }
+  }
+}
+
+static bool conv4_wgrad_rows_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  return s->kh == 3 && s->kw == 3 && s->stride == 1 && s->dil == 1 && s->pad_h == 1 && s->pad_w == 1 &&
+         gin->H == gout->H && gin->W == gout->W && gin->ph >= 1 && gin->pw >= 1 &&
+         (long)gout->B * gout->H * ((gout->W + 127) / 128) < (1L << 31);
+}
+static int conv4_wgrad_rows_grid(const as_pcl* gout) {
+  const long nch = (long)gout->B * gout->H * ((gout->W + 127) / 128);
+  long g = (nch + 3) / 4;
+  if (g > 1024) g = 1024;
+  return (int)(g < 1 ? 1 : g);
+}
+
 // dW[co][c][t] = sum_chunks partial[chunk][k>>5][k&31][co], k = 4t + c
 // 32 lanes per output element: lane q sums chunks q, q+32, ..., then a fixed-order butterfly (deterministic).
 __global__ void conv4_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
@@ -462,7 +537,10 @@ extern "C" int64_t as_conv4_wgrad_workspace(const as_pcl* gout, const as_conv_sh
   if (!gout || !s || !as_pcl_ok(gout)) return -1;
   int nb, rpc, nchunks;
   plan4(gout, s, &nb, &rpc, &nchunks);
-  return (int64_t)nchunks * nb * 1024 + (int64_t)nchunks * 32;
+  int64_t need = (int64_t)nchunks * nb * 1024 + (int64_t)nchunks * 32;
+  const int64_t rows_need = (int64_t)conv4_wgrad_rows_grid(gout) * (2048 + 32);     // the 3x3 stride-1 instance
+  if (s->kh == 3 && s->kw == 3 && s->stride == 1 && rows_need > need) need = rows_need;
+  return need;
 }
 
 template <int NB>
@@ -476,6 +554,20 @@ extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* g
                               void* stream) {
   if (int e = check4(gin, gout, s, "as_conv4_wgrad")) return e;
   AS_CHECK_ARG(x4 && gz && dW && workspace && Cin >= 1 && Cin <= 4, "as_conv4_wgrad: bad argument");
+  if (conv4_wgrad_rows_applicable(gin, gout, s)) {
+    Wgrad4RowsArgs r;
+    const int grid = conv4_wgrad_rows_grid(gout);
+    r.x4 = x4; r.gz = gz; r.partial = workspace; r.partial_db = workspace + (int64_t)grid * 2048;
+    r.gin = as_make_dev(gin); r.gout = as_make_dev(gout);
+    r.chunks_per_row = (gout->W + 127) / 128; r.nchunks = gout->B * gout->H * r.chunks_per_row;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv4_wgrad_rows_kernel, dim3(grid), dim3(256), 0, st, r);
+    AS_CHECK_LAUNCH("as_conv4_wgrad(rows)");
+    hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up((32 * Cin * 9 + 32) * 32, 256)), dim3(256), 0, st, r.partial,
+                       r.partial_db, grid, 2, 9, Cin, dW, db, accumulate);
+    AS_CHECK_LAUNCH("as_conv4_wgrad(reduce)");
+    return AS_OK;
+  }
   int nb, rpc, nchunks;
   plan4(gout, s, &nb, &rpc, &nchunks);
   AS_CHECK_ARG(nb >= 1 && nb <= 4, "as_conv4_wgrad: kernel too large");
