@@ -74,6 +74,9 @@ int as_cost_volume_bwd(const float* gvol, float* gL, float* gR, const as_pcl* g,
  *               parts = as_conv32_stat_parts() (capacity as_conv32_num_blocks() always suffices);
  *   epilogue 1: z = lrelu(acc*ep_scale[c] + ep_shift[c]) (+ residual[v][c] if given):
  *               eval-mode BatchNorm + LeakyReLU (+ BasicBlock skip) fused.
+ *   z must not alias x or residual (2-D 3x3 layers with W >= 128 run on an LDS-staged kernel whose last
+ *   row segment overlaps its neighbour: the overlap is computed and stored twice).  The halo of z is never
+ *   written.
  * as_conv32_wgrad: dW[o][i][tap] (PyTorch layout) = sum_v x[v+tap][i] * gz[v][o];
  *   workspace must hold as_conv32_wgrad_workspace() floats. db (may be NULL) gets
  *   sum_v gz[v][o].  accumulate=1 adds into dW/db instead of overwriting them (all parameter-gradient
