@@ -160,18 +160,22 @@ class OnlineAdapter(object):
       return self._replay(left, right)
     return self._step_eager(left, right)
 
+  def _forward_maps(self, left, right):
+    fl, fr = self.feature_net(left), self.feature_net(right)
+    out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+    pred = out["pred_disp_l/{}".format(self.scale)]
+    warped, mask = self.warper(right, pred, right_to_left=True)
+    total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+    fcs_map = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
+    return total, mask, fcs_map, out, warped
+
   def _step_eager(self, left, right):
     self.feature_net.train(); self.stereo_net.train()
     self.arena.rebind_grads()
     self.arena.zero_grads()
     self.plan.begin()
     try:
-      fl, fr = self.feature_net(left), self.feature_net(right)
-      out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
-      pred = out["pred_disp_l/{}".format(self.scale)]
-      warped, mask = self.warper(right, pred, right_to_left=True)
-      total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
-      fcs_map = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
+      total, mask, fcs_map, out, warped = self._forward_maps(left, right)
 
       if self.world == 1:
         loss = masked_mean(total, mask)
@@ -262,13 +266,12 @@ class OnlineAdapter(object):
 
   # -- hipGraph capture of the whole step ------------------------------------------------------------
   def capture(self, left, right, warmup=3):
-    """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~540 kernel launches)
-    into a hipGraph and replays it from then on.  Every entry point of the C ABI only enqueues work on
-    the current stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the
-    device.  Inputs are copied into static buffers before each replay.  Single-GPU only: the RCCL
-    all-reduce is kept out of the graph."""
-    if self.world != 1:
-      raise RuntimeError("OnlineAdapter.capture: graph replay is implemented for world size 1")
+    """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~360 kernel launches) into
+    hipGraphs and replays them from then on.  Every entry point of the C ABI only enqueues work on the current
+    stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the device.  Inputs
+    are copied into static buffers before each replay.
+    One GPU: a single graph.  Data parallel: three graphs (forward + local sums | backward | clip + Adam + EMA)
+    with the two RCCL all-reduces issued between them on the same stream, outside any capture."""
     self._static_left, self._static_right = left.clone(), right.clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -277,22 +280,67 @@ class OnlineAdapter(object):
         self._step_eager(self._static_left, self._static_right)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
     self.optimizer.step_count_at_capture = self.optimizer.step_count
-    with torch.cuda.graph(graph):
-      self._static_result = self._step_eager(self._static_left, self._static_right)
+    if self.world == 1:
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(graph):
+        self._static_result = self._step_eager(self._static_left, self._static_right)
+      self._graph = graph
+    else:
+      if self.pg is not None or dist.is_initialized():
+        dist.barrier(group=self.pg)
+      cap = torch.cuda.Stream()          # forward and backward must be captured on the same stream (autograd
+      g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()   # replays backward there)
+      with torch.cuda.graph(g1, stream=cap):
+        self.feature_net.train(); self.stereo_net.train()
+        self.arena.rebind_grads()
+        self.arena.zero_grads()
+        self.plan.begin()
+        try:
+          total, mask, fcs_map, out, warped = self._forward_maps(self._static_left, self._static_right)
+          m8 = self._dp_local_sums(total, mask, fcs_map)
+        finally:
+          self.plan.end(final=False)
+      torch.cuda.synchronize()
+      dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
+      torch.cuda.synchronize()
+      with torch.cuda.graph(g2, pool=g1.pool(), stream=cap):
+        self.plan.begin(resume=True)
+        try:
+          self._dp_backward(total, m8)
+        finally:
+          self.plan.end()
+      torch.cuda.synchronize()
+      allreduce_gradients(self.arena.grads, self.pg)
+      torch.cuda.synchronize()
+      with torch.cuda.graph(g3, pool=g1.pool(), stream=cap):
+        loss, fcs = self._dp_results()
+        self.optimizer.step(clip=self.clip)
+        self.fcs_smoothed.mul_(self.fcs_ema_weight).add_(fcs.detach(), alpha=1.0 - self.fcs_ema_weight)
+        out["left_warped/{}".format(self.scale)] = warped
+        self._static_result = {"loss": loss.detach(), "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
+      self._graph = (g1, g2, g3)
     # capture only records: the python-side counter advanced, the device-side one did not
     self.optimizer.step_count = self.optimizer.step_count_at_capture
-    self._graph = graph
     return self
 
   def _replay(self, left, right):
     self._static_left.copy_(left); self._static_right.copy_(right)
-    self._graph.replay()
+    if self.world == 1:
+      self._graph.replay()
+    else:
+      g1, g2, g3 = self._graph
+      g1.replay()
+      dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
+      g2.replay()
+      allreduce_gradients(self.arena.grads, self.pg)
+      g3.replay()
     self.optimizer.step_count += 1          # host mirror of the device-side counter
     return self._static_result
 
-  def _distributed_backward(self, total, mask, fcs_map, pairs):
+  # -- data-parallel step in three device-side phases with the two collectives between them ---------------
+  def _dp_local_sums(self, total, mask, fcs_map):
+    """Phase 1 tail: this rank's [valid count, loss sum, FCS sum, FCS count] into self.scalars (no communication)."""
     m8 = mask.to(torch.uint8)
     lib = nat.load()
     n = total.numel()
@@ -300,18 +348,36 @@ class OnlineAdapter(object):
     local = torch.empty(2, dtype=torch.float32, device=total.device)
     td, m8c = total.detach().contiguous(), m8.contiguous()
     nat.call("as_masked_sum", nat.ptr(td), nat.ptr(m8c), n, nat.ptr(local), nat.ptr(ws), nat.stream())
-    s = allreduce_step_scalars(self.scalars, local[0], local[1], fcs_map.sum(), float(fcs_map.numel()), self.pg)
-    # d(global mean)/d(total) on this rank = mask / N_total
-    total.backward(m8.to(torch.float32) / s[0])
-    allreduce_gradients(self.arena.grads, self.pg)
+    fill_step_scalars(self.scalars, local[0], local[1], fcs_map.sum(), float(fcs_map.numel()))
+    return m8
+
+  def _dp_backward(self, total, m8):
+    """Phase 2: d(global mean)/d(total) on this rank = mask / N_total (self.scalars is all-reduced by now)."""
+    total.backward(m8.to(torch.float32) / self.scalars[0])
+
+  def _dp_results(self):
+    s = self.scalars
     return s[1] / s[0], s[2] / s[3]
+
+  def _distributed_backward(self, total, mask, fcs_map, pairs):
+    m8 = self._dp_local_sums(total, mask, fcs_map)
+    dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
+    self._dp_backward(total, m8)
+    allreduce_gradients(self.arena.grads, self.pg)
+    return self._dp_results()
+
+
+def fill_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count):
+    buf[0] = valid_count; buf[1] = loss_sum; buf[2] = fcs_sum
+    buf[3:4].fill_(fcs_count)        # a python float: fill_ is a kernel (capturable), item assignment a host copy
+    return buf
 
 
 def allreduce_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count, group=None):
     """One 16-byte all-reduce(sum) of [valid-pixel count, loss sum, FCS sum, FCS count], issued BEFORE
     backward: the reference's loss is the mean over the valid pixels of the whole batch (adapt.py:83),
     so every rank must scale its local gradient by 1/N_total, not 1/N_rank."""
-    buf[0] = valid_count; buf[1] = loss_sum; buf[2] = fcs_sum; buf[3] = fcs_count
+    fill_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
 

@@ -139,7 +139,7 @@ def main():
   adapter = OnlineAdapter(fnet, snet, args.height, args.width, lr=5e-5, clip_grad_norm=True)
 
   lib = nat.load()
-  use_graph = (world == 1) and not args.no_graph
+  use_graph = not args.no_graph
   log("setup done: %d pairs/GPU at %dx%d, world %d, %s" % (B, args.width, args.height, world,
                                                            "hipGraph replay" if use_graph else "eager launches"))
   # ---- forward + adaptation step ---------------------------------------------------------

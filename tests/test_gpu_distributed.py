@@ -93,3 +93,52 @@ def test_two_rank_adaptation_step_on_one_gpu(tmp_path):
   assert abs(got["loss"] - float(loss)) < 2e-5, (got["loss"], float(loss))
   assert abs(got["fcs"] - float(torch.cat(fcss).mean())) < 1e-4
   assert abs(got["grad_norm"] - float(gnorm)) <= 5e-2 * float(gnorm), (got["grad_norm"], float(gnorm))
+
+
+def _graph_worker(rank, world, port, out_path):
+  """Eager data-parallel stepping vs the three-graph replay (forward | backward | update, collectives between)."""
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from adaptive_stereo.adaptation import OnlineAdapter
+  from adaptive_stereo.utils import synthetic as syn
+  batches = [syn.stereo_pair(4, H, W, seed=s, disparities=(3.0, 6.0, 4.0, 8.0)) for s in (31, 32, 33, 34)]
+  lo = rank * 2
+  batches = [(l[lo:lo + 2].cuda(), r[lo:lo + 2].cuda()) for l, r in batches]
+  results = []
+  for use_graph in (False, True):
+    fnet, snet, fsd, ssd, _, _ = _states()
+    fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+    adapter = OnlineAdapter(fnet.cuda(), snet.cuda(), H, W, lr=5e-5)
+    adapter.step(*batches[0])
+    if use_graph:
+      adapter.capture(*batches[0], warmup=1)        # the warm-up inside capture() is one more step on batch 0
+    else:
+      adapter.step(*batches[0])
+    losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
+    torch.cuda.synchronize()
+    results.append((losses, adapter.arena.params.detach().cpu().clone(), adapter.optimizer.step_count,
+                    float(adapter.optimizer.step_dev)))
+    dist.barrier()
+  (l0, p0, c0, d0), (l1, p1, c1, d1) = results
+  gathered = [torch.zeros_like(p1) for _ in range(world)]
+  dist.all_gather(gathered, p1)
+  if rank == 0:
+    torch.save({"losses_equal": l0 == l1, "losses": (l0, l1), "params_equal": bool(torch.equal(p0, p1)),
+                "max_diff": float((p0 - p1).abs().max()), "ranks_equal": bool(torch.equal(gathered[0], gathered[1])),
+                "counts": (c0, c1, d0, d1)}, out_path)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_graph_replay_equals_eager(tmp_path):
+  out_path = str(tmp_path / "dp_graph.pt")
+  mp.spawn(_graph_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+  got = torch.load(out_path)
+  assert got["counts"] == (5, 5, 5.0, 5.0), got["counts"]
+  assert got["losses_equal"], got["losses"]
+  assert got["params_equal"], got["max_diff"]
+  assert got["ranks_equal"]
