@@ -117,9 +117,15 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if os.environ.get("AS_BENCH_SINGLE_DEVICE"):      # rehearsal of the N>1 code path on a one-GPU box (with gloo)
+    local_rank = 0
   if world > 1:
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    backend = os.environ.get("AS_BENCH_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only for the rehearsal above
+    if backend == "nccl":
+      dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+      dist.init_process_group(backend=backend)
   assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU product path)"
   dev = torch.device("cuda", local_rank)
 
