@@ -93,6 +93,7 @@ _SIGNATURES = {
   "as_eval_metrics_workspace": (c_i64, [c_i64]),
   "as_eval_metrics": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_sumsq_workspace": (c_i64, [c_i64]),
+  "as_clip_coef": (c_int, [c_vp, c_float, c_vp, c_vp]),
   "as_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_float, c_float, c_float, c_float, c_int, c_vp,
                            c_vp]),

@@ -93,7 +93,7 @@ class FusedClipAdam(object):
       if clip and gi == self.clip_group:
         nat.call("as_sumsq", nat.ptr(a.grads[s:e]), e - s, nat.ptr(self.sumsq), nat.ptr(self.ws), nat.stream())
         # torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
-        torch.clamp(self.max_norm / (torch.sqrt(self.sumsq) + 1e-6), max=1.0, out=self.coef)
+        nat.call("as_clip_coef", nat.ptr(self.sumsq), float(self.max_norm), nat.ptr(self.coef), nat.stream())
         scale = self.coef
       nat.call("as_adam_step", nat.ptr(a.params[s:e]), nat.ptr(a.grads[s:e]), nat.ptr(self.exp_avg[s:e]),
                nat.ptr(self.exp_avg_sq[s:e]), e - s, nat.ptr(scale), self.lr, self.betas[0], self.betas[1],

@@ -93,6 +93,18 @@ __global__ void sumsq_finalize_kernel(const double* __restrict__ partial, int nb
   if (threadIdx.x == 0) out[0] = (float)s;
 }
 
+// torch.nn.utils.clip_grad_norm_: coef = min(max_norm / (sqrt(sumsq) + 1e-6), 1), in fp32 like ATen
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef) {
+  if (threadIdx.x == 0) coef[0] = fminf(max_norm / (sqrtf(sumsq[0]) + 1e-6f), 1.0f);
+}
+
+extern "C" int as_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream) {
+  AS_CHECK_ARG(sumsq && coef && max_norm > 0.f, "as_clip_coef: bad argument");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, max_norm, coef);
+  AS_CHECK_LAUNCH("as_clip_coef");
+  return AS_OK;
+}
+
 extern "C" int64_t as_sumsq_workspace(int64_t n) { return n > 0 ? 2 * SS_BLOCKS : -1; }
 
 extern "C" int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream) {

@@ -12,7 +12,7 @@
 #include "as_common.h"
 #pragma clang fp contract(off)
 
-#define PH_BLOCKS_PER_IMAGE 128
+#define PH_BLOCKS_PER_IMAGE 512     // x B workgroups: eight per CU at 4 images
 
 // ---- deterministic per-image reductions --------------------------------------------------
 // partial[b][blk] (fp64) then a fixed-order finalize.
@@ -29,14 +29,14 @@ __global__ __launch_bounds__(256) void image_sum_kernel(const float* __restrict_
   if (threadIdx.x == 0) partial[(long)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// out[b] = sum_blk partial[b][blk] * mul
-__global__ void image_sum_finalize_kernel(const double* __restrict__ partial, int nblk, int B, double mul,
-                                          float* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// out[b] = sum_blk partial[b][blk] * mul: one wave per image, lanes stride over the blocks, fixed-order butterfly
+__global__ __launch_bounds__(64) void image_sum_finalize_kernel(const double* __restrict__ partial, int nblk, int B,
+                                                                double mul, float* __restrict__ out) {
+  const int b = blockIdx.x;
   double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += partial[(long)b * nblk + i];
-  out[b] = (float)(s * mul);
+  for (int i = threadIdx.x; i < nblk; i += 64) s += partial[(long)b * nblk + i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[b] = (float)(s * mul);
 }
 
 // ---- shared per-pixel SSIM arithmetic --------------------------------------------------------
@@ -273,7 +273,7 @@ static PhWs carve(float* ws, int B) {
 static int image_mean(const float* pred, int B, long plane, PhWs& w, hipStream_t st) {
   hipLaunchKernelGGL(image_sum_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, pred, plane, w.partial);
   AS_CHECK_LAUNCH("monodepth(mean)");
-  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(as_div_up(B, 64)), dim3(64), 0, st, w.partial,
+  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(B), dim3(64), 0, st, w.partial,
                      PH_BLOCKS_PER_IMAGE, B, 1.0 / (double)plane, w.mean);
   AS_CHECK_LAUNCH("monodepth(mean finalize)");
   return AS_OK;
@@ -309,7 +309,7 @@ extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, co
   hipLaunchKernelGGL(monodepth_bwd_a_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, g_total, g_ssim, g_smooth,
                      pred, img, warped, w.mean, B, H, W, smoothness_weight, w.coef, w.partial);
   AS_CHECK_LAUNCH("as_monodepth_loss_bwd(A)");
-  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(as_div_up(B, 64)), dim3(64), 0, st, w.partial,
+  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(B), dim3(64), 0, st, w.partial,
                      PH_BLOCKS_PER_IMAGE, B, 1.0, w.sum);
   AS_CHECK_LAUNCH("as_monodepth_loss_bwd(sum)");
   hipLaunchKernelGGL(monodepth_bwd_b_kernel, dim3(as_div_up((long)B * plane, 256)), dim3(256), 0, st, g_total, g_l1,

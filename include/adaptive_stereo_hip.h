@@ -241,6 +241,8 @@ int as_eval_metrics(const float* pred, const float* gt, int64_t n, float* out6, 
  * the latter lets a captured hipGraph replay successive steps. */
 int64_t as_sumsq_workspace(int64_t n);
 int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream);
+/* coef[0] = min(max_norm / (sqrt(sumsq[0]) + 1e-6), 1): the scale clip_grad_norm_ applies (adapt.py:391). */
+int as_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
 int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
                  int step, const float* step_dev, void* stream);
