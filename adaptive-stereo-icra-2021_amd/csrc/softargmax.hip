@@ -521,7 +521,7 @@ extern "C" int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl
   }
   if (g_w || g_bias) {
     long nb = (p.M + 31) / 32;
-    if (nb > OUTW_BLOCKS) nb = OUTW_BLOCKS;
+    if (nb > 512) nb = 512;          // every workgroup ends with a 27-round LDS reduction: keep them few
     if (p.k.ntaps == 27) hipLaunchKernelGGL(conv32to1_wgrad_kernel<27>, dim3((int)nb), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(conv32to1_wgrad_kernel<9>, dim3((int)nb), dim3(256), 0, st, p);
     AS_CHECK_LAUNCH("as_conv32to1_bwd(wgrad)");

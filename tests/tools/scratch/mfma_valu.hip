@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int NACC, int OP>
+template <int NACC, int OP, int PRIO>
 __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* t, int iters) {
   const int wave = threadIdx.x >> 6;   // 8 waves: two per SIMD. waves 0-3 = MFMA, 4-7 = VALU
   if (wave < 4) {
@@ -20,6 +20,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* t, i
     float s = 0.f; for (int a = 0; a < (NACC > 0 ? NACC : 1); ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
     out[blockIdx.x * 512 + threadIdx.x] = s;
   } else {
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
     unsigned long long t0 = wall_clock64();
     float x = threadIdx.x * 0.5f, y = 1.0001f;
     unsigned u = threadIdx.x;
@@ -35,12 +36,12 @@ __global__ __launch_bounds__(512, 1) void k(float* out, unsigned long long* t, i
     if ((threadIdx.x & 63) == 0) t[blockIdx.x * 4 + wave - 4] = t1 - t0;
   }
 }
-template <int NACC, int OP> void run(const char* name, int iters) {
+template <int NACC, int OP, int PRIO = 0> void run(const char* name, int iters) {
   float* out; unsigned long long* t; hipMalloc(&out, 256 * 512 * 4); hipMalloc(&t, 256 * 4 * 8);
-  hipLaunchKernelGGL((k<NACC, OP>), dim3(256), dim3(512), 0, 0, out, t, iters);
+  hipLaunchKernelGGL((k<NACC, OP, PRIO>), dim3(256), dim3(512), 0, 0, out, t, iters);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipEventRecord(e0); hipLaunchKernelGGL((k<NACC, OP>), dim3(256), dim3(512), 0, 0, out, t, iters); hipEventRecord(e1);
+  hipEventRecord(e0); hipLaunchKernelGGL((k<NACC, OP, PRIO>), dim3(256), dim3(512), 0, 0, out, t, iters); hipEventRecord(e1);
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
   unsigned long long h[1024]; hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost);
@@ -54,6 +55,8 @@ int main() {
   run<1, 0>("partner 1 acc (dependent), fma", iters);
   run<2, 0>("partner 2 acc, fma", iters);
   run<4, 0>("partner 4 acc, fma", iters);
+  run<1, 0, 1>("partner 1 acc, fma, VALU wave s_setprio 3", iters);
+  run<4, 0, 1>("partner 4 acc, fma, VALU wave s_setprio 3", iters);
   run<0, 1>("partner sleeping, int mul", iters);
   run<1, 1>("partner 1 acc (dependent), imul", iters);
   run<2, 1>("partner 2 acc, imul", iters);
