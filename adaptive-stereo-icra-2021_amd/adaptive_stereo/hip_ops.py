@@ -355,67 +355,18 @@ def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train,
   return z, a, st
 
 
-class SideQueue(object):
-  """Weight gradients are off the critical path of backward (nothing downstream reads them before the optimizer),
-  and at full resolution they are matrix-core bound while the BatchNorm passes between two data gradients are
-  HBM bound.  With gradient sinks in place (the result goes straight into the flat arena) a layer's weight
-  gradient is therefore launched on a second stream, ordered AFTER that layer's data gradient, so that it runs
-  next to the following layer's BatchNorm backward instead of in front of it.  Buffers it reads are kept out of
-  the pool until join().  Works under hipGraph capture (fork / join through events)."""
-
-  def __init__(self):
-    self.stream = None
-    self.deferred = []
-    self.pending = False
-
-  def launch(self, fn):
-    main = torch.cuda.current_stream()
-    if self.stream is None:
-      self.stream = torch.cuda.Stream()
-    ev = torch.cuda.Event()
-    ev.record(main)
-    self.stream.wait_event(ev)
-    with torch.cuda.stream(self.stream):
-      fn()
-    self.pending = True
-
-  def defer(self, buf, g, channels=32):
-    self.deferred.append((buf, g, channels))
-
-  def join(self):
-    if self.pending:
-      torch.cuda.current_stream().wait_stream(self.stream)
-      self.pending = False
-    for buf, g, channels in self.deferred:
-      POOL.put(buf, g, channels=channels)
-    self.deferred = []
-
-
-SIDE = SideQueue()
-SIDE_WGRAD = False       # off: next to a matrix-core-bound kernel every latency-critical VALU kernel (bn_bwd_finalize: 8 -> 257 us)
-                         # is starved of issue slots, the overlap with the BatchNorm passes is lost again (DESIGN.md §4)
-
-
-def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx, sinks=None, side=None):
+def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx, sinks=None):
   """g_out: gradient w.r.t. the block output (PCL).  Returns (g_x or None, dW, db, g_gamma, g_beta).
   With a skip connection g_x = g_out + dgrad(...) — the add is fused into the dgrad epilogue.
-  ``sinks`` = (w, b, gamma, beta) accumulation targets; sunk gradients come back as None.
-  ``side``: a SideQueue; with sinks for w and b the weight gradient goes there (the caller joins it)."""
+  ``sinks`` = (w, b, gamma, beta) accumulation targets; sunk gradients come back as None."""
   sw, sb, sg, sbeta = sinks if sinks is not None else (None, None, None, None)
   g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta)
-  on_side = side is not None and SIDE_WGRAD and sw is not None and sb is not None
-  if not on_side:
-    dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
+  dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
   g_x = None
   if need_dx:
     wp_t = pack_weights(w, shape, True)
     g_x = conv32(g_z, g, wp_t, None, g, shape, residual=g_out if skip else None)
-  if on_side:
-    side.launch(lambda: conv32_wgrad(x, g, g_z, g, shape, True, sw, sb))
-    side.defer(g_z, g)
-    dW = db = None
-  else:
-    POOL.put(g_z, g)
+  POOL.put(g_z, g)
   return g_x, dW, db, g_gamma, g_beta
 
 
@@ -765,10 +716,9 @@ class EdgeRefineFn(torch.autograd.Function):
       wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
       g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], wl, gamma, g,
                                                     conv_shape_2d(REFINE_DILATIONS[l]), ctx.train, True, True,
-                                                    sinks[4 + 4 * l:8 + 4 * l] if sinks is not None else None, SIDE)
+                                                    sinks[4 + 4 * l:8 + 4 * l] if sinks is not None else None)
       grads[4 + 4 * l:8 + 4 * l] = [dW, db, g_gamma, g_beta]
-      POOL.put(g_a, g); POOL.put(zs[l], g)
-      SIDE.defer(xs[l + 1], g)          # block l+1's weight gradient may still be reading it
+      POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
       g_a = g_x
 
     # conv2d_feature backward
@@ -794,9 +744,7 @@ class EdgeRefineFn(torch.autograd.Function):
       call("as_upsample_bilinear_bwd", ptr(g_up), B, H, W, ptr(g_coarse), h, w, gain, stream())
     if ctx.needs_input_grad[1]:
       raise NotImplementedError("EdgeRefineFn: gradient w.r.t. the guidance image is not part of the adaptation path")
-    SIDE.defer(xs[0], g)
-    SIDE.join()
-    POOL.put(g_z0, g); POOL.put(g_a, g); POOL.put(ctx.z0, g); POOL.put(ctx.in4, g4, channels=4)
+    POOL.put(g_z0, g); POOL.put(g_a, g); POOL.put(ctx.z0, g); POOL.put(xs[0], g); POOL.put(ctx.in4, g4, channels=4)
     ctx.xs = ctx.zs = ctx.sts = ctx.in4 = ctx.z0 = None
     return (g_coarse, None, None, None, None) + tuple(grads)
 
