@@ -293,3 +293,39 @@ def test_step_plan_equals_per_call_launches():
     assert int(n0[k]) == int(n1[k]), k
   # stereo_net layers: 4 steps; feature_net layers: two images per step; BasicBlock.conv2 (never run): 0
   assert {int(v) for v in n0.values()} == {0, 4, 8}
+
+
+def test_three_adaptation_steps_follow_the_oracle():
+  """State carried across steps — Adam moments and bias correction, BatchNorm running statistics, the parameters
+  themselves — must follow the oracle's: three steps on three different pairs, per-step loss / FCS and the final
+  parameters and buffers compared.  (One step against the reference itself: the golden tests above.)"""
+  B, H, W, k, maxdisp = 2, 64, 160, 3, 64
+  meta = dict(k=k, s=0, maxdisp=maxdisp, gain=5.0)
+  fnet, snet = build(meta)
+  fsd = {n: t.detach().cpu().clone() for n, t in fnet.state_dict().items()}
+  ssd = {n: t.detach().cpu().clone() for n, t in snet.state_dict().items()}
+  fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
+  state = {}
+  adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+  for step, seed in enumerate((41, 42, 43)):
+    left, right = syn.stereo_pair(B, H, W, seed=seed, disparities=(4.0, 7.0))
+    ref = orc.adapt_step(fp, sp, state, left, right, k, 0, maxdisp)
+    got = adapter.step(left.to(DEV), right.to(DEV))
+    rl, gl = float(ref["loss"]), float(got["loss"])
+    assert abs(gl - rl) <= 2e-5 + 1e-4 * abs(rl), (step, gl, rl)
+    assert abs(float(got["fcs"]) - float(ref["fcs"])) <= 1e-4 * max(1.0, abs(float(ref["fcs"]))), step
+  torch.cuda.synchronize()
+  lr = 5e-5
+  for name, net, ref_p in (("feature", fnet, fp), ("stereo", snet, sp)):
+    sd = net.state_dict()
+    for key, ref_t in ref_p.items():
+      got_t = sd[key].detach().cpu()
+      if not got_t.is_floating_point():
+        assert int(got_t) == int(ref_t), (name, key)
+        continue
+      # three Adam steps move a weight by at most 3*lr; noise-level gradients may flip the sign of single updates
+      tol = 6 * lr + 1e-4 * float(ref_t.detach().abs().max())
+      diff = float((got_t - ref_t.detach()).abs().max())
+      assert diff <= tol, (name, key, diff, tol)
+    bad = [kk for kk in sd if kk not in ref_p]
+    assert not bad, bad
