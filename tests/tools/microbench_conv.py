@@ -23,6 +23,8 @@ cases = [
   ("2D 375x1242 B1 dil1", Pcl(1, 1, 375, 1242, 0, 8, 8), ops.conv_shape_2d(1)),
   ("3D 12x24x78 B4", Pcl(4, 12, 24, 78, 1, 1, 1), ops.CONV3D_333),
   ("3D 12x24x78 B1", Pcl(1, 12, 24, 78, 1, 1, 1), ops.CONV3D_333),
+  ("3D 12x24x78 B16", Pcl(16, 12, 24, 78, 1, 1, 1), ops.CONV3D_333),
+  ("3D 12x24x78 B64", Pcl(64, 12, 24, 78, 1, 1, 1), ops.CONV3D_333),
 ]
 only = sys.argv[1:]
 for name, g, shape in cases:
