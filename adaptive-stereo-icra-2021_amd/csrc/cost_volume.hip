@@ -4,7 +4,7 @@
 // (a python loop of Dc slice-assignments into a zero-filled NCDHW tensor there).
 //
 // MI355X design: one launch; features arrive NCHW (W fastest), the volume leaves
-// in PCL (channel fastest).  A workgroup owns a 64-pixel segment of one image row:
+// in PCL (channel fastest).  A workgroup owns a 16-pixel segment of one image row:
 // it stages the L segment and the R segment (plus D-1 pixels of left context)
 // through LDS, transposing W-major -> channel-major on the way, so global reads
 // are coalesced along W and global writes are full 128-byte voxel lines (float4
@@ -12,7 +12,7 @@
 // HBM-bound: algorithmic traffic = 2*F read + V written.
 #include "as_common.h"
 
-#define CV_TX 64
+#define CV_TX 16        // 5 x H x B workgroups at W=78: the volume is small (2.9 MB per pair), parallelism matters more than halo reuse
 #define CV_MAXD 64
 #define CV_LDS_STRIDE 33
 

@@ -106,8 +106,26 @@ def cpu_baseline(args, fsd, ssd, budget_s=12.0):
   log("cpu baseline: adapt %.3f s/step (%d reps)" % (t_adapt, n_adapt))
   t_fwd, n_fwd = sample(lambda: orc.forward_only(fsd, ssd, left, right, args.k, 0, args.maxdisp))
   log("cpu baseline: forward %.3f s (%d reps)" % (t_fwd, n_fwd))
+  # parity in the same run: the GPU forward of this pair against the CPU oracle's
+  from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+  ref_out, _ = orc.forward_only(fsd, ssd, left, right, args.k, 0, args.maxdisp)
+  fnet, snet = FeatureExtractorNetwork(args.k), StereoNet(args.k, 1, 0, maxdisp=args.maxdisp)
+  fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+  fnet, snet = fnet.cuda().eval(), snet.cuda().eval()
+  with torch.no_grad():
+    ld, rd = left.cuda(), right.cuda()
+    out = snet(ld, fnet(ld), fnet(rd), "l", output_cost_volume=True)
+  key = "cost_volume_l/%d" % args.k
+  epe = float((out["pred_disp_l/0"].cpu() - ref_out["pred_disp_l/0"]).abs().mean())
+  srt = torch.sort(ref_out[key], dim=1, descending=True)[0]
+  decided = (srt[:, 0] - srt[:, 1]) > 2e-5            # pixels whose arg-max the reference itself resolves beyond fp32 noise
+  am, ref_am = out[key]._as_argmax.cpu().long(), torch.argmax(ref_out[key], dim=1)
+  parity = {"disparity_epe_vs_cpu": epe, "epe_bar": 1e-3, "argmax_equal": bool((am[decided] == ref_am[decided]).all()),
+            "argmax_pixels_compared": int(decided.sum()), "argmax_pixels_total": int(decided.numel())}
+  log("parity: EPE %.2e, arg-max equal on %d of %d pixels: %s" % (epe, parity["argmax_pixels_compared"],
+                                                                 parity["argmax_pixels_total"], parity["argmax_equal"]))
   return {"value": round(1.0 / t_adapt, 4), "unit": "stereo pairs/s (fwd+adapt-step)", "cores": torch.get_num_threads(),
-          "kind": "port", "fwd_value": round(1.0 / t_fwd, 4),
+          "kind": "port", "fwd_value": round(1.0 / t_fwd, 4), "parity": parity,
           "sample": "oracle/stereo_oracle.py (PyTorch CPU fp32), batch 1 at %dx%d: 1 warm-up + %d adapt steps, "
                     "1 warm-up + %d forwards" % (args.width, args.height, n_adapt, n_fwd)}
 

@@ -24,5 +24,18 @@ for _ in range(5):
   ops.conv32(x, g, wp, b, g, shape, out=z, stats=stats)              # conv32_lds_kernel<0,false>: training forward
   ops.conv32(z, g, wpt, None, g, shape, out=gx, residual=x)           # conv32_lds_kernel<2,true>: data gradient + skip
   nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(z), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
+# a3: one 3-D cost-aggregation layer (forward + weight gradient), 4 pairs
+g3 = Pcl(B, 12, 24, 78, 1, 1, 1)
+x3 = torch.randn(g3.numel(), device=dev) * 0.5
+x3v = ops.pcl_view(x3, g3).clone(); ops.pcl_interior(x3v, g3).zero_(); x3 = x3 - x3v.view(-1)
+w3 = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.03
+wp3 = ops.pack_weights(w3, ops.CONV3D_333, False)
+z3 = torch.zeros(g3.numel(), device=dev)
+st3 = ops.conv32_stat_parts(g3, g3, ops.CONV3D_333, dev)
+ws3 = torch.empty(nat.load().as_conv32_wgrad_workspace(g3, g3, ops.CONV3D_333), device=dev)
+dW3 = torch.empty_like(w3)
+for _ in range(5):
+  ops.conv32(x3, g3, wp3, b, g3, ops.CONV3D_333, out=z3, stats=st3)
+  nat.call("as_conv32_wgrad", nat.ptr(x3), g3, nat.ptr(z3), g3, ops.CONV3D_333, nat.ptr(dW3), nat.ptr(db), 0, nat.ptr(ws3), nat.stream())
 torch.cuda.synchronize()
 print("done")

@@ -17,8 +17,10 @@ sq, fe, wr = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
 B, H, W = 4, 375, 1242
 vox = B * H * W
 flops = 2.0 * vox * 1024 * 9
+vox3 = B * 12 * 24 * 78
 alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>": 3 * vox * 128,
-       "conv32_wgrad_lds_kernel": 2 * vox * 128}
+       "conv32_wgrad_lds_kernel": 2 * vox * 128,
+       "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128}
 out = {"shape": "2-D 3x3 stride 1, 32->32, 4 pairs x 375x1242 (one full-resolution refinement layer)",
        "pairs_per_launch": B, "algorithmic_flops_per_launch": flops,
        "command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 tests/tools/pmc_conv.py   (separate passes: SQ_* ; FETCH_SIZE ; WRITE_SIZE GRBM_GUI_ACTIVE)",
