@@ -379,7 +379,7 @@ class CostAggregationFn(torch.autograd.Function):
      outputs: logits [B,D,H,W], pred [B,H,W], argmax int32 [B,H,W], fcs [B,H,W]"""
 
   @staticmethod
-  def forward(ctx, fl, fr, num_disp, train, bn_buffers, sinks, *params):
+  def forward(ctx, fl, fr, num_disp, train, grad_on, bn_buffers, sinks, *params):
     assert len(params) == 18
     fl, fr = f32c(fl), f32c(fr)
     params = [f32c(p) for p in params]
@@ -389,7 +389,8 @@ class CostAggregationFn(torch.autograd.Function):
     dev = fl.device
     D = int(num_disp)
     g = Pcl(B, D, H, W, 1, 1, 1)
-    need_bwd = any(ctx.needs_input_grad)
+    need_bwd = grad_on and any(ctx.needs_input_grad)   # grad_on: the caller's grad mode (forward() itself always runs
+    # with grad disabled, and needs_input_grad stays True under torch.no_grad())
 
     vol = POOL.get(g, dev)
     call("as_cost_volume_fwd", ptr(fl), ptr(fr), ptr(vol), g, stream())
@@ -465,7 +466,7 @@ class CostAggregationFn(torch.autograd.Function):
       POOL.put(g_a, g)
     POOL.put(xs[0], g)
     ctx.xs = ctx.zs = ctx.sts = None
-    return (g_fl, g_fr, None, None, None, None) + tuple(grads)
+    return (g_fl, g_fr, None, None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------
@@ -484,7 +485,7 @@ class FeatureExtractorFn(torch.autograd.Function):
   params: k x (downsample w, b), 6 x (conv w, conv b, bn w, bn b), conv_alone (w, b)."""
 
   @staticmethod
-  def forward(ctx, rgb, k, train, bn_buffers, sinks, *params):
+  def forward(ctx, rgb, k, train, grad_on, bn_buffers, sinks, *params):
     k = int(k)
     assert len(params) == 2 * k + 26
     rgb = f32c(rgb)
@@ -494,7 +495,8 @@ class FeatureExtractorFn(torch.autograd.Function):
       raise RuntimeError("FeatureExtractorFn: expected an RGB image [B,3,H,W]")
     dev = rgb.device
     lib = nat.load()
-    need_bwd = any(ctx.needs_input_grad)
+    need_bwd = grad_on and any(ctx.needs_input_grad)   # grad_on: the caller's grad mode (forward() itself always runs
+    # with grad disabled, and needs_input_grad stays True under torch.no_grad())
 
     # head: level 0 = image (PCL4, halo 2); level i = output of downsample[i-1]
     g4 = Pcl(B, 1, H, W, 0, 2, 2)
@@ -600,7 +602,7 @@ class FeatureExtractorFn(torch.autograd.Function):
     for buf, gi in zip(levels, geoms):
       POOL.put(buf, gi)
     ctx.xs = ctx.zs = ctx.sts = ctx.levels = ctx.in4 = None
-    return (None, None, None, None, None) + tuple(grads)
+    return (None, None, None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------
@@ -615,7 +617,7 @@ class EdgeRefineFn(torch.autograd.Function):
   params: conv2d_feature (w[32,4,3,3], b, bn w, bn b), 6 x (w[32,32,3,3], b, bn w, bn b), conv2d_out (w[1,32,3,3], b)."""
 
   @staticmethod
-  def forward(ctx, coarse, rgb, train, bn_buffers, sinks, *params):
+  def forward(ctx, coarse, rgb, train, grad_on, bn_buffers, sinks, *params):
     assert len(params) == 30
     coarse, rgb = f32c(coarse), f32c(rgb)
     params = [f32c(p) for p in params]
@@ -625,7 +627,8 @@ class EdgeRefineFn(torch.autograd.Function):
       raise RuntimeError("EdgeRefineFn: guidance image must be [B,3,H,W]")
     dev = rgb.device
     lib = nat.load()
-    need_bwd = any(ctx.needs_input_grad)
+    need_bwd = grad_on and any(ctx.needs_input_grad)   # grad_on: the caller's grad mode (forward() itself always runs
+    # with grad disabled, and needs_input_grad stays True under torch.no_grad())
     gain = W / w                                     # float ratio (stereo_net.py:113)
     g = Pcl(B, 1, H, W, 0, REFINE_HALO, REFINE_HALO)
     g4 = Pcl(B, 1, H, W, 0, 1, 1)
@@ -746,7 +749,7 @@ class EdgeRefineFn(torch.autograd.Function):
       raise NotImplementedError("EdgeRefineFn: gradient w.r.t. the guidance image is not part of the adaptation path")
     POOL.put(g_z0, g); POOL.put(g_a, g); POOL.put(ctx.z0, g); POOL.put(xs[0], g); POOL.put(ctx.in4, g4, channels=4)
     ctx.xs = ctx.zs = ctx.sts = ctx.in4 = ctx.z0 = None
-    return (g_coarse, None, None, None, None) + tuple(grads)
+    return (g_coarse, None, None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------

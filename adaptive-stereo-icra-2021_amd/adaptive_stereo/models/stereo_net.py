@@ -88,7 +88,8 @@ class FeatureExtractorNetwork(nn.Module):
     live = [b.live() for b in self.residual_blocks]
     block_params, buffers = _block_params(live)
     params += block_params + [self.conv_alone.weight, self.conv_alone.bias]
-    out = hip_ops.FeatureExtractorFn.apply(rgb_img, self.k, self.training, buffers, hip_ops.grad_sinks(params), *params)
+    out = hip_ops.FeatureExtractorFn.apply(rgb_img, self.k, self.training, torch.is_grad_enabled(), buffers,
+                                           hip_ops.grad_sinks(params), *params)
     if self.training:
       _count_batches(live)
     return out
@@ -105,7 +106,7 @@ class EdgeAwareRefinement(nn.Module):
     live = [self.conv2d_feature[0]] + [b.live() for b in self.residual_astrous_blocks]
     params, buffers = _block_params(live)
     params += [self.conv2d_out.weight, self.conv2d_out.bias]
-    out = hip_ops.EdgeRefineFn.apply(coarse_disparity, guidance_rgb, self.training, buffers,
+    out = hip_ops.EdgeRefineFn.apply(coarse_disparity, guidance_rgb, self.training, torch.is_grad_enabled(), buffers,
                                      hip_ops.grad_sinks(params), *params)
     if self.training:
       _count_batches(live)
@@ -151,7 +152,8 @@ class StereoNet(nn.Module):
     params += [self.conv3d_alone.weight, self.conv3d_alone.bias]
 
     logits, pred, argmax, fcs = hip_ops.CostAggregationFn.apply(
-        left_features, right_features, self.coarse_max_disp(), self.training, buffers, hip_ops.grad_sinks(params),
+        left_features, right_features, self.coarse_max_disp(), self.training, torch.is_grad_enabled(), buffers,
+        hip_ops.grad_sinks(params),
         *params)
     if self.training:
       for f in self.filter:
