@@ -59,6 +59,7 @@ _SIGNATURES = {
   "as_bn_finalize": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp,
                              c_vp, c_vp]),
   "as_bn_eval_affine": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  "as_bn_eval_affine_batch": (c_int, [c_vp, c_int, c_float, c_vp]),
   "as_bn_act_fwd": (c_int, [c_vp, c_vp, c_vp, c_float, c_vp, c_vp, _P(Pcl), c_vp]),
   "as_bn_bwd_workspace": (c_i64, [_P(Pcl)]),
   "as_bn_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_int, c_vp,

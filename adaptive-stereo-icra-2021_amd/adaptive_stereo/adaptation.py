@@ -144,15 +144,47 @@ class OnlineAdapter(object):
     self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [count, loss_sum, fcs_sum, pairs]
     self._graph = None
     self.plan = hip_ops.StepPlan()     # one-launch weight packing / batch counters (recorded on the first step)
+    self.infer_plan = hip_ops.StepPlan()   # same for the eval-mode forward (+ all BatchNorm affines in one launch)
+    self._infer_graph = None
 
   # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
   @torch.no_grad()
   def infer(self, left, right):
+    if self._infer_graph is not None:
+      self._infer_left.copy_(left); self._infer_right.copy_(right)
+      self._infer_graph.replay()
+      return self._infer_result
+    return self._infer_eager(left, right)
+
+  @torch.no_grad()
+  def _infer_eager(self, left, right):
     self.feature_net.eval(); self.stereo_net.eval()
-    fl, fr = self.feature_net(left), self.feature_net(right)
-    out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+    self.infer_plan.begin()
+    try:
+      fl, fr = self.feature_net(left), self.feature_net(right)
+      out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
+    finally:
+      self.infer_plan.end()
     fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
     return out, fcs
+
+  @torch.no_grad()
+  def capture_infer(self, left, right, warmup=2):
+    """Captures the eval-mode forward (~75 launches) into a hipGraph; infer() replays it from then on.  The graph
+    reads the weights where they live (the flat arena), so it stays valid across adaptation steps."""
+    self._infer_left, self._infer_right = left.clone(), right.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(max(2, warmup)):          # the first call records the plan, the second runs it
+        self._infer_eager(self._infer_left, self._infer_right)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      self._infer_result = self._infer_eager(self._infer_left, self._infer_right)
+    self._infer_graph = graph
+    return self
 
   # -- one adaptation step: adapt.py:304-396 (NONSTOP) --------------------------------------------
   def step(self, left, right):

@@ -135,6 +135,9 @@ class StepPlan(object):
     self.ready = False
     self._rec_pack = {}        # (data_ptr, taps, flip) -> (weight tensor, ConvShape)
     self._rec_bn = {}          # id(bn module) -> [bn module, count]
+    self._rec_affine = {}      # gamma.data_ptr() -> (gamma, beta, running_mean, running_var)   (eval-mode layers)
+    self._affine_states = {}
+    self._affine_jobs = None
     self._views = {}
     self._jobs = None
     self._bn_index = {}
@@ -147,6 +150,14 @@ class StepPlan(object):
       self._rec_pack[key] = (w, shape)
       return None
     return self._views.get(key)
+
+  # -- eval-mode BatchNorm affines -------------------------------------------------------------------
+  def eval_affine(self, gamma, beta, running_mean, running_var):
+    key = gamma.data_ptr()
+    if not self.ready:
+      self._rec_affine[key] = (gamma, beta, running_mean, running_var)
+      return None
+    return self._affine_states.get(key)
 
   # -- batch counters --------------------------------------------------------------------------------
   def count(self, bn):
@@ -172,6 +183,8 @@ class StepPlan(object):
     if self.ready:
       if self._jobs is not None:
         call("as_conv32_pack_weights_batch", ptr(self._jobs), self._njobs, self._max_taps, stream())
+      if self._affine_jobs is not None:
+        call("as_bn_eval_affine_batch", ptr(self._affine_jobs), len(self._affine_states), BN_EPS, stream())
       self._pending = [0] * len(self._bn_index)
 
   def end(self, final=True):
@@ -212,6 +225,15 @@ class StepPlan(object):
       self._jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
       self._njobs = len(self._rec_pack)
       self._max_taps = max(k[1] for k in self._rec_pack)
+    if self._rec_affine:
+      dev = next(iter(self._rec_affine.values()))[0].device
+      self._affine_buf = torch.empty(len(self._rec_affine), 4, 32, dtype=torch.float32, device=dev)
+      blob = b""
+      for i, (key, (ga, be, rm, rv)) in enumerate(self._rec_affine.items()):
+        self._affine_states[key] = BnState(dev, self._affine_buf[i])
+        blob += struct.pack("<QQQQQ", ga.data_ptr(), be.data_ptr(), rm.data_ptr(), rv.data_ptr(), self._affine_buf[i].data_ptr())
+      self._affine_keep = list(self._rec_affine.values())        # keep the storages alive
+      self._affine_jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
     if self._rec_bn:
       mods = [m for m, _ in self._rec_bn.values()]
       dev = mods[0].num_batches_tracked.device
@@ -282,8 +304,9 @@ class BnState(object):
   """Per-layer BatchNorm scalars living on the device: scale/shift (the affine the
   activation pass applies) and mean/invstd (what backward needs)."""
 
-  def __init__(self, device):
-    buf = torch.empty(4, 32, dtype=torch.float32, device=device)
+  def __init__(self, device, buf=None):
+    if buf is None:
+      buf = torch.empty(4, 32, dtype=torch.float32, device=device)
     self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
 
 
@@ -296,6 +319,11 @@ def bn_train_stats(stats: StatParts, gamma, beta, running_mean, running_var):
 
 
 def bn_eval_stats(gamma, beta, running_mean, running_var):
+  plan = _ACTIVE_PLAN
+  if plan is not None:
+    hit = plan.eval_affine(gamma, beta, running_mean, running_var)
+    if hit is not None:
+      return hit
   st = BnState(gamma.device)
   call("as_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS,
        ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream())

@@ -125,6 +125,19 @@ __device__ inline f32x4 lrelu4(f32x4 y, f32x4 v, float slope) {   // v where y >
   return r;
 }
 
+// every eval-mode layer of a forward pass in one launch (the job table lives on the device, built once)
+__global__ void bn_eval_affine_batch_kernel(const as_bn_affine_job* __restrict__ jobs, float eps) {
+  const as_bn_affine_job j = jobs[blockIdx.x];
+  const int c = threadIdx.x;
+  if (c >= 32) return;
+  const float invstd = 1.0f / sqrtf(j.running_var[c] + eps);
+  const float sc = invstd * j.gamma[c];
+  j.out[c] = j.running_mean[c];
+  j.out[32 + c] = invstd;
+  j.out[64 + c] = sc;
+  j.out[96 + c] = j.beta[c] - j.running_mean[c] * sc;
+}
+
 // ---- a = lrelu(z*scale + shift) (+ residual), interior only -------------------------
 template <bool RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
@@ -307,6 +320,13 @@ extern "C" int as_bn_eval_affine(const float* gamma, const float* beta, const fl
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean,
                      running_var, eps, save_mean, save_invstd, scale, shift);
   AS_CHECK_LAUNCH("as_bn_eval_affine");
+  return AS_OK;
+}
+
+extern "C" int as_bn_eval_affine_batch(const as_bn_affine_job* jobs, int njobs, float eps, void* stream) {
+  AS_CHECK_ARG(jobs && njobs >= 1 && njobs <= 65535, "as_bn_eval_affine_batch: bad job table");
+  hipLaunchKernelGGL(bn_eval_affine_batch_kernel, dim3(njobs), dim3(64), 0, (hipStream_t)stream, jobs, eps);
+  AS_CHECK_LAUNCH("as_bn_eval_affine_batch");
   return AS_OK;
 }
 

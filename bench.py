@@ -197,6 +197,9 @@ def main():
   # ---- forward only --------------------------------------------------------------------------
   for _ in range(max(1, args.warmup // 2)):
     adapter.infer(left, right)
+  if use_graph:
+    adapter.capture_infer(left, right)
+    adapter.infer(left, right)
   torch.cuda.synchronize()
   log("warm-up forward done")
   t_fwd = timed(lambda: adapter.infer(left, right), args.steps, world)

@@ -130,6 +130,15 @@ int as_bn_finalize(const float* stat_mean, const float* stat_m2, const float* st
 int as_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* save_mean, float* save_invstd,
                       float* scale, float* shift, void* stream);
+/* as_bn_eval_affine for many layers in one launch; `jobs` is a DEVICE array, out = [mean, invstd, scale, shift][32]. */
+typedef struct as_bn_affine_job {
+  const float* gamma;
+  const float* beta;
+  const float* running_mean;
+  const float* running_var;
+  float* out;
+} as_bn_affine_job;
+int as_bn_eval_affine_batch(const as_bn_affine_job* jobs, int njobs, float eps, void* stream);
 int as_bn_act_fwd(const float* z, const float* scale, const float* shift, float slope,
                   const float* residual, float* a, const as_pcl* g, void* stream);
 int64_t as_bn_bwd_workspace(const as_pcl* g);

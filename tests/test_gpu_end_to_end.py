@@ -329,3 +329,37 @@ def test_three_adaptation_steps_follow_the_oracle():
       assert diff <= tol, (name, key, diff, tol)
     bad = [kk for kk in sd if kk not in ref_p]
     assert not bad, bad
+
+
+def test_inference_plan_and_graph_equal_plain_forward():
+  """infer(): the recorded plan (one weight-packing launch, one launch for all BatchNorm affines) and the captured
+  hipGraph must reproduce the plain eval forward bit for bit — also after the weights and the BatchNorm running
+  statistics have moved (the graph reads them where they live)."""
+  meta = dict(k=4, s=0, maxdisp=192, gain=5.0)
+  H, W, B = 96, 256, 2
+  fnet, snet = build(meta)
+  adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-3)          # large lr: the step must visibly change the output
+  l1, r1 = (t.to(DEV) for t in syn.stereo_pair(B, H, W, seed=51))
+  l2, r2 = (t.to(DEV) for t in syn.stereo_pair(B, H, W, seed=52))
+
+  def plain(l, r):
+    fnet.eval(); snet.eval()
+    with torch.no_grad():
+      out = snet(l, fnet(l), fnet(r), "l", output_cost_volume=True)
+    return out["pred_disp_l/0"].clone(), out["cost_volume_l/4"].clone()
+
+  ref_pred, ref_logits = plain(l1, r1)
+  for _ in range(3):                                           # 1st call records the plan, later ones use it
+    out, fcs = adapter.infer(l1, r1)
+    assert torch.equal(out["pred_disp_l/0"], ref_pred) and torch.equal(out["cost_volume_l/4"], ref_logits)
+  assert adapter.infer_plan.ready
+  adapter.capture_infer(l1, r1)
+  out, fcs = adapter.infer(l1, r1)
+  assert torch.equal(out["pred_disp_l/0"], ref_pred)
+  adapter.step(l2, r2)                                         # weights and running statistics change
+  new_pred, new_logits = plain(l2, r2)
+  assert float((new_pred - plain(l2, r2)[0]).abs().max()) == 0.0
+  out, fcs = adapter.infer(l2, r2)                             # graph replay on other inputs, new weights
+  assert torch.equal(out["pred_disp_l/0"], new_pred) and torch.equal(out["cost_volume_l/4"], new_logits)
+  stale_pred, _ = ref_pred, None
+  assert not torch.equal(plain(l1, r1)[0], stale_pred), "the adaptation step should have changed the network"
