@@ -181,7 +181,7 @@ class OnlineAdapter(object):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
       self._infer_result = self._infer_eager(self._infer_left, self._infer_right)
     self._infer_graph = graph
     return self
@@ -299,7 +299,8 @@ class OnlineAdapter(object):
   # -- hipGraph capture of the whole step ------------------------------------------------------------
   def capture(self, left, right, warmup=3):
     """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~360 kernel launches) into
-    hipGraphs and replays them from then on.  Every entry point of the C ABI only enqueues work on the current
+    hipGraphs and replays them from then on.  (capture_error_mode="thread_local": the process-group watchdog thread
+    queries events while a capture is open; only this thread's calls have to be capture-safe.)  Every entry point of the C ABI only enqueues work on the current
     stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the device.  Inputs
     are copied into static buffers before each replay.
     One GPU: a single graph.  Data parallel: three graphs (forward + local sums | backward | clip + Adam + EMA)
@@ -315,7 +316,7 @@ class OnlineAdapter(object):
     self.optimizer.step_count_at_capture = self.optimizer.step_count
     if self.world == 1:
       graph = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(graph):
+      with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         self._static_result = self._step_eager(self._static_left, self._static_right)
       self._graph = graph
     else:
@@ -323,7 +324,7 @@ class OnlineAdapter(object):
         dist.barrier(group=self.pg)
       cap = torch.cuda.Stream()          # forward and backward must be captured on the same stream (autograd
       g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()   # replays backward there)
-      with torch.cuda.graph(g1, stream=cap):
+      with torch.cuda.graph(g1, stream=cap, capture_error_mode="thread_local"):
         self.feature_net.train(); self.stereo_net.train()
         self.arena.rebind_grads()
         self.arena.zero_grads()
@@ -336,7 +337,7 @@ class OnlineAdapter(object):
       torch.cuda.synchronize()
       dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
       torch.cuda.synchronize()
-      with torch.cuda.graph(g2, pool=g1.pool(), stream=cap):
+      with torch.cuda.graph(g2, pool=g1.pool(), stream=cap, capture_error_mode="thread_local"):
         self.plan.begin(resume=True)
         try:
           self._dp_backward(total, m8)
@@ -345,7 +346,7 @@ class OnlineAdapter(object):
       torch.cuda.synchronize()
       allreduce_gradients(self.arena.grads, self.pg)
       torch.cuda.synchronize()
-      with torch.cuda.graph(g3, pool=g1.pool(), stream=cap):
+      with torch.cuda.graph(g3, pool=g1.pool(), stream=cap, capture_error_mode="thread_local"):
         loss, fcs = self._dp_results()
         self.optimizer.step(clip=self.clip)
         self.fcs_smoothed.mul_(self.fcs_ema_weight).add_(fcs.detach(), alpha=1.0 - self.fcs_ema_weight)
