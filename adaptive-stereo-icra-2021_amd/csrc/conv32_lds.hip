@@ -403,6 +403,7 @@ struct WgradLdsArgs {
   int dil, tiles_per_row, ntiles, tiles_per_band, wg_per_xcd;
 };
 
+template <int NW>
 __device__ inline void issue_wgrad_dma(const WgradLdsArgs& p, int tile, unsigned lds_x, unsigned lds_g, int wave,
                                        unsigned lane16) {
   const int row = tile / p.tiles_per_row;
@@ -416,16 +417,16 @@ __device__ inline void issue_wgrad_dma(const WgradLdsArgs& p, int tile, unsigned
   for (int r = 0; r < 3; ++r) {
     const float* srow = xrow0 + r * row_stride;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int i = wave + 4 * k;
+    for (int k = 0; k < (TL_DMA_PER_ROW + NW - 1) / NW; ++k) {
+      const int i = wave + NW * k;
       if (i < TL_DMA_PER_ROW)
         dma_1kb(srow + (long)min(px0 + 8 * i, Wp - 8) * 32, lane16, lds_x + (unsigned)((r * TL_W + 8 * i) * 128));
     }
   }
   const float* grow = p.gz + (((long)b * p.gout.Hp + (y + p.gout.ph)) * p.gout.Wp + p.gout.pw) * 32;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = wave + 4 * k;
+  for (int k = 0; k < 16 / NW; ++k) {
+    const int i = wave + NW * k;
     dma_1kb(grow + (long)min(x0 + 8 * i, p.gout.W) * 32, lane16, lds_g + (unsigned)(8 * i * 128));
   }
 }
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wgrad_lds_kernel(WgradLdsArgs p
   const int t_begin = xcd * p.tiles_per_band;
   const int t_end = min(t_begin + p.tiles_per_band, p.ntiles);
   for (int tile = t_begin + j; tile < t_end; tile += p.wg_per_xcd) {
-    issue_wgrad_dma(p, tile, lds_x, lds_g, wave, lane16);
+    issue_wgrad_dma<4>(p, tile, lds_x, lds_g, wave, lane16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // this wave's 32 voxels of the segment: 16 steps of one voxel pair (lane half h picks the voxel)
@@ -517,7 +518,110 @@ __global__ __launch_bounds__(256, 2) void conv32_wgrad_lds_kernel(WgradLdsArgs p
   if (threadIdx.x < 32) p.partial_db[blockIdx.x * 32 + li] = dbs[li] + dbs[32 + li] + dbs[64 + li] + dbs[96 + li];
 }
 
+
+// Double-buffered form for launches that fill the chip: ONE 8-wave workgroup per CU, two tile buffers (143 KB of
+// LDS), the DMA of tile i+1 in flight while tile i is multiplied, one barrier per tile.  A wave takes 16 of the
+// segment's voxels (8 steps of one voxel pair) for all nine taps.
+#define TLW2_LDS_BYTES (2 * TLW_LDS_BYTES)
+__global__ __launch_bounds__(512, 1) void conv32_wgrad_lds2_kernel(WgradLdsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_ptr_t)smem));
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const char* gaddr0 = smem + TL_BUF_BYTES + (16 * wave + h) * 128 + li * 4;
+  const char* xaddr0[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) xaddr0[kx] = smem + (16 * wave + h + 8 + (kx - 1) * p.dil) * 128 + li * 4;
+
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int t_begin = xcd * p.tiles_per_band;
+  const int t_end = min(t_begin + p.tiles_per_band, p.ntiles);
+  int tile = t_begin + j;
+  if (tile < t_end) issue_wgrad_dma<8>(p, tile, lds0, lds0 + TL_BUF_BYTES, wave, lane16);
+  int cur = 0;
+  for (; tile < t_end; tile += p.wg_per_xcd, cur ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the current tile
+    __syncthreads();                                      // everybody's share landed; everybody is done with the other buffer
+    const int next = tile + p.wg_per_xcd;
+    if (next < t_end) {
+      const unsigned nb = lds0 + (unsigned)((cur ^ 1) * TLW_LDS_BYTES);
+      issue_wgrad_dma<8>(p, next, nb, nb + TL_BUF_BYTES, wave, lane16);
+    }
+    const char* gaddr = gaddr0 + cur * TLW_LDS_BYTES;
+    const char* xaddr[3] = {xaddr0[0] + cur * TLW_LDS_BYTES, xaddr0[1] + cur * TLW_LDS_BYTES, xaddr0[2] + cur * TLW_LDS_BYTES};
+    float bv[2], av[2][9];
+    bv[0] = *reinterpret_cast<const float*>(gaddr);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) av[0][t] = *reinterpret_cast<const float*>(xaddr[t % 3] + (t / 3) * TL_ROW_BYTES);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s + 1 < 8) {
+        bv[(s + 1) & 1] = *reinterpret_cast<const float*>(gaddr + (s + 1) * 256);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          av[(s + 1) & 1][t] = *reinterpret_cast<const float*>(xaddr[t % 3] + (t / 3) * TL_ROW_BYTES + (s + 1) * 256);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bsum += bv[s & 1];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][t], bv[s & 1], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+
+  // reduce the eight waves' accumulators through LDS, three taps per round (fixed order w0 + w1 + .. + w7)
+  float* slab = reinterpret_cast<float*>(smem);           // [7 waves][3 taps][16][64] floats = 86,016 B
+  float* out = p.partial + (long)blockIdx.x * 9 * 1024;
+#pragma unroll
+  for (int round = 0; round < 3; ++round) {
+    if (wave > 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(((wave - 1) * 3 + g) * 16 + r) * 64 + lane] = acc[round * 3 + g][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[round * 3 + g][r];
+#pragma unroll
+          for (int w2 = 0; w2 < 7; ++w2) v += slab[((w2 * 3 + g) * 16 + r) * 64 + lane];
+          const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+          out[(round * 3 + g) * 1024 + ci * 32 + li] = v;
+        }
+    }
+    __syncthreads();
+  }
+  float* dbs = reinterpret_cast<float*>(smem);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) dbs[wave * 32 + li] = bsum;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float sdb = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < 8; ++w2) sdb += dbs[w2 * 32 + li];
+    p.partial_db[blockIdx.x * 32 + li] = sdb;
+  }
+}
+
+static bool wgrad_lds2(const as_pcl* gout) { return lds_ntiles(gout) >= 256 * 16; }   // the launch fills the chip
+
 int conv32_wgrad_lds_slabs(const as_pcl* gout) {
+  if (wgrad_lds2(gout)) return 256;                      // one double-buffered 8-wave workgroup per CU
   // every workgroup ends with a 36 KB slab (+ its share of the final reduce): give each at least 16 tiles
   const int nt = lds_ntiles(gout);
   int g = ((nt + 15) / 16 + 7) / 8 * 8;
@@ -531,8 +635,11 @@ int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, 
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, TLW_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds2_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, TLW2_LDS_BYTES);
     if (e != hipSuccess) {
-      as_set_error("conv32_wgrad_lds: cannot reserve %d bytes of LDS: %s", TLW_LDS_BYTES, hipGetErrorString(e));
+      as_set_error("conv32_wgrad_lds: cannot reserve %d bytes of LDS: %s", TLW2_LDS_BYTES, hipGetErrorString(e));
       return AS_ERR_LAUNCH;
     }
     attr_set = true;
@@ -546,7 +653,10 @@ int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, 
   const int grid = conv32_wgrad_lds_slabs(gout);
   a.tiles_per_band = (a.ntiles + 7) / 8;
   a.wg_per_xcd = grid / 8;
-  hipLaunchKernelGGL(conv32_wgrad_lds_kernel, dim3(grid), dim3(256), TLW_LDS_BYTES, (hipStream_t)stream, a);
+  if (wgrad_lds2(gout))
+    hipLaunchKernelGGL(conv32_wgrad_lds2_kernel, dim3(grid), dim3(512), TLW2_LDS_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv32_wgrad_lds_kernel, dim3(grid), dim3(256), TLW_LDS_BYTES, (hipStream_t)stream, a);
   AS_CHECK_LAUNCH("as_conv32_wgrad(lds)");
   return AS_OK;
 }

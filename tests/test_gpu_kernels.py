@@ -81,6 +81,8 @@ CONV_CASES = [
   (1, 1, 23, 257, ConvShape(1, 3, 3, 0, 4, 4, 4, 1), (0, 8, 8)),
   (3, 1, 130, 131, ConvShape(1, 3, 3, 0, 8, 8, 8, 1), (0, 8, 8)),
   (1, 1, 375, 1242, ConvShape(1, 3, 3, 0, 2, 2, 2, 1), (0, 8, 8)),
+  # >= 4096 row segments: the double-buffered one-workgroup-per-CU weight-gradient kernel, ragged last segment
+  (1, 1, 421, 1250, ConvShape(1, 3, 3, 0, 4, 4, 4, 1), (0, 8, 8)),
 ]
 
 
