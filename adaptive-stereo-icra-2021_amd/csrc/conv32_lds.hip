@@ -2,24 +2,27 @@
 // 32->32 layers and their data gradients — 83 % of the model's FLOPs (stereo_net.py:10-18, 33-51, 97).
 //
 // MI355X design
-//   * persistent workgroups, TWO per CU (8 waves = two per SIMD), walk 128-pixel row segments;
+//   * persistent workgroups, TWO per CU (8 waves = two per SIMD), walk 128-pixel row segments; the last segment
+//     of a row is shifted left to end at W, so every tile is 128 valid voxels (no ragged-edge code);
 //   * the 3 input rows a segment needs (y-d, y, y+d; x0-8 .. x0+135) are DMA'd into LDS
-//     (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR round trip): HBM/L2 sees each
-//     input voxel 3 times per layer instead of 9, as full 128-byte lines;
-//   * one tile buffer per workgroup: while one workgroup waits for its DMA or runs its epilogue
-//     (stores, residual, BatchNorm moments) the other one owns the matrix cores — the overlap comes
-//     from the second workgroup, not from double buffering.  (A double-buffered single-workgroup
-//     variant with LDS-resident weights measured 69 TFLOP/s: hipcc places vmcnt(0) waits in the
-//     compute phase that also drain an in-flight DMA, and the epilogue is fully exposed.)
+//     (global_load_lds_dwordx4: 1 KB per wave instruction, scalar base + constant lane offset): HBM sees each
+//     input voxel once per layer (the two re-reads by neighbouring rows hit L2);
+//   * one tile buffer per workgroup: while one workgroup waits for its DMA or runs its epilogue the other one owns
+//     the matrix cores — the overlap comes from the second workgroup, not from double buffering;
 //   * LDS image is lane-linear (a DMA cannot pad), so bank conflicts are removed by swizzling the
 //     SOURCE: LDS slot s of voxel v holds channel chunk s ^ ((v>>1)&7); a ds_read_b128 of one chunk
 //     from 16 consecutive voxels then hits 16 distinct 16-byte bank groups;
-//   * weights are read from L2 in the [tap][q][lane][4] packing: every wave load is one contiguous KB;
+//   * the weights' B fragments stay in registers for the whole launch (7-9 of 9 taps, the rest re-read from L2
+//     48 MFMAs ahead of use); activations come through a 4-deep ring of ds_read_b128;
+//   * vector-ALU instructions of one wave do not overlap the MFMAs of the other wave on a SIMD (measured: the times
+//     add), so the per-tile path carries almost none: DMA, output stores and residual loads are scalar base +
+//     constant lane offset + immediate (inline asm, which also keeps hipcc from draining them with vmcnt(0)),
+//     retired by counted waits; BatchNorm moments are per-lane shifted sums (no barrier, no LDS in the loop);
 //   * tiles are banded per XCD (workgroup b is on XCD b%8 under round-robin dispatch — speed only):
 //     the three uses of an input row happen close in time on one XCD's L2;
-//   * BatchNorm moments of a workgroup's tiles are Chan-merged in registers: one partial per
-//     workgroup (512 per layer instead of 15,000).
-// LDS per workgroup: 55,296 (tile) + 640; two workgroups per CU use 112 KB of the CU's 160 KB.
+//   * one BatchNorm partial per workgroup (512 per layer instead of 15,000).
+// LDS per workgroup: 55,296 (tile) + 1,024; two workgroups per CU use 112 KB of the CU's 160 KB.
+// Measured (4 pairs, 375x1242): 116-121 TFLOP/s forward, 106-114 with the skip connection.
 #include "as_common.h"
 #include "conv_epilogue.h"
 #include "conv32_lds.h"

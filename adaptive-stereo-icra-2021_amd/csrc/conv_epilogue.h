@@ -5,7 +5,7 @@
 #pragma once
 #include "as_common.h"
 
-// 64 floats that swallow the stores of invalid rows when a kernel needs an exact store count per wave
+// 64 floats that swallow stores a kernel issues only to keep its per-wave store count exact (conv4_mfma.hip)
 static __device__ float as_store_dump[64];     // one copy per translation unit (no relocatable device code)
 
 struct EpilogueArgs {
@@ -41,9 +41,6 @@ __device__ inline void stats_merge(TileStats& run, const TileStats& t) {
 
 // red: [4][32] floats, bmean: [32] floats of LDS.  All 256 threads of the workgroup must call.
 // nvalid = number of valid voxels in this workgroup's tile.  ts (may be null) receives the tile's moments.
-// UNIFORM_STORES: every wave issues exactly 16 store instructions (invalid rows go to as_store_dump), so a
-// caller can leave them in flight behind a counted "s_waitcnt vmcnt(16)".
-template <bool UNIFORM_STORES = false>
 __device__ inline void conv_epilogue(const f32x16& acc, const EpilogueArgs& e, int out_vox, bool valid, int nvalid,
                                      float (*red)[32], float* bmean, TileStats* ts) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -73,12 +70,7 @@ __device__ inline void conv_epilogue(const f32x16& acc, const EpilogueArgs& e, i
     for (int r = 0; r < 16; ++r) {
       float yv = acc[r] * sc + sh;
       yv = yv > 0.f ? yv : yv * e.slope;
-      if (UNIFORM_STORES) {
-        float* dst = rv[r] ? e.z + (long)ov[r] * 32 + li : as_store_dump + lane;
-        *dst = yv + res[r];
-      } else if (rv[r]) {
-        e.z[(long)ov[r] * 32 + li] = yv + res[r];
-      }
+      if (rv[r]) e.z[(long)ov[r] * 32 + li] = yv + res[r];
     }
     return;
   }
@@ -86,11 +78,7 @@ __device__ inline void conv_epilogue(const f32x16& acc, const EpilogueArgs& e, i
   float s1 = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    if (UNIFORM_STORES) {
-      float* dst = rv[r] ? e.z + (long)ov[r] * 32 + li : as_store_dump + lane;
-      *dst = acc[r] + res[r];
-      s1 += rv[r] ? acc[r] : 0.f;
-    } else if (rv[r]) {
+    if (rv[r]) {
       e.z[(long)ov[r] * 32 + li] = acc[r] + res[r];
       s1 += acc[r];
     }
