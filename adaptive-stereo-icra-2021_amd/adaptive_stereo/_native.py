@@ -64,6 +64,11 @@ _SIGNATURES = {
   "as_bn_bwd_workspace": (c_i64, [_P(Pcl)]),
   "as_bn_act_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_int, c_vp,
                             _P(Pcl), c_vp]),
+  "as_bn_act_bwd_given": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_int, c_vp,
+                                  _P(Pcl), c_int, c_vp]),
+  "as_conv32_bnbwd_parts": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
+  "as_conv32_fwd_bnbwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float,
+                                  c_vp, c_vp]),
   "as_conv3d_out_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp]),
   "as_conv3d_out_bwd_workspace": (c_i64, [_P(Pcl)]),
   "as_conv3d_out_bwd": (c_int, [c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),

@@ -336,19 +336,44 @@ def bn_act(z, st: BnState, g: Pcl, residual=None, out=None):
   return a
 
 
-def bn_act_bwd(g_a, z, st: BnState, gamma, g: Pcl, train: bool, sink_gamma=None, sink_beta=None):
+class BnBwdSums(object):
+  """Stage 1 of a BatchNorm backward (per-channel sums) that a fused producer has already left in a workspace."""
+
+  def __init__(self, workspace, nparts):
+    self.workspace, self.nparts = workspace, nparts
+
+
+def bn_act_bwd(g_a, z, st: BnState, gamma, g: Pcl, train: bool, sink_gamma=None, sink_beta=None, sums=None):
   lib = nat.load()
   dev = z.device
   g_z = POOL.get(g, dev)
-  ws = _empty(lib.as_bn_bwd_workspace(g), dev)
+  ws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
+  fn = "as_bn_act_bwd_given" if sums is not None else "as_bn_act_bwd"
+  tail = (ptr(ws), g, sums.nparts, stream()) if sums is not None else (ptr(ws), g, stream())
   if sink_gamma is not None and sink_beta is not None:
-    call("as_bn_act_bwd", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-         LEAKY_SLOPE, int(train), ptr(g_z), ptr(sink_gamma), ptr(sink_beta), 1, ptr(ws), g, stream())
+    call(fn, ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+         LEAKY_SLOPE, int(train), ptr(g_z), ptr(sink_gamma), ptr(sink_beta), 1, *tail)
     return g_z, None, None
   g_gamma, g_beta = _empty(32, dev), _empty(32, dev)
-  call("as_bn_act_bwd", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-       LEAKY_SLOPE, int(train), ptr(g_z), ptr(g_gamma), ptr(g_beta), 0, ptr(ws), g, stream())
+  call(fn, ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+       LEAKY_SLOPE, int(train), ptr(g_z), ptr(g_gamma), ptr(g_beta), 0, *tail)
   return g_z, g_gamma, g_beta
+
+
+def conv32_dgrad_bnbwd(g_z, g: Pcl, wp_t, shape: ConvShape, residual, next_z, next_st: BnState):
+  """g_x = dgrad(g_z) (+ residual) fused with stage 1 of the BatchNorm backward of the layer whose output gradient
+  g_x is (pre-activation next_z, statistics next_st).  Returns (g_x, BnBwdSums) or None when the configuration has no
+  fused kernel."""
+  lib = nat.load()
+  nparts = lib.as_conv32_bnbwd_parts(g, g, shape)
+  if nparts <= 0:
+    return None
+  dev = g_z.device
+  g_x = POOL.get(g, dev)
+  ws = _empty(lib.as_bn_bwd_workspace(g), dev)
+  call("as_conv32_fwd_bnbwd", ptr(g_z), g, ptr(wp_t), ptr(g_x), g, shape, ptr(residual), ptr(next_z), ptr(next_st.scale),
+       ptr(next_st.shift), ptr(next_st.mean), LEAKY_SLOPE, ptr(ws), stream())
+  return g_x, BnBwdSums(ws, nparts)
 
 
 # ----------------------------------------------------------------------------------------
@@ -383,19 +408,29 @@ def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train,
   return z, a, st
 
 
-def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx, sinks=None):
-  """g_out: gradient w.r.t. the block output (PCL).  Returns (g_x or None, dW, db, g_gamma, g_beta).
+def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx, sinks=None,
+                   sums=None, next_bn=None):
+  """g_out: gradient w.r.t. the block output (PCL).  Returns (g_x or None, dW, db, g_gamma, g_beta, next_sums).
   With a skip connection g_x = g_out + dgrad(...) — the add is fused into the dgrad epilogue.
-  ``sinks`` = (w, b, gamma, beta) accumulation targets; sunk gradients come back as None."""
+  ``sinks`` = (w, b, gamma, beta) accumulation targets; sunk gradients come back as None.
+  ``sums``: stage 1 of this block's BatchNorm backward, if the producer of g_out already computed it;
+  ``next_bn`` = (z, BnState) of the layer whose output gradient g_x is: its stage 1 is then fused into this block's
+  data gradient and returned as next_sums (None when not available)."""
   sw, sb, sg, sbeta = sinks if sinks is not None else (None, None, None, None)
-  g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta)
+  g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta, sums)
   dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
-  g_x = None
+  g_x, next_sums = None, None
   if need_dx:
     wp_t = pack_weights(w, shape, True)
-    g_x = conv32(g_z, g, wp_t, None, g, shape, residual=g_out if skip else None)
+    fused = None
+    if next_bn is not None and train:
+      fused = conv32_dgrad_bnbwd(g_z, g, wp_t, shape, g_out if skip else None, next_bn[0], next_bn[1])
+    if fused is not None:
+      g_x, next_sums = fused
+    else:
+      g_x = conv32(g_z, g, wp_t, None, g, shape, residual=g_out if skip else None)
   POOL.put(g_z, g)
-  return g_x, dW, db, g_gamma, g_beta
+  return g_x, dW, db, g_gamma, g_beta, next_sums
 
 
 # ----------------------------------------------------------------------------------------
@@ -480,9 +515,9 @@ class CostAggregationFn(torch.autograd.Function):
     need_feat = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
     for l in range(3, -1, -1):
       w, b, gamma, beta = params[4 * l:4 * l + 4]
-      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], w, gamma, g, CONV3D_333, ctx.train,
-                                                    False, l > 0 or need_feat,
-                                                    sinks[4 * l:4 * l + 4] if sinks is not None else None)
+      g_x, dW, db, g_gamma, g_beta, _ = block_backward(g_a, xs[l], zs[l], sts[l], w, gamma, g, CONV3D_333, ctx.train,
+                                                       False, l > 0 or need_feat,
+                                                       sinks[4 * l:4 * l + 4] if sinks is not None else None)
       grads[4 * l:4 * l + 4] = [dW, db, g_gamma, g_beta]
       POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
       g_a = g_x
@@ -596,7 +631,7 @@ class FeatureExtractorFn(torch.autograd.Function):
     POOL.put(g_out, g)
     for l in range(5, -1, -1):
       wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
-      g_x, dW, db, g_gamma, g_beta = block_backward(
+      g_x, dW, db, g_gamma, g_beta, _ = block_backward(
           g_a, xs[l], zs[l], sts[l], wl, gamma, g, shape, ctx.train, True, True,
           sinks[2 * k + 4 * l:2 * k + 4 * l + 4] if sinks is not None else None)
       grads[2 * k + 4 * l:2 * k + 4 * l + 4] = [dW, db, g_gamma, g_beta]
@@ -743,18 +778,23 @@ class EdgeRefineFn(torch.autograd.Function):
            ptr(ws), stream())
       grads[28], grads[29] = g_wout, g_bout
 
+    sums = None
     for l in range(5, -1, -1):
       wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
-      g_x, dW, db, g_gamma, g_beta = block_backward(g_a, xs[l], zs[l], sts[l], wl, gamma, g,
-                                                    conv_shape_2d(REFINE_DILATIONS[l]), ctx.train, True, True,
-                                                    sinks[4 + 4 * l:8 + 4 * l] if sinks is not None else None)
+      # the data gradient of block l is the output gradient of block l-1 (or of conv2d_feature): stage 1 of that
+      # layer's BatchNorm backward rides on the data-gradient kernel
+      next_bn = (zs[l - 1], sts[l - 1]) if l > 0 else (ctx.z0, ctx.st0)
+      g_x, dW, db, g_gamma, g_beta, sums = block_backward(g_a, xs[l], zs[l], sts[l], wl, gamma, g,
+                                                          conv_shape_2d(REFINE_DILATIONS[l]), ctx.train, True, True,
+                                                          sinks[4 + 4 * l:8 + 4 * l] if sinks is not None else None,
+                                                          sums, next_bn)
       grads[4 + 4 * l:8 + 4 * l] = [dW, db, g_gamma, g_beta]
       POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
       g_a = g_x
 
     # conv2d_feature backward
     w0, b0, gamma0, beta0 = params[0:4]
-    g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train, _sink(sinks, 2), _sink(sinks, 3))
+    g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train, _sink(sinks, 2), _sink(sinks, 3), sums)
     ws4 = _empty(lib.as_conv4_wgrad_workspace(g, s33), dev)
     if _sink(sinks, 0) is not None and _sink(sinks, 1) is not None:
       call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())

@@ -361,10 +361,10 @@ extern "C" int64_t as_bn_bwd_workspace(const as_pcl* g) {
   return (int64_t)BNB_BLOCKS * 128 + 96 + 32;
 }
 
-extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const float* shift,
-                             const float* save_mean, const float* save_invstd, const float* gamma,
-                             float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
-                             float* workspace, const as_pcl* g, void* stream) {
+static int bn_act_bwd_impl(const float* g_a, const float* z, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_invstd, const float* gamma,
+                           float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
+                           float* workspace, const as_pcl* g, int nparts_given, void* stream) {
   AS_CHECK_ARG(as_pcl_ok(g), "as_bn_act_bwd: bad geometry");
   AS_CHECK_ARG(g_a && z && scale && shift && save_mean && save_invstd && gamma && g_z && g_gamma && g_beta && workspace,
                "as_bn_act_bwd: null pointer");
@@ -372,15 +372,18 @@ extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scal
   const long M = (long)g->B * g->D * g->H * g->W;
   const long nch = row_chunks(g);
   AS_CHECK_ARG(nch < (1L << 31), "as_bn_act_bwd: volume too large");
-  const int nb = bnb_blocks(nch), cpr = chunks_per_row(g);
+  AS_CHECK_ARG(nparts_given >= 0 && nparts_given <= BNB_BLOCKS, "as_bn_act_bwd_given: %d partials", nparts_given);
+  const int nb = nparts_given > 0 ? nparts_given : bnb_blocks(nch), cpr = chunks_per_row(g);
   double* partial = reinterpret_cast<double*>(workspace);
   float* coef = workspace + (int64_t)BNB_BLOCKS * 128;
   hipStream_t st = (hipStream_t)stream;
   const PclDev gd = as_make_dev(g);
   as_prof_mark(5, st, 1, 0.0);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g_a, z, scale, shift, save_mean, slope,
-                     partial, gd, (int)nch, cpr);
-  AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
+  if (nparts_given == 0) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g_a, z, scale, shift, save_mean, slope,
+                       partial, gd, (int)nch, cpr);
+    AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nb, M, save_invstd, gamma, train,
                      g_gamma, g_beta, coef, accumulate);
   AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
@@ -389,4 +392,22 @@ extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scal
   as_prof_mark(5, st, 0, 5.0 * 128.0 * (double)M);
   AS_CHECK_LAUNCH("as_bn_act_bwd(apply)");
   return AS_OK;
+}
+
+extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const float* shift,
+                             const float* save_mean, const float* save_invstd, const float* gamma,
+                             float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
+                             float* workspace, const as_pcl* g, void* stream) {
+  return bn_act_bwd_impl(g_a, z, scale, shift, save_mean, save_invstd, gamma, slope, train, g_z, g_gamma, g_beta,
+                         accumulate, workspace, g, 0, stream);
+}
+
+// Stage 1 (the per-channel sums) was already done by as_conv32_fwd_bnbwd: `workspace` holds `nparts` slabs.
+extern "C" int as_bn_act_bwd_given(const float* g_a, const float* z, const float* scale, const float* shift,
+                                   const float* save_mean, const float* save_invstd, const float* gamma,
+                                   float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
+                                   float* workspace, const as_pcl* g, int nparts, void* stream) {
+  AS_CHECK_ARG(nparts >= 1, "as_bn_act_bwd_given: nparts=%d", nparts);
+  return bn_act_bwd_impl(g_a, z, scale, shift, save_mean, save_invstd, gamma, slope, train, g_z, g_gamma, g_beta,
+                         accumulate, workspace, g, nparts, stream);
 }

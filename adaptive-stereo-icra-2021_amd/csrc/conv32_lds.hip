@@ -40,6 +40,12 @@ struct ConvLdsArgs {
   EpilogueArgs ep;
   PclDev gin, gout;
   int dil, tiles_per_row, ntiles, tiles_per_band, wg_per_xcd;
+  // MODE 3: stage 1 of the NEXT BatchNorm backward, fused (its g_a is this kernel's output)
+  const float* bn_z;       // PCL, output geometry: pre-activation of the layer whose output gradient this kernel writes
+  const float* bn_scale;   // [32] that layer's scale / shift / mean
+  const float* bn_shift;
+  const float* bn_mean;
+  double* bn_partial;      // [workgroups][64]: sum g_y, sum g_y*(z-mean) per channel (layout of bn_bwd_reduce_kernel)
 #ifdef AS_LDS_TRACE_BUILD
   unsigned long long* trace;           // diagnostic build only: [wg][32 tiles][8] 100-MHz timestamps
 #endif
@@ -129,9 +135,15 @@ __device__ inline void glb_load_w(f32x4 (&r)[4], const float* p) {
 // Kernel flavours (compile time, so that no path carries another one's waits):
 //   MODE 0: raw output + BatchNorm moments (training forward)   MODE 1: lrelu(acc*scale+shift) (eval forward)
 //   MODE 2: raw output, no moments (data gradients)             RES: + residual in the output geometry
+//   MODE 3: MODE 2 + stage 1 of the following BatchNorm backward: the output IS that layer's g_a, so the sums
+//           sum g_y and sum g_y*(z-mean), g_y = g_a * lrelu'(z*scale+shift), are taken from the register tile
+//           (saves bn_bwd_reduce_kernel's pass over g_a and z: 477 MB per full-resolution layer at 4 pairs)
 // Kernel flavours (compile time, so that no path carries another one's waits):
 //   MODE 0: raw output + BatchNorm moments (training forward)   MODE 1: lrelu(acc*scale+shift) (eval forward)
 //   MODE 2: raw output, no moments (data gradients)             RES: + residual in the output geometry
+//   MODE 3: MODE 2 + stage 1 of the following BatchNorm backward: the output IS that layer's g_a, so the sums
+//           sum g_y and sum g_y*(z-mean), g_y = g_a * lrelu'(z*scale+shift), are taken from the register tile
+//           (saves bn_bwd_reduce_kernel's pass over g_a and z: 477 MB per full-resolution layer at 4 pairs)
 template <int MODE, bool RES>
 __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,13 +165,15 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
   // (3 VALU per element, no barrier, no LDS in the tile loop); shift = the lane's first element, so the sums
   // stay small and  M2 = s2 - s1^2/n  loses nothing.  One Chan merge per workgroup at the end.
   float st_n = 0.f, st_c = 0.f, st_s1 = 0.f, st_s2 = 0.f;
+  float bn_sc = 0.f, bn_sh = 0.f, bn_mu = 0.f, bn_dy = 0.f, bn_dx = 0.f;
+  if (MODE == 3) { bn_sc = p.bn_scale[li]; bn_sh = p.bn_shift[li]; bn_mu = p.bn_mean[li]; }
   // DMA lane constant: voxel vl of an 8-voxel group, channel chunk swizzled by the voxel (see file header)
   const unsigned dma_lane_off =
       (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) << 4);
 
   // B fragments of taps 0..RESIDENT-1 stay in registers for the whole launch; the others do not fit next to
   // the rest of the working set and are re-read from L2 every tile, 48 MFMAs before their use.
-  constexpr int RESIDENT = RES ? 7 : (MODE == 0 ? 8 : 9);              // the residual tile needs 16 registers of its own
+  constexpr int RESIDENT = (RES ? 7 : (MODE == 0 ? 8 : 9)) - (MODE == 3 ? 3 : 0);              // the residual tile needs 16 registers of its own
   constexpr int W_LEAD = 12;                          // streamed taps are requested 12 chunks (48 MFMAs) ahead
   f32x4 w[9][4];
 #pragma unroll
@@ -182,6 +196,8 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
     const int vbase = 32 * wave + li + 8;
     float* z_base = p.ep.z + vox0 * 32;                 // wave-uniform
     const float* res_base = RES ? p.ep.residual + vox0 * 32 : nullptr;
+    const float* bnz_base = MODE == 3 ? p.bn_z + vox0 * 32 : nullptr;
+    float zt[16];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias_v;
@@ -217,6 +233,11 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
         AS_FOR_ROWS(AS_LD)
 #undef AS_LD
       }
+      if (MODE == 3 && c == 26) {      // the next layer's pre-activation tile (for its BatchNorm backward sums)
+#define AS_LD(r) load_imm<AS_ROW_IMM(r)>(zt[r], bnz_base, io_off);
+        AS_FOR_ROWS(AS_LD)
+#undef AS_LD
+      }
       __builtin_amdgcn_sched_barrier(0);
       const f32x4 av = a[c & 3], bv = w[c >> 2][c & 3];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
@@ -237,6 +258,12 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if (MODE == 3) {                   // same wait, the z tile as its operands (all loads are home by now)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(zt[0]), "+v"(zt[1]), "+v"(zt[2]), "+v"(zt[3]), "+v"(zt[4]), "+v"(zt[5]), "+v"(zt[6]),
+                     "+v"(zt[7]), "+v"(zt[8]), "+v"(zt[9]), "+v"(zt[10]), "+v"(zt[11]), "+v"(zt[12]),
+                     "+v"(zt[13]), "+v"(zt[14]), "+v"(zt[15]) :: "memory");
+    }
     __syncthreads();                   // every wave has read its operands: the tile buffer is free
     AS_TRACE(4);
     const int next_tile = tile + p.wg_per_xcd;
@@ -245,10 +272,16 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
     AS_TRACE(5);
 
     // ---- epilogue: exactly 16 store instructions per wave, nothing that waits on vector memory ----
+    const int dup3 = MODE == 3 ? x_new - xw : 0;          // rows below dup3 also belong to the neighbouring tile
 #define AS_ST(r) { float v = acc[r];                                                        \
                    if (MODE == 1) { v = v * sc + sh; v = fmaxf(v, v * p.ep.slope); }         \
                    if (RES) v += res[r];                                                      \
-                   store_imm<AS_ROW_IMM(r)>(z_base, io_off, v); }
+                   store_imm<AS_ROW_IMM(r)>(z_base, io_off, v);                               \
+                   if (MODE == 3) {                                                           \
+                     const float y = fmaf(zt[r], bn_sc, bn_sh);                               \
+                     float gy = y > 0.f ? v : v * p.ep.slope;                                 \
+                     if (dup3 > 0) gy = ((r & 3) + 8 * (r >> 2) + 4 * h) >= dup3 ? gy : 0.f; \
+                     bn_dy += gy; bn_dx = fmaf(gy, zt[r] - bn_mu, bn_dx); } }
     AS_FOR_ROWS(AS_ST)
 #undef AS_ST
     if (MODE == 0) {
@@ -273,6 +306,21 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
     if (p.trace && threadIdx.x == 0 && it == 0) p.trace[((long)blockIdx.x * 32) * 8 + 7] =
         ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
 #endif
+  }
+  if (MODE == 3) {
+    // lane sums -> one [64] slab per workgroup in the layout bn_bwd_finalize_kernel reads (fixed order)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* part = reinterpret_cast<float*>(smem);      // [8][2][32]
+    part[((wave * 2 + h) * 2 + 0) * 32 + li] = bn_dy;
+    part[((wave * 2 + h) * 2 + 1) * 32 + li] = bn_dx;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      double sum = 0.0;
+      for (int q = 0; q < 8; ++q) sum += (double)part[(q * 2 + which) * 32 + c];
+      p.bn_partial[(long)blockIdx.x * 64 + which * 32 + c] = sum;
+    }
   }
   if (MODE == 0 && p.ep.stat_mean != nullptr) {
     // lane sums -> (n, mean, M2) -> one partial per workgroup: 8 (wave, half) partials per channel, merged in
@@ -320,8 +368,11 @@ int conv32_lds_grid(const as_pcl* gout) {
 int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, const float* bias,
                       float* z, const as_pcl* gout, const as_conv_shape* s,
                       int epilogue, const float* ep_scale, const float* ep_shift, float slope,
-                      const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream) {
+                      const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt,
+                      const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                      double* bn_partial, void* stream) {
   ConvLdsArgs a;
+  a.bn_z = bn_z; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_partial = bn_partial;
   a.x = x; a.wq = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = residual;
   a.ep.stat_mean = epilogue == 0 ? stat_mean : nullptr; a.ep.stat_m2 = epilogue == 0 ? stat_m2 : nullptr;
@@ -335,13 +386,14 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
   a.tiles_per_band = (a.ntiles + 7) / 8;
   a.wg_per_xcd = grid / 8;
   hipStream_t st = (hipStream_t)stream;
-  const int mode = epilogue == 1 ? 1 : (a.ep.stat_mean != nullptr ? 0 : 2);
+  const int mode = bn_partial != nullptr ? 3 : (epilogue == 1 ? 1 : (a.ep.stat_mean != nullptr ? 0 : 2));
   const void* fn = nullptr;
 #define AS_LDS_PICK(M, R) (R ? reinterpret_cast<const void*>(conv32_lds_kernel<M, true>) : reinterpret_cast<const void*>(conv32_lds_kernel<M, false>))
   const bool has_res = residual != nullptr;
-  fn = mode == 0 ? AS_LDS_PICK(0, has_res) : mode == 1 ? AS_LDS_PICK(1, has_res) : AS_LDS_PICK(2, has_res);
+  fn = mode == 0 ? AS_LDS_PICK(0, has_res) : mode == 1 ? AS_LDS_PICK(1, has_res) : mode == 2 ? AS_LDS_PICK(2, has_res)
+                                                                                              : AS_LDS_PICK(3, has_res);
 #undef AS_LDS_PICK
-  static bool attr_set[6] = {false, false, false, false, false, false};
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   const int fi = mode * 2 + (has_res ? 1 : 0);
   if (!attr_set[fi]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES);

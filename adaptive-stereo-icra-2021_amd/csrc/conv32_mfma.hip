@@ -426,6 +426,24 @@ extern "C" int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, 
   return AS_OK;
 }
 
+// Convolution (data gradient) fused with stage 1 of the BatchNorm backward that consumes its output.
+extern "C" int as_conv32_bnbwd_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
+  return conv32_lds_applicable(gin, gout, s) ? conv32_lds_grid(gout) : 0;
+}
+
+extern "C" int as_conv32_fwd_bnbwd(const float* x, const as_pcl* gin, const float* packed_w, float* z, const as_pcl* gout,
+                                   const as_conv_shape* s, const float* residual, const float* bn_z,
+                                   const float* bn_scale, const float* bn_shift, const float* bn_mean, float slope,
+                                   float* bn_workspace, void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_fwd_bnbwd")) return e;
+  AS_CHECK_ARG(x && packed_w && z && bn_z && bn_scale && bn_shift && bn_mean && bn_workspace, "as_conv32_fwd_bnbwd: null pointer");
+  AS_CHECK_ARG(conv32_lds_applicable(gin, gout, s), "as_conv32_fwd_bnbwd: configuration not supported (as_conv32_bnbwd_parts() == 0)");
+  AS_CHECK_ARG(((uintptr_t)bn_workspace & 7) == 0, "as_conv32_fwd_bnbwd: workspace must be 8-byte aligned");
+  return conv32_lds_launch(x, gin, packed_w, nullptr, z, gout, s, 0, nullptr, nullptr, slope, residual, nullptr, nullptr,
+                           nullptr, bn_z, bn_scale, bn_shift, bn_mean, reinterpret_cast<double*>(bn_workspace), stream);
+}
+
 extern "C" int as_conv32_num_blocks(const as_pcl* gout) {
   if (!as_pcl_ok(gout)) return AS_ERR_ARG;
   const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;
@@ -448,7 +466,7 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
   AS_CHECK_ARG(epilogue_args_ok(epilogue, ep_scale, ep_shift, stat_mean, stat_m2, stat_cnt), "as_conv32_fwd: bad epilogue arguments");
   if (conv32_lds_applicable(gin, gout, s))
     return conv32_lds_launch(x, gin, packed_w, bias, z, gout, s, epilogue, ep_scale, ep_shift, slope, residual,
-                             stat_mean, stat_m2, stat_cnt, stream);
+                             stat_mean, stat_m2, stat_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
   ConvArgs a;
   a.x = x; a.wp = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = residual;

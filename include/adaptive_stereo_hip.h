@@ -146,6 +146,21 @@ int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const fl
                   const float* save_mean, const float* save_invstd, const float* gamma,
                   float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
                   float* workspace, const as_pcl* g, void* stream);
+/* Data gradient of a convolution fused with stage 1 (the per-channel sums) of the BatchNorm backward that consumes
+ * its output: z_out = conv(x) (+ residual) IS the g_a of the layer whose pre-activation is bn_z, so
+ * sum g_y and sum g_y*(bn_z - mean), g_y = z_out * lrelu'(bn_z*scale + shift), are taken from the output tile in
+ * registers and written to bn_workspace (an as_bn_bwd_workspace() buffer) as as_conv32_bnbwd_parts() slabs;
+ * as_bn_act_bwd_given then runs stages 2 and 3 only.  as_conv32_bnbwd_parts() == 0: not available for the
+ * configuration (use as_conv32_fwd + as_bn_act_bwd). */
+int as_conv32_bnbwd_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+int as_conv32_fwd_bnbwd(const float* x, const as_pcl* gin, const float* packed_w, float* z_out, const as_pcl* gout,
+                        const as_conv_shape* s, const float* residual, const float* bn_z,
+                        const float* bn_scale, const float* bn_shift, const float* bn_mean, float slope,
+                        float* bn_workspace, void* stream);
+int as_bn_act_bwd_given(const float* g_a, const float* z, const float* scale, const float* shift,
+                        const float* save_mean, const float* save_invstd, const float* gamma,
+                        float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
+                        float* workspace, const as_pcl* g, int nparts, void* stream);
 
 /* ---- a4 + a5 + a8: conv3d 32->1, soft-argmax, arg-max index, FCS ---------------
  * nn.Conv3d(32,1,3,padding=1) (stereo_net.py:162,187), F.softmax(dim=1) +

@@ -477,3 +477,34 @@ def test_conv32_dgrad_stride2(B, H, W):
   close(ops.pcl_to_ncdhw(gxb, ggx)[:, :, 0], x.grad, 3e-5, 1e-5, "stride-2 dgrad")
   full = ops.pcl_view(gxb, ggx).clone(); ops.pcl_interior(full, ggx).zero_()
   assert float(full.abs().max()) == 0.0, "dgrad wrote into the halo"
+
+
+@pytest.mark.parametrize("B,H,W,dil", [(2, 9, 131, 1), (1, 20, 300, 2)])
+def test_conv32_dgrad_fused_with_bn_backward_sums(B, H, W, dil):
+  """as_conv32_fwd_bnbwd (data gradient + stage 1 of the next BatchNorm backward) followed by as_bn_act_bwd_given must
+  give what as_conv32_fwd followed by as_bn_act_bwd gives: the same g_x bit for bit (same kernel arithmetic), g_z and the
+  gamma/beta gradients up to the different summation order of the per-channel sums."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  gz = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=1).to(DEV), g)
+  res = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=2).to(DEV), g)
+  zprev = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=3).to(DEV), g)
+  w = (rnd(32, 32, 3, 3, seed=4) * 0.06).to(DEV)
+  wp_t = ops.pack_weights(w, shape, True)
+  st = ops.BnState(DEV)
+  st.mean.copy_(rnd(32, seed=5).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=6).abs().to(DEV) + 0.5)
+  gamma = (rnd(32, seed=7).abs() + 0.5).to(DEV)
+  st.scale.copy_(st.invstd * gamma); st.shift.copy_(rnd(32, seed=8).to(DEV) * 0.1 - st.mean * st.scale)
+  # separate path
+  gx_ref = ops.conv32(gz, g, wp_t, None, g, shape, residual=res)
+  gzp_ref, gg_ref, gb_ref = ops.bn_act_bwd(gx_ref, zprev, st, gamma, g, True)
+  # fused path
+  fused = ops.conv32_dgrad_bnbwd(gz, g, wp_t, shape, res, zprev, st)
+  assert fused is not None
+  gx, sums = fused
+  assert torch.equal(gx, gx_ref)
+  gzp, gg, gb = ops.bn_act_bwd(gx, zprev, st, gamma, g, True, sums=sums)
+  n = B * H * W
+  close(gg, gg_ref, 2e-6 * n ** 0.5 * float(gg_ref.abs().max()) + 1e-5, 1e-5, "fused BN backward: g_gamma")
+  close(gb, gb_ref, 2e-6 * n ** 0.5 * float(gb_ref.abs().max()) + 1e-5, 1e-5, "fused BN backward: g_beta")
+  close(ops.pcl_interior(ops.pcl_view(gzp, g), g), ops.pcl_interior(ops.pcl_view(gzp_ref, g), g), 1e-5, 1e-4, "fused BN backward: g_z")
