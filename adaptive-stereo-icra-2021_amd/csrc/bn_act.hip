@@ -225,23 +225,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// stage 2: fixed-order sum of the slabs (256 threads = 4 slices x 64 sums); emits g_gamma, g_beta and
+// stage 2: fixed-order sum of the slabs (1024 threads = 16 slices x 64 sums); emits g_gamma, g_beta and
 // the per-channel coefficients of stage 3:  g_z = (g_y - k1 - (z-mean)*k2) * k3.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, long count,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                int train, float* g_gamma, float* g_beta, float* coef,
                                                                int accumulate) {
-  __shared__ double red[4][64];
-  const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  __shared__ double red[16][64];
+  const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;      // 16 slices x 64 sums: a slice adds <= 64 slabs
   double s = 0.0;
 #pragma unroll 8
-  for (int i = sl; i < nblocks; i += 4) s += partial[(long)i * 64 + j];
+  for (int i = sl; i < nblocks; i += 16) s += partial[(long)i * 64 + j];
   red[sl][j] = s;
   __syncthreads();
   if (threadIdx.x < 32) {
     const int c = threadIdx.x;
-    const double sdy = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-    const double sdx = red[0][32 + c] + red[1][32 + c] + red[2][32 + c] + red[3][32 + c];
+    double sdy = 0.0, sdx = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { sdy += red[q][c]; sdx += red[q][32 + c]; }
     const double is = (double)invstd[c];
     g_gamma[c] = accumulate ? g_gamma[c] + (float)(sdx * is) : (float)(sdx * is);
     g_beta[c] = accumulate ? g_beta[c] + (float)sdy : (float)sdy;
@@ -384,7 +385,7 @@ static int bn_act_bwd_impl(const float* g_a, const float* z, const float* scale,
                        partial, gd, (int)nch, cpr);
     AS_CHECK_LAUNCH("as_bn_act_bwd(reduce)");
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nb, M, save_invstd, gamma, train,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nb, M, save_invstd, gamma, train,
                      g_gamma, g_beta, coef, accumulate);
   AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(nch)), dim3(256), 0, st, g_a, z, scale, shift,
