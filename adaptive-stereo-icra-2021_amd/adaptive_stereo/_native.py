@@ -66,6 +66,10 @@ _SIGNATURES = {
                             _P(Pcl), c_vp]),
   "as_bn_act_bwd_given": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_int, c_vp,
                                   _P(Pcl), c_int, c_vp]),
+  "as_bn_bwd_coef_offset": (c_i64, []),
+  "as_conv32_wgrad_bnapply_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
+  "as_conv32_wgrad_bnapply": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_float,
+                                      c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_conv32_bnbwd_parts": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_fwd_bnbwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float,
                                   c_vp, c_vp]),

@@ -417,8 +417,28 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
   ``next_bn`` = (z, BnState) of the layer whose output gradient g_x is: its stage 1 is then fused into this block's
   data gradient and returned as next_sums (None when not available)."""
   sw, sb, sg, sbeta = sinks if sinks is not None else (None, None, None, None)
-  g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta, sums)
-  dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
+  lib = nat.load()
+  if sw is not None and sb is not None and sg is not None and sbeta is not None and \
+      lib.as_conv32_wgrad_bnapply_ok(g, g, shape) == 1:
+    # stages 1-2 of the BatchNorm backward only (stage 1 may already be in `sums`); stage 3 rides on the weight gradient,
+    # which stages g_out and z rows, applies it in LDS, accumulates dW / db and writes g_z for the data gradient
+    dev = z.device
+    ws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
+    if sums is not None:
+      call("as_bn_act_bwd_given", ptr(g_out), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+           LEAKY_SLOPE, int(train), None, ptr(sg), ptr(sbeta), 1, ptr(ws), g, sums.nparts, stream())
+    else:
+      call("as_bn_act_bwd", ptr(g_out), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+           LEAKY_SLOPE, int(train), None, ptr(sg), ptr(sbeta), 1, ptr(ws), g, stream())
+    coef = ws[lib.as_bn_bwd_coef_offset():]
+    g_z = POOL.get(g, dev)
+    wws = _empty(lib.as_conv32_wgrad_workspace(g, g, shape), dev)
+    call("as_conv32_wgrad_bnapply", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(st.scale), ptr(st.shift), ptr(st.mean),
+         ptr(coef), LEAKY_SLOPE, ptr(g_z), ptr(sw), ptr(sb), 1, ptr(wws), stream())
+    g_gamma = g_beta = dW = db = None
+  else:
+    g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta, sums)
+    dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
   g_x, next_sums = None, None
   if need_dx:
     wp_t = pack_weights(w, shape, True)

@@ -356,6 +356,8 @@ static int bnb_blocks(long nchunks) {
   return (int)nb;
 }
 
+extern "C" int64_t as_bn_bwd_coef_offset(void) { return (int64_t)BNB_BLOCKS * 128; }
+
 extern "C" int64_t as_bn_bwd_workspace(const as_pcl* g) {
   if (!as_pcl_ok(g)) return -1;
   // fp64 slabs [blocks][64] (= 128 floats each) + 96 coefficient floats
@@ -367,7 +369,7 @@ static int bn_act_bwd_impl(const float* g_a, const float* z, const float* scale,
                            float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
                            float* workspace, const as_pcl* g, int nparts_given, void* stream) {
   AS_CHECK_ARG(as_pcl_ok(g), "as_bn_act_bwd: bad geometry");
-  AS_CHECK_ARG(g_a && z && scale && shift && save_mean && save_invstd && gamma && g_z && g_gamma && g_beta && workspace,
+  AS_CHECK_ARG(g_a && z && scale && shift && save_mean && save_invstd && gamma && g_gamma && g_beta && workspace,
                "as_bn_act_bwd: null pointer");
   AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_bn_act_bwd: workspace must be 8-byte aligned");
   const long M = (long)g->B * g->D * g->H * g->W;
@@ -388,9 +390,13 @@ static int bn_act_bwd_impl(const float* g_a, const float* z, const float* scale,
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nb, M, save_invstd, gamma, train,
                      g_gamma, g_beta, coef, accumulate);
   AS_CHECK_LAUNCH("as_bn_act_bwd(finalize)");
+  if (g_z == nullptr) {            // stage 3 is somebody else's (as_conv32_wgrad_bnapply): coefficients stay in the workspace
+    as_prof_mark(5, st, 0, (nparts_given == 0 ? 2.0 : 0.0) * 128.0 * (double)M);
+    return AS_OK;
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(nch)), dim3(256), 0, st, g_a, z, scale, shift,
                      save_mean, coef, slope, g_z, gd, (int)nch, cpr);
-  as_prof_mark(5, st, 0, 5.0 * 128.0 * (double)M);
+  as_prof_mark(5, st, 0, (nparts_given == 0 ? 5.0 : 3.0) * 128.0 * (double)M);
   AS_CHECK_LAUNCH("as_bn_act_bwd(apply)");
   return AS_OK;
 }

@@ -12,5 +12,11 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
 
 // LDS-staged weight gradient of the same instance (conv32_lds.hip); dispatched from as_conv32_wgrad.
 int conv32_wgrad_lds_slabs(const as_pcl* gout);        // number of partial slabs it writes
+struct WgradBnApply {          // stage 3 of the layer's BatchNorm backward applied to the staged gradient row
+  const float* z; const float* scale; const float* shift; const float* mean; const float* coef;
+  float* gz_out; float slope;
+};
+bool conv32_wgrad_bnapply_ok(const as_pcl* gout);      // the fused form exists for this launch size
 int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
-                            const as_conv_shape* s, float* partial, float* partial_db, void* stream);
+                            const as_conv_shape* s, float* partial, float* partial_db, const WgradBnApply* bn,
+                            void* stream);

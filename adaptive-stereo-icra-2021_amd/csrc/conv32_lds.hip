@@ -456,11 +456,19 @@ struct WgradLdsArgs {
   float* partial_db;   // [wgs][32]
   PclDev gin, gout;
   int dil, tiles_per_row, ntiles, tiles_per_band, wg_per_xcd;
+  // APPLY flavour: gz is the layer's output gradient g_a, stage 3 of its BatchNorm backward runs on the staged row
+  const float* bn_z;       // PCL (output geometry): pre-activation
+  const float* bn_scale;   // [32] scale, shift, mean of the forward pass
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_coef;    // [96] k1, k2, k3 of bn_bwd_finalize_kernel
+  float* gz_out;           // PCL (output geometry): g_z, written here for the data gradient that follows
+  float slope;
 };
 
-template <int NW>
+template <int NW, bool WITH_Z = false>
 __device__ inline void issue_wgrad_dma(const WgradLdsArgs& p, int tile, unsigned lds_x, unsigned lds_g, int wave,
-                                       unsigned lane16) {
+                                       unsigned lane16, unsigned lds_z = 0) {
   const int row = tile / p.tiles_per_row;
   const int x0 = (tile - row * p.tiles_per_row) * 128;
   const int b = row / p.gout.H, y = row - b * p.gout.H;
@@ -483,6 +491,14 @@ __device__ inline void issue_wgrad_dma(const WgradLdsArgs& p, int tile, unsigned
   for (int k = 0; k < 16 / NW; ++k) {
     const int i = wave + NW * k;
     dma_1kb(grow + (long)min(x0 + 8 * i, p.gout.W) * 32, lane16, lds_g + (unsigned)(8 * i * 128));
+  }
+  if (WITH_Z) {
+    const float* zrow = p.bn_z + (((long)b * p.gout.Hp + (y + p.gout.ph)) * p.gout.Wp + p.gout.pw) * 32;
+#pragma unroll
+    for (int k = 0; k < 16 / NW; ++k) {
+      const int i = wave + NW * k;
+      dma_1kb(zrow + (long)min(x0 + 8 * i, p.gout.W) * 32, lane16, lds_z + (unsigned)(8 * i * 128));
+    }
   }
 }
 
@@ -577,7 +593,14 @@ __global__ __launch_bounds__(256, 2) void conv32_wgrad_lds_kernel(WgradLdsArgs p
 // Double-buffered form for launches that fill the chip: ONE 8-wave workgroup per CU, two tile buffers (143 KB of
 // LDS), the DMA of tile i+1 in flight while tile i is multiplied, one barrier per tile.  A wave takes 16 of the
 // segment's voxels (8 steps of one voxel pair) for all nine taps.
+// APPLY: the G row arrives as the layer's OUTPUT gradient g_a together with its pre-activation row z; stage 3 of the
+// BatchNorm backward, g_z = (g_a*lrelu'(z*scale+shift) - k1 - (z-mean)*k2)*k3, is applied to the staged row in LDS
+// (8 elements per thread) and the result is also written out for the data gradient that follows — the separate
+// element-wise pass (read g_a, read z, write g_z: 715 MB per full-resolution layer) disappears.  The z row has a
+// single buffer (159,744 B of LDS in all): it is dead once the row is transformed, before the next tile's DMA.
 #define TLW2_LDS_BYTES (2 * TLW_LDS_BYTES)
+#define TLW2A_LDS_BYTES (2 * TLW_LDS_BYTES + TLG_BYTES)
+template <bool APPLY>
 __global__ __launch_bounds__(512, 1) void conv32_wgrad_lds2_kernel(WgradLdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_ptr_t)smem));
@@ -600,16 +623,50 @@ __global__ __launch_bounds__(512, 1) void conv32_wgrad_lds2_kernel(WgradLdsArgs 
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int t_begin = xcd * p.tiles_per_band;
   const int t_end = min(t_begin + p.tiles_per_band, p.ntiles);
+  const unsigned lds_z = lds0 + TLW2_LDS_BYTES;
+  // APPLY: this thread's two float4 of a 128-voxel row (float4 index f = tid, tid + 512: channel group tid & 7)
+  f32x4 k1, k2, k3, bsc, bsh, bmu;
+  if (APPLY) {
+    const int c4 = (threadIdx.x & 7) * 4;
+    k1 = *reinterpret_cast<const f32x4*>(p.bn_coef + c4); k2 = *reinterpret_cast<const f32x4*>(p.bn_coef + 32 + c4);
+    k3 = *reinterpret_cast<const f32x4*>(p.bn_coef + 64 + c4);
+    bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + c4); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + c4);
+    bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + c4);
+  }
   int tile = t_begin + j;
-  if (tile < t_end) issue_wgrad_dma<8>(p, tile, lds0, lds0 + TL_BUF_BYTES, wave, lane16);
+  if (tile < t_end) issue_wgrad_dma<8, APPLY>(p, tile, lds0, lds0 + TL_BUF_BYTES, wave, lane16, lds_z);
   int cur = 0;
   for (; tile < t_end; tile += p.wg_per_xcd, cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the current tile
     __syncthreads();                                      // everybody's share landed; everybody is done with the other buffer
+    if (APPLY) {
+      const int row = tile / p.tiles_per_row;
+      const int x0 = (tile - row * p.tiles_per_row) * 128;
+      const int b = row / p.gout.H, y = row - b * p.gout.H;
+      float* gsm = reinterpret_cast<float*>(smem + cur * TLW_LDS_BYTES + TL_BUF_BYTES);
+      const float* zsm = reinterpret_cast<const float*>(smem + TLW2_LDS_BYTES);
+      float* orow = p.gz_out + p.gout.vox(b, 0, y, x0) * 32;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int f = threadIdx.x + 512 * q;
+        const bool inside = x0 + (f >> 3) < p.gout.W;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gsm + f * 4);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(zsm + f * 4);
+        const f32x4 yy = zz * bsc + bsh;
+        f32x4 gy;
+        gy.x = yy.x > 0.f ? ga.x : ga.x * p.slope; gy.y = yy.y > 0.f ? ga.y : ga.y * p.slope;
+        gy.z = yy.z > 0.f ? ga.z : ga.z * p.slope; gy.w = yy.w > 0.f ? ga.w : ga.w * p.slope;
+        f32x4 gzv = (gy - k1 - (zz - bmu) * k2) * k3;
+        if (!inside) gzv = (f32x4){0.f, 0.f, 0.f, 0.f};   // beyond W the staged rows are halo: G must vanish there
+        *reinterpret_cast<f32x4*>(gsm + f * 4) = gzv;
+        if (inside) *reinterpret_cast<f32x4*>(orow + f * 4) = gzv;
+      }
+      __syncthreads();                                    // the row is g_z now; the z buffer is free
+    }
     const int next = tile + p.wg_per_xcd;
     if (next < t_end) {
       const unsigned nb = lds0 + (unsigned)((cur ^ 1) * TLW_LDS_BYTES);
-      issue_wgrad_dma<8>(p, next, nb, nb + TL_BUF_BYTES, wave, lane16);
+      issue_wgrad_dma<8, APPLY>(p, next, nb, nb + TL_BUF_BYTES, wave, lane16, lds_z);
     }
     const char* gaddr = gaddr0 + cur * TLW_LDS_BYTES;
     const char* xaddr[3] = {xaddr0[0] + cur * TLW_LDS_BYTES, xaddr0[1] + cur * TLW_LDS_BYTES, xaddr0[2] + cur * TLW_LDS_BYTES};
@@ -684,15 +741,21 @@ int conv32_wgrad_lds_slabs(const as_pcl* gout) {
   return g;
 }
 
+bool conv32_wgrad_bnapply_ok(const as_pcl* gout) { return wgrad_lds2(gout); }
+
 int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
-                            const as_conv_shape* s, float* partial, float* partial_db, void* stream) {
+                            const as_conv_shape* s, float* partial, float* partial_db, const WgradBnApply* bn,
+                            void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, TLW_LDS_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds2_kernel),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds2_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, TLW2_LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds2_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, TLW2A_LDS_BYTES);
     if (e != hipSuccess) {
       as_set_error("conv32_wgrad_lds: cannot reserve %d bytes of LDS: %s", TLW2_LDS_BYTES, hipGetErrorString(e));
       return AS_ERR_LAUNCH;
@@ -708,8 +771,14 @@ int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, 
   const int grid = conv32_wgrad_lds_slabs(gout);
   a.tiles_per_band = (a.ntiles + 7) / 8;
   a.wg_per_xcd = grid / 8;
-  if (wgrad_lds2(gout))
-    hipLaunchKernelGGL(conv32_wgrad_lds2_kernel, dim3(grid), dim3(512), TLW2_LDS_BYTES, (hipStream_t)stream, a);
+  a.bn_z = nullptr; a.bn_scale = a.bn_shift = a.bn_mean = a.bn_coef = nullptr; a.gz_out = nullptr; a.slope = 0.f;
+  if (bn != nullptr) {
+    if (!wgrad_lds2(gout)) { as_set_error("as_conv32_wgrad_bnapply: configuration not supported"); return AS_ERR_ARG; }
+    a.bn_z = bn->z; a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_mean = bn->mean; a.bn_coef = bn->coef;
+    a.gz_out = bn->gz_out; a.slope = bn->slope;
+    hipLaunchKernelGGL(conv32_wgrad_lds2_kernel<true>, dim3(grid), dim3(512), TLW2A_LDS_BYTES, (hipStream_t)stream, a);
+  } else if (wgrad_lds2(gout))
+    hipLaunchKernelGGL(conv32_wgrad_lds2_kernel<false>, dim3(grid), dim3(512), TLW2_LDS_BYTES, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(conv32_wgrad_lds_kernel, dim3(grid), dim3(256), TLW_LDS_BYTES, (hipStream_t)stream, a);
   AS_CHECK_LAUNCH("as_conv32_wgrad(lds)");

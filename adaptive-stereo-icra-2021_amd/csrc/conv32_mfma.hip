@@ -28,6 +28,8 @@
 #include "conv_epilogue.h"
 #include "conv32_lds.h"
 
+static bool wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+
 struct ConvArgs {
   const float* x;
   const float* wp;
@@ -426,6 +428,34 @@ extern "C" int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, 
   return AS_OK;
 }
 
+// Weight gradient fused with stage 3 of the layer's BatchNorm backward (the gradient operand arrives as g_a).
+extern "C" int as_conv32_wgrad_bnapply_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
+  return wgrad_lds_applicable(gin, gout, s) && conv32_wgrad_bnapply_ok(gout) ? 1 : 0;
+}
+
+extern "C" int as_conv32_wgrad_bnapply(const float* x, const as_pcl* gin, const float* g_a, const float* z,
+                                       const as_pcl* gout, const as_conv_shape* s, const float* scale,
+                                       const float* shift, const float* mean, const float* coef, float slope,
+                                       float* g_z, float* dW, float* db, int accumulate, float* workspace, void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_wgrad_bnapply")) return e;
+  AS_CHECK_ARG(x && g_a && z && scale && shift && mean && coef && g_z && dW && workspace, "as_conv32_wgrad_bnapply: null pointer");
+  AS_CHECK_ARG(wgrad_lds_applicable(gin, gout, s) && conv32_wgrad_bnapply_ok(gout),
+               "as_conv32_wgrad_bnapply: configuration not supported (as_conv32_wgrad_bnapply_ok() == 0)");
+  const int T = 9;
+  const int slabs = conv32_wgrad_lds_slabs(gout);
+  float* partial_db = workspace + (int64_t)slabs * T * 1024;
+  WgradBnApply bn = {z, scale, shift, mean, coef, g_z, slope};
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(3, st, 1, 0.0);
+  if (int e = conv32_wgrad_lds_launch(x, gin, g_a, gout, s, workspace, partial_db, &bn, stream)) return e;
+  as_prof_mark(3, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
+                     workspace, partial_db, slabs, T, dW, db, accumulate);
+  AS_CHECK_LAUNCH("as_conv32_wgrad_bnapply(reduce)");
+  return AS_OK;
+}
+
 // Convolution (data gradient) fused with stage 1 of the BatchNorm backward that consumes its output.
 extern "C" int as_conv32_bnbwd_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
   if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
@@ -533,7 +563,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
     float* partial_db = workspace + (int64_t)slabs * T * 1024;
     hipStream_t st = (hipStream_t)stream;
     as_prof_mark(3, st, 1, 0.0);
-    if (int e = conv32_wgrad_lds_launch(x, gin, gz, gout, s, workspace, partial_db, stream)) return e;
+    if (int e = conv32_wgrad_lds_launch(x, gin, gz, gout, s, workspace, partial_db, nullptr, stream)) return e;
     as_prof_mark(3, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
                        workspace, partial_db, slabs, T, dW, db, accumulate);

@@ -157,6 +157,17 @@ int as_conv32_fwd_bnbwd(const float* x, const as_pcl* gin, const float* packed_w
                         const as_conv_shape* s, const float* residual, const float* bn_z,
                         const float* bn_scale, const float* bn_shift, const float* bn_mean, float slope,
                         float* bn_workspace, void* stream);
+/* Stage 3 (g_z = (g_a*lrelu'(z*scale+shift) - k1 - (z-mean)*k2)*k3) fused into the weight gradient of the same layer:
+ * call as_bn_act_bwd / as_bn_act_bwd_given with g_z = NULL (stages 1-2 only; the coefficients k1,k2,k3 stay in the
+ * workspace at float offset as_bn_bwd_coef_offset()), then as_conv32_wgrad_bnapply, which stages g_a and z rows, applies
+ * stage 3 in LDS, accumulates dW/db from the result and writes g_z (PCL interior) for the data gradient that follows.
+ * Available when as_conv32_wgrad_bnapply_ok() == 1 (launches that fill the chip). */
+int64_t as_bn_bwd_coef_offset(void);
+int as_conv32_wgrad_bnapply_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+int as_conv32_wgrad_bnapply(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                            const as_conv_shape* s, const float* scale, const float* shift, const float* mean,
+                            const float* coef, float slope, float* g_z, float* dW, float* db, int accumulate,
+                            float* workspace, void* stream);
 int as_bn_act_bwd_given(const float* g_a, const float* z, const float* scale, const float* shift,
                         const float* save_mean, const float* save_invstd, const float* gamma,
                         float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,

@@ -508,3 +508,41 @@ def test_conv32_dgrad_fused_with_bn_backward_sums(B, H, W, dil):
   close(gg, gg_ref, 2e-6 * n ** 0.5 * float(gg_ref.abs().max()) + 1e-5, 1e-5, "fused BN backward: g_gamma")
   close(gb, gb_ref, 2e-6 * n ** 0.5 * float(gb_ref.abs().max()) + 1e-5, 1e-5, "fused BN backward: g_beta")
   close(ops.pcl_interior(ops.pcl_view(gzp, g), g), ops.pcl_interior(ops.pcl_view(gzp_ref, g), g), 1e-5, 1e-4, "fused BN backward: g_z")
+
+
+def test_conv32_wgrad_fused_with_bn_backward_apply():
+  """as_bn_act_bwd(g_z=NULL) + as_conv32_wgrad_bnapply (stage 3 of the BatchNorm backward applied to the staged gradient
+  row inside the weight-gradient kernel, g_z written as a by-product) against the separate passes, at a size that takes the
+  double-buffered kernel (>= 4096 row segments) with a ragged last segment."""
+  B, H, W, dil = 1, 421, 1250, 2
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_wgrad_bnapply_ok(g, g, shape) == 1
+  x = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=1).to(DEV), g)
+  g_a = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=2).to(DEV), g)
+  z = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=3).to(DEV), g)
+  st = ops.BnState(DEV)
+  st.mean.copy_(rnd(32, seed=5).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=6).abs().to(DEV) + 0.5)
+  gamma = (rnd(32, seed=7).abs() + 0.5).to(DEV)
+  st.scale.copy_(st.invstd * gamma); st.shift.copy_(rnd(32, seed=8).to(DEV) * 0.1 - st.mean * st.scale)
+  # separate passes
+  gz_ref, gg_ref, gb_ref = ops.bn_act_bwd(g_a, z, st, gamma, g, True)
+  dW_ref, db_ref = ops.conv32_wgrad(x, g, gz_ref, g, shape)
+  # fused
+  ws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  gg, gb = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+  nat.call("as_bn_act_bwd", nat.ptr(g_a), nat.ptr(z), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(st.mean),
+           nat.ptr(st.invstd), nat.ptr(gamma), 0.2, 1, None, nat.ptr(gg), nat.ptr(gb), 0, nat.ptr(ws), g, nat.stream())
+  assert torch.equal(gg, gg_ref) and torch.equal(gb, gb_ref)
+  coef = ws[lib.as_bn_bwd_coef_offset():]
+  gz = ops.pcl_zeros(g, DEV)
+  dW = torch.zeros(32, 32, 3, 3, device=DEV); db = torch.zeros(32, device=DEV)
+  wws = torch.empty(lib.as_conv32_wgrad_workspace(g, g, shape), device=DEV)
+  nat.call("as_conv32_wgrad_bnapply", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(z), g, shape, nat.ptr(st.scale), nat.ptr(st.shift),
+           nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gz), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(wws), nat.stream())
+  gzv, gzr = ops.pcl_view(gz, g), ops.pcl_view(gz_ref, g)
+  assert torch.equal(ops.pcl_interior(gzv, g), ops.pcl_interior(gzr, g)), "stage 3 in LDS must round like the element-wise pass"
+  halo = gzv.clone(); ops.pcl_interior(halo, g).zero_()
+  assert float(halo.abs().max()) == 0.0, "the halo of g_z must stay zero"
+  assert torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
