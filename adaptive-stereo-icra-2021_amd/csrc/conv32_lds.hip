@@ -413,7 +413,8 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
     hipMalloc(&trace_buf, trace_bytes); hipMemset(trace_buf, 0, trace_bytes); a.trace = trace_buf;
   }
 #endif
-  as_prof_mark(2, st, 1, 0.0);
+  const int prof_id = mode == 3 ? 6 : 2;
+  as_prof_mark(prof_id, st, 1, 0.0);
   void* kargs[] = {&a};
   hipError_t le = hipLaunchKernel(fn, dim3(grid), dim3(256), kargs, TL_LDS_BYTES, st);
   if (le != hipSuccess) { as_set_error("as_conv32_fwd(lds): launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
@@ -424,7 +425,7 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
     FILE* f = fopen("gpurun_out/lds_trace.bin", "wb"); if (f) { fwrite(hbuf, 1, trace_bytes, f); fclose(f); } free(hbuf);
   }
 #endif
-  as_prof_mark(2, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
+  as_prof_mark(prof_id, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
   AS_CHECK_LAUNCH("as_conv32_fwd(lds)");
   return AS_OK;
 }

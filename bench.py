@@ -188,7 +188,7 @@ def main():
   if not use_graph:
     t_adapt = min(t_adapt, t_adapt_eager)
   prof = []
-  for kid in (0, 1, 2, 3, 4, 5):
+  for kid in (0, 1, 2, 3, 4, 5, 6):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     nat.call("as_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
     prof.append((n.value, ms.value, fl.value))
@@ -220,27 +220,42 @@ def main():
       return None
     return {"kernel": name, "achieved": round(fl / (ms * 1e-3) / 1e12, 3), "launches": n,
             "avg_launch_us": round(1e3 * ms / n, 2), "flops_per_launch": fl / n}
-  dom = entry(2, "conv32_lds_kernel")
+  # the LDS convolution family: id 2 = forward flavours, id 6 = the data gradient that also carries stage 1 of the
+  # following BatchNorm backward (one more tensor read and ~100 vector instructions per tile that the FLOP count
+  # does not credit).  The roofline line is the whole family, as one kernel.
+  fam = [prof[2], prof[6]]
+  n_f, ms_f, fl_f = (sum(t[i] for t in fam) for i in range(3))
+  prof_family = (n_f, ms_f, fl_f)
+  def entry_family():
+    if n_f == 0 or ms_f <= 0:
+      return None
+    return {"kernel": "conv32_lds_kernel", "achieved": round(fl_f / (ms_f * 1e-3) / 1e12, 3), "launches": n_f,
+            "avg_launch_us": round(1e3 * ms_f / n_f, 2), "flops_per_launch": fl_f / n_f}
+  dom = entry_family()
   roofline = None
   if dom is not None:
     # HBM bytes per launch from the committed PMC passes (profiles/pmc_conv32_lds.json; FETCH_SIZE / WRITE_SIZE
     # corrected as MI355X_MICROARCH.md prescribes).  A step launches the kernel as 6 training forwards
-    # (<0,false>: read x, write z) and 6 data gradients with the skip connection (<2,true>: + read residual):
-    # `traffic` is the mean over that mix, like `achieved`.
+    # (<0,false>: read x, write z) and 6 data gradients with the skip connection and the fused BatchNorm-backward
+    # sums (<3,true>: + read residual, + read the next layer's pre-activation): `traffic` is the mean over that
+    # mix, like `achieved`.
     traffic, traffic_detail = None, None
     pmc = os.path.join(REPO, "profiles", "pmc_conv32_lds.json")
     if os.path.exists(pmc):
       rec = json.load(open(pmc))
       ks = rec.get("kernels", {})
-      if rec.get("pairs_per_launch") == B and "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<2, true>" in ks:
-        a, b = ks["conv32_lds_kernel<0, false>"], ks["conv32_lds_kernel<2, true>"]
+      if rec.get("pairs_per_launch") == B and "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
+        a, b = ks["conv32_lds_kernel<0, false>"], ks["conv32_lds_kernel<3, true>"]
         traffic = int((a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"]) / 2)
         traffic_detail = {"forward": {"hbm_bytes": a["hbm_bytes_per_launch"], "algorithmic_bytes": a["algorithmic_bytes_per_launch"]},
-                          "dgrad_with_skip": {"hbm_bytes": b["hbm_bytes_per_launch"], "algorithmic_bytes": b["algorithmic_bytes_per_launch"]}}
+                          "dgrad_with_skip_and_bn_sums": {"hbm_bytes": b["hbm_bytes_per_launch"], "algorithmic_bytes": b["algorithmic_bytes_per_launch"]}}
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
                 "flops_per_launch": dom["flops_per_launch"], "traffic_detail": traffic_detail,
+                "flavours": [e for e in (entry(2, "conv32_lds_kernel<0,false> (training forward: raw output + BatchNorm moments)"),
+                                         entry(6, "conv32_lds_kernel<3,true> (data gradient + skip + stage 1 of the next BatchNorm backward)"))
+                             if e is not None],
                 "other_mfma_kernels": [e for e in (entry(3, "conv32_wgrad_lds_kernel"),
                                                    entry(0, "conv32_fwd_kernel<taps> (3-D, strided, small 2-D)"),
                                                    entry(1, "conv32_wgrad_kernel<taps>")) if e is not None]}

@@ -288,7 +288,9 @@ int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
  * 0 conv32_fwd_kernel<taps> (direct-load forward/dgrad), 1 conv32_wgrad_kernel<..> (direct-load wgrad),
  * 2 conv32_lds_kernel (LDS-staged 3x3 forward/dgrad), 3 conv32_wgrad_lds_kernel.
  * HBM-bound passes account algorithmic BYTES in the same slot: 4 as_bn_act_fwd (2 or 3 tensors x interior
- * bytes), 5 as_bn_act_bwd (its three kernels together: 5 tensor passes).
+ * bytes), 5 as_bn_act_bwd (its kernels together: 5 tensor passes, fewer when stages are fused elsewhere).
+ * 6 conv32_lds_kernel<3,*> (the data gradient that also carries stage 1 of the next BatchNorm backward); id 2 then
+ * counts the other flavours only.
  * as_prof_read synchronises on the recorded events.
  * Disabled by default; must stay disabled under hipGraph capture. */
 int as_prof_enable(int on);

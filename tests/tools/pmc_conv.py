@@ -20,9 +20,23 @@ ws = torch.empty(nat.load().as_conv32_wgrad_workspace(g, g, shape), device=dev)
 dW = torch.empty_like(w); db = torch.empty(32, device=dev)
 wpt = ops.pack_weights(w, shape, True)
 gx = torch.zeros(g.numel(), device=dev)
+lib = nat.load()
+st = ops.BnState(dev); st.mean.zero_(); st.invstd.fill_(1.0); st.scale.fill_(1.0); st.shift.zero_()
+gam = torch.ones(32, device=dev)
+bws = torch.empty(lib.as_bn_bwd_workspace(g), device=dev)
+coef = bws[lib.as_bn_bwd_coef_offset():]; coef.zero_(); coef[64:96] = 1.0
+gzo = torch.zeros(g.numel(), device=dev)
+zb = x.clone()            # a distinct buffer for the next layer's pre-activation (a shared one would be read from HBM once)
 for _ in range(5):
   ops.conv32(x, g, wp, b, g, shape, out=z, stats=stats)              # conv32_lds_kernel<0,false>: training forward
   ops.conv32(z, g, wpt, None, g, shape, out=gx, residual=x)           # conv32_lds_kernel<2,true>: data gradient + skip
+  # conv32_lds_kernel<3,true>: data gradient + skip + stage 1 of the next BatchNorm backward (what a step launches)
+  nat.call("as_conv32_fwd_bnbwd", nat.ptr(z), g, nat.ptr(wpt), nat.ptr(gx), g, shape, nat.ptr(x), nat.ptr(zb), nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), 0.2, nat.ptr(bws), nat.stream())
+  # conv32_wgrad_lds2_kernel<true>: weight gradient + stage 3 of the layer's BatchNorm backward (B >= 2 at this size)
+  if lib.as_conv32_wgrad_bnapply_ok(g, g, shape) == 1:
+    nat.call("as_conv32_wgrad_bnapply", nat.ptr(x), g, nat.ptr(gx), nat.ptr(zb), g, shape, nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gzo), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
   nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(z), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
 # a3: one 3-D cost-aggregation layer (forward + weight gradient), 4 pairs
 g3 = Pcl(B, 12, 24, 78, 1, 1, 1)
