@@ -44,6 +44,13 @@ for name, g, shape in cases:
   t_fe = timeit(lambda: ops.conv32(x, g, wp, b, g, shape, out=z, epilogue=1, scale=one, shift=b))
   t_res = timeit(lambda: ops.conv32(x, g, wp, None, g, shape, out=z, residual=gz))
   t_fres = timeit(lambda: ops.conv32(x, g, wp, b, g, shape, out=z, epilogue=1, scale=one, shift=b, residual=gz))
+  t_fus = float("nan")
+  if nat.load().as_conv32_bnbwd_parts(g, g, shape) > 0:
+    stb = ops.BnState(dev); stb.mean.zero_(); stb.invstd.fill_(1.0); stb.scale.fill_(1.0); stb.shift.zero_()
+    zb = x.clone()
+    def fused():
+      r = ops.conv32_dgrad_bnbwd(x, g, wp, shape, gz, zb, stb); ops.POOL.put(r[0], g)
+    t_fus = timeit(fused)
   ws = torch.empty(nat.load().as_conv32_wgrad_workspace(g, g, shape), device=dev)
   dW = torch.empty_like(w); db = torch.empty(32, device=dev)
   t_w = timeit(lambda: nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(gz), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream()))
@@ -56,6 +63,7 @@ for name, g, shape in cases:
   t_b = timeit(bwd)
   t_fin = timeit(lambda: ops.bn_train_stats(stats, gam, b, None, None))
   byts = g.voxels() * 128
-  print("%-22s dgrad+res %8.1f us %6.1f TF | fused-ep+res %8.1f us %6.1f TF" % (name, t_res, flops / t_res / 1e6, t_fres, flops / t_fres / 1e6), flush=True)
+  print("%-22s dgrad+res %8.1f us %6.1f TF | fused-ep+res %8.1f us %6.1f TF | dgrad+res+bn-sums %8.1f us %6.1f TF" % (
+      name, t_res, flops / t_res / 1e6, t_fres, flops / t_fres / 1e6, t_fus, flops / t_fus / 1e6), flush=True)
   print("%-22s fwd %8.1f us %6.1f TF | fused-ep %8.1f us %6.1f TF | wgrad %8.1f us %6.1f TF | bn_act %7.1f us %5.2f TB/s | bn_bwd %7.1f us %5.2f TB/s | finalize %6.1f us" % (
       name, t_f, flops / t_f / 1e6, t_fe, flops / t_fe / 1e6, t_w, flops / t_w / 1e6, t_a, 3 * byts / t_a / 1e6, t_b, 5 * byts / t_b / 1e6, t_fin), flush=True)
