@@ -814,14 +814,31 @@ class EdgeRefineFn(torch.autograd.Function):
 
     # conv2d_feature backward
     w0, b0, gamma0, beta0 = params[0:4]
-    g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train, _sink(sinks, 2), _sink(sinks, 3), sums)
     ws4 = _empty(lib.as_conv4_wgrad_workspace(g, s33), dev)
-    if _sink(sinks, 0) is not None and _sink(sinks, 1) is not None:
-      call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())
-      dW0 = db0 = None
+    all_sinks = all(_sink(sinks, i) is not None for i in range(4))
+    if all_sinks and lib.as_conv4_wgrad_bnapply_ok(g4, g, s33) == 1:
+      # stages 1-2 of the BatchNorm backward (stage 1 usually already in `sums`); stage 3 rides on the weight gradient
+      bws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
+      st0 = ctx.st0
+      if sums is not None:
+        call("as_bn_act_bwd_given", ptr(g_a), ptr(ctx.z0), ptr(st0.scale), ptr(st0.shift), ptr(st0.mean), ptr(st0.invstd),
+             ptr(gamma0), LEAKY_SLOPE, int(ctx.train), None, ptr(sinks[2]), ptr(sinks[3]), 1, ptr(bws), g, sums.nparts, stream())
+      else:
+        call("as_bn_act_bwd", ptr(g_a), ptr(ctx.z0), ptr(st0.scale), ptr(st0.shift), ptr(st0.mean), ptr(st0.invstd),
+             ptr(gamma0), LEAKY_SLOPE, int(ctx.train), None, ptr(sinks[2]), ptr(sinks[3]), 1, ptr(bws), g, stream())
+      coef = bws[lib.as_bn_bwd_coef_offset():]
+      g_z0 = POOL.get(g, dev)
+      call("as_conv4_wgrad_bnapply", ptr(ctx.in4), g4, ptr(g_a), ptr(ctx.z0), g, s33, 4, ptr(st0.scale), ptr(st0.shift),
+           ptr(st0.mean), ptr(coef), LEAKY_SLOPE, ptr(g_z0), ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())
+      dW0 = db0 = g_gamma0 = g_beta0 = None
     else:
-      dW0 = torch.empty_like(w0); db0 = _empty(32, dev)
-      call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(dW0), ptr(db0), 0, ptr(ws4), stream())
+      g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train, _sink(sinks, 2), _sink(sinks, 3), sums)
+      if _sink(sinks, 0) is not None and _sink(sinks, 1) is not None:
+        call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())
+        dW0 = db0 = None
+      else:
+        dW0 = torch.empty_like(w0); db0 = _empty(32, dev)
+        call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(dW0), ptr(db0), 0, ptr(ws4), stream())
     grads[0:4] = [dW0, db0, g_gamma0, g_beta0]
 
     g_coarse = None

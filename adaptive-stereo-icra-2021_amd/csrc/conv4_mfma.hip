@@ -342,8 +342,15 @@ struct Wgrad4RowsArgs {
   float* partial_db;   // [blocks][32]
   PclDev gin, gout;
   int nchunks, chunks_per_row;
+  // APPLY flavour: gz is the layer's output gradient g_a; stage 3 of its BatchNorm backward is applied on the fly
+  const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_coef;
+  float* gz_out; float slope;
 };
 
+// APPLY: g_z = (g_a*lrelu'(z*scale+shift) - k1 - (z-mean)*k2)*k3 is formed in registers from g_a and z (the lane's four
+// output channels), used for the products and written out for whoever needs g_z next — the element-wise pass of
+// as_bn_act_bwd (read g_a, read z, write g_z) disappears.
+template <bool APPLY>
 __global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p) {
   __shared__ float red[32][33];
   const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
@@ -351,11 +358,19 @@ __global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p)
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  f32x4 k1, k2, k3, bsc, bsh, bmu;
+  if (APPLY) {
+    k1 = *reinterpret_cast<const f32x4*>(p.bn_coef + c4 * 4); k2 = *reinterpret_cast<const f32x4*>(p.bn_coef + 32 + c4 * 4);
+    k3 = *reinterpret_cast<const f32x4*>(p.bn_coef + 64 + c4 * 4);
+    bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + c4 * 4); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + c4 * 4);
+    bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + c4 * 4);
+  }
   for (int ch = blockIdx.x; ch < p.nchunks; ch += gridDim.x) {
     const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
     const int y = rowi % p.gout.H, b = rowi / p.gout.H, x0 = cx * 128;
     const int nf4 = min(128, p.gout.W - x0) * 8;
-    const float* grow = p.gz + p.gout.vox(b, 0, y, x0) * 32;
+    const long goff = p.gout.vox(b, 0, y, x0) * 32;
+    const float* grow = p.gz + goff;
     const float* xrow = p.x4 + (((long)b * p.gin.Hp + (y + p.gin.ph - 1)) * p.gin.Wp + (x0 + p.gin.pw - 1)) * 4;
     const long rs = (long)p.gin.Wp * 4;
 #pragma unroll
@@ -363,7 +378,19 @@ __global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p)
       const int f = threadIdx.x + 256 * k4;
       if (f < nf4) {
         const int vx = f >> 3;
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(grow + f * 4);
+        f32x4 g4 = *reinterpret_cast<const f32x4*>(grow + f * 4);
+        if (APPLY) {
+          const f32x4 zz = *reinterpret_cast<const f32x4*>(p.bn_z + goff + f * 4);
+          const f32x4 yy = zz * bsc + bsh;
+          f32x4 gy;
+          gy.x = yy.x > 0.f ? g4.x : g4.x * p.slope; gy.y = yy.y > 0.f ? g4.y : g4.y * p.slope;
+          gy.z = yy.z > 0.f ? g4.z : g4.z * p.slope; gy.w = yy.w > 0.f ? g4.w : g4.w * p.slope;
+          g4 = (gy - k1 - (zz - bmu) * k2) * k3;
+          // the products below must see the ROUNDED g_z (what the element-wise pass would have stored), not a value
+          // hipcc contracts into their FMAs
+          asm volatile("" : "+v"(g4.x), "+v"(g4.y), "+v"(g4.z), "+v"(g4.w));
+          *reinterpret_cast<f32x4*>(p.gz_out + goff + f * 4) = g4;
+        }
         f32x4 px[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) px[t] = *reinterpret_cast<const f32x4*>(xrow + (t / 3) * rs + (vx + t % 3) * 4);
@@ -549,25 +576,52 @@ static void launch4(const Wgrad4Args& a, int nchunks, hipStream_t st) {
   hipLaunchKernelGGL(conv4_wgrad_kernel<NB>, dim3(nchunks), dim3(256), lds, st, a);
 }
 
+static int conv4_wgrad_rows_launch(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout, int Cin,
+                                   float* dW, float* db, int accumulate, float* workspace, bool apply,
+                                   const float* bn_z, const float* scale, const float* shift, const float* mean,
+                                   const float* coef, float slope, float* gz_out, void* stream) {
+  Wgrad4RowsArgs r;
+  const int grid = conv4_wgrad_rows_grid(gout);
+  r.x4 = x4; r.gz = gz; r.partial = workspace; r.partial_db = workspace + (int64_t)grid * 2048;
+  r.gin = as_make_dev(gin); r.gout = as_make_dev(gout);
+  r.chunks_per_row = (gout->W + 127) / 128; r.nchunks = gout->B * gout->H * r.chunks_per_row;
+  r.bn_z = bn_z; r.bn_scale = scale; r.bn_shift = shift; r.bn_mean = mean; r.bn_coef = coef; r.gz_out = gz_out; r.slope = slope;
+  hipStream_t st = (hipStream_t)stream;
+  if (apply) hipLaunchKernelGGL(conv4_wgrad_rows_kernel<true>, dim3(grid), dim3(256), 0, st, r);
+  else hipLaunchKernelGGL(conv4_wgrad_rows_kernel<false>, dim3(grid), dim3(256), 0, st, r);
+  AS_CHECK_LAUNCH("as_conv4_wgrad(rows)");
+  hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up((32 * Cin * 9 + 32) * 32, 256)), dim3(256), 0, st, r.partial,
+                     r.partial_db, grid, 2, 9, Cin, dW, db, accumulate);
+  AS_CHECK_LAUNCH("as_conv4_wgrad(reduce)");
+  return AS_OK;
+}
+
+// Weight gradient fused with stage 3 of the layer's BatchNorm backward (see as_conv32_wgrad_bnapply).
+extern "C" int as_conv4_wgrad_bnapply_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!gin || !gout || !s || !as_pcl_ok(gout)) return AS_ERR_ARG;
+  return conv4_wgrad_rows_applicable(gin, gout, s) ? 1 : 0;
+}
+
+extern "C" int as_conv4_wgrad_bnapply(const float* x4, const as_pcl* gin, const float* g_a, const float* z,
+                                      const as_pcl* gout, const as_conv_shape* s, int Cin, const float* scale,
+                                      const float* shift, const float* mean, const float* coef, float slope, float* g_z,
+                                      float* dW, float* db, int accumulate, float* workspace, void* stream) {
+  if (int e = check4(gin, gout, s, "as_conv4_wgrad_bnapply")) return e;
+  AS_CHECK_ARG(x4 && g_a && z && scale && shift && mean && coef && g_z && dW && workspace && Cin >= 1 && Cin <= 4,
+               "as_conv4_wgrad_bnapply: bad argument");
+  AS_CHECK_ARG(conv4_wgrad_rows_applicable(gin, gout, s), "as_conv4_wgrad_bnapply: configuration not supported");
+  return conv4_wgrad_rows_launch(x4, gin, g_a, gout, Cin, dW, db, accumulate, workspace, true, z, scale, shift, mean, coef,
+                                 slope, g_z, stream);
+}
+
 extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,
                               const as_conv_shape* s, int Cin, float* dW, float* db, int accumulate, float* workspace,
                               void* stream) {
   if (int e = check4(gin, gout, s, "as_conv4_wgrad")) return e;
   AS_CHECK_ARG(x4 && gz && dW && workspace && Cin >= 1 && Cin <= 4, "as_conv4_wgrad: bad argument");
-  if (conv4_wgrad_rows_applicable(gin, gout, s)) {
-    Wgrad4RowsArgs r;
-    const int grid = conv4_wgrad_rows_grid(gout);
-    r.x4 = x4; r.gz = gz; r.partial = workspace; r.partial_db = workspace + (int64_t)grid * 2048;
-    r.gin = as_make_dev(gin); r.gout = as_make_dev(gout);
-    r.chunks_per_row = (gout->W + 127) / 128; r.nchunks = gout->B * gout->H * r.chunks_per_row;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv4_wgrad_rows_kernel, dim3(grid), dim3(256), 0, st, r);
-    AS_CHECK_LAUNCH("as_conv4_wgrad(rows)");
-    hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up((32 * Cin * 9 + 32) * 32, 256)), dim3(256), 0, st, r.partial,
-                       r.partial_db, grid, 2, 9, Cin, dW, db, accumulate);
-    AS_CHECK_LAUNCH("as_conv4_wgrad(reduce)");
-    return AS_OK;
-  }
+  if (conv4_wgrad_rows_applicable(gin, gout, s))
+    return conv4_wgrad_rows_launch(x4, gin, gz, gout, Cin, dW, db, accumulate, workspace, false, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, 0.f, nullptr, stream);
   int nb, rpc, nchunks;
   plan4(gout, s, &nb, &rpc, &nchunks);
   AS_CHECK_ARG(nb >= 1 && nb <= 4, "as_conv4_wgrad: kernel too large");

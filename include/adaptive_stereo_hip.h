@@ -218,6 +218,13 @@ int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* packed_w, cons
                  float* z, const as_pcl* gout, const as_conv_shape* s,
                  int epilogue, const float* ep_scale, const float* ep_shift, float slope,
                  float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
+/* as_conv4_wgrad with stage 3 of the layer's BatchNorm backward applied on the fly (gradient operand = g_a, g_z written as
+ * a by-product; coefficients from as_bn_act_bwd(g_z = NULL), see as_conv32_wgrad_bnapply).  3x3 stride-1 layers only. */
+int as_conv4_wgrad_bnapply_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+int as_conv4_wgrad_bnapply(const float* x4, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                           const as_conv_shape* s, int Cin, const float* scale, const float* shift, const float* mean,
+                           const float* coef, float slope, float* g_z, float* dW, float* db, int accumulate,
+                           float* workspace, void* stream);
 int64_t as_conv4_wgrad_workspace(const as_pcl* gout, const as_conv_shape* s);
 int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,
                    const as_conv_shape* s, int Cin, float* dW, float* db, int accumulate, float* workspace,

@@ -546,3 +546,41 @@ def test_conv32_wgrad_fused_with_bn_backward_apply():
   halo = gzv.clone(); ops.pcl_interior(halo, g).zero_()
   assert float(halo.abs().max()) == 0.0, "the halo of g_z must stay zero"
   assert torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
+
+
+def test_conv4_wgrad_fused_with_bn_backward_apply():
+  """as_conv4_wgrad_bnapply against as_bn_act_bwd + as_conv4_wgrad: g_z bit for bit (same arithmetic per element),
+  dW / db bit for bit (same products, same order)."""
+  B, H, W = 2, 37, 150
+  g4, g = Pcl(B, 1, H, W, 0, 8, 8), Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(1)
+  lib = nat.load()
+  assert lib.as_conv4_wgrad_bnapply_ok(g4, g, shape) == 1
+  x4 = torch.zeros(lib.as_pcl4_numel(g4), device=DEV)
+  ch0, img = rnd(B, 1, H, W, seed=1).to(DEV), rnd(B, 3, H, W, seed=2).to(DEV)
+  nat.call("as_pack_in4", nat.ptr(ch0), nat.ptr(img), 3, nat.ptr(x4), g4, nat.stream())
+  g_a = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=3).to(DEV), g)
+  z = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=4).to(DEV), g)
+  st = ops.BnState(DEV)
+  st.mean.copy_(rnd(32, seed=5).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=6).abs().to(DEV) + 0.5)
+  gamma = (rnd(32, seed=7).abs() + 0.5).to(DEV)
+  st.scale.copy_(st.invstd * gamma); st.shift.copy_(rnd(32, seed=8).to(DEV) * 0.1 - st.mean * st.scale)
+  gz_ref, gg_ref, gb_ref = ops.bn_act_bwd(g_a, z, st, gamma, g, True)
+  dW_ref = torch.zeros(32, 4, 3, 3, device=DEV); db_ref = torch.zeros(32, device=DEV)
+  ws = torch.empty(lib.as_conv4_wgrad_workspace(g, shape), device=DEV)
+  nat.call("as_conv4_wgrad", nat.ptr(x4), g4, nat.ptr(gz_ref), g, shape, 4, nat.ptr(dW_ref), nat.ptr(db_ref), 0, nat.ptr(ws),
+           nat.stream())
+  bws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  gg, gb = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+  nat.call("as_bn_act_bwd", nat.ptr(g_a), nat.ptr(z), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(st.mean),
+           nat.ptr(st.invstd), nat.ptr(gamma), 0.2, 1, None, nat.ptr(gg), nat.ptr(gb), 0, nat.ptr(bws), g, nat.stream())
+  coef = bws[lib.as_bn_bwd_coef_offset():]
+  gz = ops.pcl_zeros(g, DEV)
+  dW = torch.zeros(32, 4, 3, 3, device=DEV); db = torch.zeros(32, device=DEV)
+  nat.call("as_conv4_wgrad_bnapply", nat.ptr(x4), g4, nat.ptr(g_a), nat.ptr(z), g, shape, 4, nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gz), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
+  assert torch.equal(gg, gg_ref) and torch.equal(gb, gb_ref)
+  assert torch.equal(ops.pcl_interior(ops.pcl_view(gz, g), g), ops.pcl_interior(ops.pcl_view(gz_ref, g), g))
+  halo = ops.pcl_view(gz, g).clone(); ops.pcl_interior(halo, g).zero_()
+  assert float(halo.abs().max()) == 0.0
+  assert torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
