@@ -346,7 +346,7 @@ static int launch_conv32(const ConvArgs& a, hipStream_t st, const char* who) {
 // Split by the parity (py,px) of (yi,xi): each phase is an ordinary gather-convolution over gz with the
 // taps j = py, py+2(, py+4), l likewise (9/6/6/4 taps), writing every second output pixel.  gz's zero
 // halo (>= 1) supplies the bounds.  packed[t][q][lane=(h,j)][e] = w[o = 16h+4q+e][i = j][tap_t].
-struct TapSubset { int n; int idx[9]; };
+struct TapSubset { int n; int idx[25]; };
 
 __global__ void pack_weights_subset_kernel(const float* __restrict__ w, float* __restrict__ packed, int T, TapSubset ts) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -368,30 +368,36 @@ extern "C" int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const floa
   hipStream_t st = (hipStream_t)stream;
   const int Wp = ggz->W + 2 * ggz->pw;
   float* wp = workspace;
+  // all four parity phases' weights in one launch: the 25 taps in phase-major order (9 + 6 + 6 + 4)
+  TapSubset all; all.n = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px)
+      for (int j = py; j < 5; j += 2)
+        for (int l = px; l < 5; l += 2) all.idx[all.n++] = j * 5 + l;
+  hipLaunchKernelGGL(pack_weights_subset_kernel, dim3(as_div_up(all.n * 1024, 256)), dim3(256), 0, st, w, wp, 25, all);
+  AS_CHECK_LAUNCH("as_conv32_dgrad_s2(pack)");
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       const int Hl = (ggx->H - py + 1) / 2, Wl = (ggx->W - px + 1) / 2;
-      if (Hl <= 0 || Wl <= 0) continue;
       ConvArgs a;
-      TapSubset ts; ts.n = 0;
+      int n = 0;
       for (int j = py; j < 5; j += 2)
         for (int l = px; l < 5; l += 2) {
-          ts.idx[ts.n] = j * 5 + l;
           // yi = 2y'+py: yo = y' + (py + 2 - j)/2 ; same for x
-          a.tap_off[ts.n] = ((py + 2 - j) / 2) * Wp + (px + 2 - l) / 2;
-          ++ts.n;
+          a.tap_off[n] = ((py + 2 - j) / 2) * Wp + (px + 2 - l) / 2;
+          ++n;
         }
-      hipLaunchKernelGGL(pack_weights_subset_kernel, dim3(as_div_up(ts.n * 1024, 256)), dim3(256), 0, st, w, wp, 25, ts);
-      AS_CHECK_LAUNCH("as_conv32_dgrad_s2(pack)");
-      a.x = gz; a.wp = wp;
-      a.ep.bias = nullptr; a.ep.z = gx; a.ep.ep_scale = nullptr; a.ep.ep_shift = nullptr; a.ep.residual = nullptr;
-      a.ep.stat_mean = nullptr; a.ep.stat_m2 = nullptr; a.ep.stat_cnt = nullptr; a.ep.epilogue = 0; a.ep.slope = 0.f;
-      a.gin = as_make_dev(ggz); a.gout = as_make_dev(ggx);
-      a.map.Hl = Hl; a.map.Wl = Wl; a.map.in_stride = 1; a.map.out_stride = 2; a.map.out_oy = py; a.map.out_ox = px;
-      a.M = ggx->B * Hl * Wl; a.ntaps = ts.n;
-      if (int e = launch_conv32(a, st, "as_conv32_dgrad_s2")) return e;
-      AS_CHECK_LAUNCH("as_conv32_dgrad_s2");
-      wp += ts.n * 1024;
+      if (Hl > 0 && Wl > 0) {
+        a.x = gz; a.wp = wp;
+        a.ep.bias = nullptr; a.ep.z = gx; a.ep.ep_scale = nullptr; a.ep.ep_shift = nullptr; a.ep.residual = nullptr;
+        a.ep.stat_mean = nullptr; a.ep.stat_m2 = nullptr; a.ep.stat_cnt = nullptr; a.ep.epilogue = 0; a.ep.slope = 0.f;
+        a.gin = as_make_dev(ggz); a.gout = as_make_dev(ggx);
+        a.map.Hl = Hl; a.map.Wl = Wl; a.map.in_stride = 1; a.map.out_stride = 2; a.map.out_oy = py; a.map.out_ox = px;
+        a.M = ggx->B * Hl * Wl; a.ntaps = n;
+        if (int e = launch_conv32(a, st, "as_conv32_dgrad_s2")) return e;
+        AS_CHECK_LAUNCH("as_conv32_dgrad_s2");
+      }
+      wp += n * 1024;
     }
   return AS_OK;
 }
