@@ -67,6 +67,9 @@ _SIGNATURES = {
   "as_bn_act_bwd_given": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp, c_int, c_vp,
                                   _P(Pcl), c_int, c_vp]),
   "as_bn_bwd_coef_offset": (c_i64, []),
+  "as_bn_bwd_sums": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp, _P(Pcl), c_int, c_vp, c_vp]),
+  "as_bn_bwd_finalize_synced": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+  "as_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp, c_vp, _P(Pcl), c_vp]),
   "as_conv32_wgrad_bnapply_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_wgrad_bnapply": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_float,
                                       c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),

@@ -127,7 +127,7 @@ class OnlineAdapter(object):
   """feature_net + stereo_net + warper + optimiser bound together for the per-step sequence."""
 
   def __init__(self, feature_net, stereo_net, height, width, lr=5e-5, clip_grad_norm=True,
-               smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None):
+               smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None, sync_bn=False):
     self.feature_net, self.stereo_net = feature_net, stereo_net
     self.scale = stereo_net.input_scale
     self.coarse_scale = stereo_net.input_scale + stereo_net.k
@@ -140,6 +140,9 @@ class OnlineAdapter(object):
     self.optimizer = FusedClipAdam(self.arena, lr)
     self.pg = process_group
     self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    # sync_bn: train-mode BatchNorm over the batches of all ranks (= the reference's single-process batch); default is
+    # per-replica statistics, as DistributedDataParallel without SyncBatchNorm.  Eager stepping only.
+    self.bn_sync = hip_ops.BnSync(process_group) if (sync_bn and self.world > 1) else None
     dev = self.arena.params.device
     self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [count, loss_sum, fcs_sum, pairs]
     self._graph = None
@@ -206,6 +209,7 @@ class OnlineAdapter(object):
     self.arena.rebind_grads()
     self.arena.zero_grads()
     self.plan.begin()
+    prev_sync = hip_ops.set_bn_sync(self.bn_sync)
     try:
       total, mask, fcs_map, out, warped = self._forward_maps(left, right)
 
@@ -216,6 +220,7 @@ class OnlineAdapter(object):
       else:
         loss, fcs = self._distributed_backward(total, mask, fcs_map, left.shape[0])
     finally:
+      hip_ops.set_bn_sync(prev_sync)
       self.plan.end()
 
     self.optimizer.step(clip=self.clip)
@@ -239,6 +244,7 @@ class OnlineAdapter(object):
       self.arena.zero_grads()
     if train:
       self.plan.begin()
+    prev_sync = hip_ops.set_bn_sync(self.bn_sync if train else None)
     try:
       with torch.set_grad_enabled(train):
         fl, fr = self.feature_net(left), self.feature_net(right)
@@ -256,6 +262,7 @@ class OnlineAdapter(object):
           replay_loss = khamis_robust_loss(rout["pred_disp_l/{}".format(self.scale)], rgt)
           backprop = loss + er_loss_weight * replay_loss
     finally:
+      hip_ops.set_bn_sync(prev_sync)
       if train:
         self.plan.end(final=False)
     fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)]).mean()
@@ -275,9 +282,11 @@ class OnlineAdapter(object):
   def backward_update(self, result):
     """backward + clip + Adam for a result of forward_loss(train=True) (adapt.py:381-394)."""
     self.plan.begin(resume=True)  # backward re-packs the (unchanged) weights: one launch
+    prev_sync = hip_ops.set_bn_sync(self.bn_sync)
     try:
       result["backprop_loss"].backward()
     finally:
+      hip_ops.set_bn_sync(prev_sync)
       self.plan.end()
     if self.world > 1:
       allreduce_gradients(self.arena.grads.div_(self.world), self.pg)
@@ -305,6 +314,9 @@ class OnlineAdapter(object):
     are copied into static buffers before each replay.
     One GPU: a single graph.  Data parallel: three graphs (forward + local sums | backward | clip + Adam + EMA)
     with the two RCCL all-reduces issued between them on the same stream, outside any capture."""
+    if self.bn_sync is not None:
+      raise RuntimeError("OnlineAdapter.capture: cross-replica BatchNorm puts collectives inside forward and backward; "
+                         "a step cannot be captured with sync_bn=True (step() runs eagerly)")
     self._static_left, self._static_right = left.clone(), right.clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

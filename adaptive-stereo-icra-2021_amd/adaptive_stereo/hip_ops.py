@@ -273,6 +273,7 @@ class StatParts(object):
   def __init__(self, nparts, device):
     self.nparts = int(nparts)
     buf = torch.empty(self.nparts * 65, dtype=torch.float32, device=device)
+    self.buf = buf
     self.mean = buf[:self.nparts * 32]
     self.m2 = buf[self.nparts * 32:self.nparts * 64]
     self.cnt = buf[self.nparts * 64:]
@@ -310,8 +311,44 @@ class BnState(object):
     self.mean, self.invstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
 
 
+class BnSync(object):
+  """Cross-replica BatchNorm for data-parallel adaptation: train-mode statistics and the backward's
+  per-channel sums span the batches of ALL ranks of ``group``, as the reference's single-process BatchNorm over the
+  whole batch does (stereo_net.py:17,29).  Every rank merges the same partials in the same (rank-major) order, so
+  the replicas stay bit-identical.  Collectives cannot be captured: stepping is eager while this is on."""
+
+  def __init__(self, group=None):
+    import torch.distributed as dist
+    self.dist, self.group = dist, group
+    self.world = dist.get_world_size(group)
+
+
+_BN_SYNC = None
+
+
+def set_bn_sync(sync):
+  """BnSync or None; returns the previous setting."""
+  global _BN_SYNC
+  prev, _BN_SYNC = _BN_SYNC, sync
+  return prev
+
+
+def _gathered_stats(stats: StatParts, sync: BnSync):
+  """The (count, mean, M2) partials of all ranks, rank-major, in one StatParts."""
+  n, w = stats.nparts, sync.world
+  every = torch.empty(w, n * 65, dtype=torch.float32, device=stats.buf.device)
+  sync.dist.all_gather(list(every.unbind(0)), stats.buf, group=sync.group)
+  out = StatParts(n * w, stats.buf.device)
+  out.mean.view(w, n * 32).copy_(every[:, :n * 32])
+  out.m2.view(w, n * 32).copy_(every[:, n * 32:n * 64])
+  out.cnt.view(w, n).copy_(every[:, n * 64:])
+  return out
+
+
 def bn_train_stats(stats: StatParts, gamma, beta, running_mean, running_var):
   st = BnState(gamma.device)
+  if _BN_SYNC is not None:
+    stats = _gathered_stats(stats, _BN_SYNC)
   call("as_bn_finalize", ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stats.nparts, ptr(gamma), ptr(beta),
        ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS, ptr(st.mean), ptr(st.invstd),
        ptr(st.scale), ptr(st.shift), stream())
@@ -343,11 +380,39 @@ class BnBwdSums(object):
     self.workspace, self.nparts = workspace, nparts
 
 
+def bn_bwd_coefs(g_a, z, st: BnState, gamma, g: Pcl, train: bool, g_gamma, g_beta, accumulate, ws, sums=None):
+  """Stages 1-2 of the BatchNorm backward (stage 1 may already be in ``sums``): parameter gradients into g_gamma /
+  g_beta, stage-3 coefficients left in ``ws`` at as_bn_bwd_coef_offset()."""
+  sync = _BN_SYNC if train else None
+  if sync is None:
+    if sums is not None:
+      call("as_bn_act_bwd_given", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+           LEAKY_SLOPE, int(train), None, ptr(g_gamma), ptr(g_beta), int(accumulate), ptr(ws), g, sums.nparts, stream())
+    else:
+      call("as_bn_act_bwd", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
+           LEAKY_SLOPE, int(train), None, ptr(g_gamma), ptr(g_beta), int(accumulate), ptr(ws), g, stream())
+    return
+  local = torch.empty(65, dtype=torch.float64, device=z.device)
+  call("as_bn_bwd_sums", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), LEAKY_SLOPE, ptr(ws), g,
+       sums.nparts if sums is not None else 0, ptr(local), stream())
+  everyone = local.clone()
+  sync.dist.all_reduce(everyone, op=sync.dist.ReduceOp.SUM, group=sync.group)
+  call("as_bn_bwd_finalize_synced", ptr(local), ptr(everyone), ptr(st.invstd), ptr(gamma), ptr(g_gamma), ptr(g_beta),
+       int(accumulate), ptr(ws), stream())
+
+
 def bn_act_bwd(g_a, z, st: BnState, gamma, g: Pcl, train: bool, sink_gamma=None, sink_beta=None, sums=None):
   lib = nat.load()
   dev = z.device
   g_z = POOL.get(g, dev)
   ws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
+  if train and _BN_SYNC is not None:
+    sunk = sink_gamma is not None and sink_beta is not None
+    g_gamma, g_beta = (sink_gamma, sink_beta) if sunk else (_empty(32, dev), _empty(32, dev))
+    bn_bwd_coefs(g_a, z, st, gamma, g, train, g_gamma, g_beta, sunk, ws, sums)
+    call("as_bn_bwd_apply", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), LEAKY_SLOPE, ptr(g_z), ptr(ws),
+         g, stream())
+    return (g_z, None, None) if sunk else (g_z, g_gamma, g_beta)
   fn = "as_bn_act_bwd_given" if sums is not None else "as_bn_act_bwd"
   tail = (ptr(ws), g, sums.nparts, stream()) if sums is not None else (ptr(ws), g, stream())
   if sink_gamma is not None and sink_beta is not None:
@@ -424,12 +489,7 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
     # which stages g_out and z rows, applies it in LDS, accumulates dW / db and writes g_z for the data gradient
     dev = z.device
     ws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
-    if sums is not None:
-      call("as_bn_act_bwd_given", ptr(g_out), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-           LEAKY_SLOPE, int(train), None, ptr(sg), ptr(sbeta), 1, ptr(ws), g, sums.nparts, stream())
-    else:
-      call("as_bn_act_bwd", ptr(g_out), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
-           LEAKY_SLOPE, int(train), None, ptr(sg), ptr(sbeta), 1, ptr(ws), g, stream())
+    bn_bwd_coefs(g_out, z, st, gamma, g, train, sg, sbeta, True, ws, sums)
     coef = ws[lib.as_bn_bwd_coef_offset():]
     g_z = POOL.get(g, dev)
     wws = _empty(lib.as_conv32_wgrad_workspace(g, g, shape), dev)
@@ -820,12 +880,7 @@ class EdgeRefineFn(torch.autograd.Function):
       # stages 1-2 of the BatchNorm backward (stage 1 usually already in `sums`); stage 3 rides on the weight gradient
       bws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
       st0 = ctx.st0
-      if sums is not None:
-        call("as_bn_act_bwd_given", ptr(g_a), ptr(ctx.z0), ptr(st0.scale), ptr(st0.shift), ptr(st0.mean), ptr(st0.invstd),
-             ptr(gamma0), LEAKY_SLOPE, int(ctx.train), None, ptr(sinks[2]), ptr(sinks[3]), 1, ptr(bws), g, sums.nparts, stream())
-      else:
-        call("as_bn_act_bwd", ptr(g_a), ptr(ctx.z0), ptr(st0.scale), ptr(st0.shift), ptr(st0.mean), ptr(st0.invstd),
-             ptr(gamma0), LEAKY_SLOPE, int(ctx.train), None, ptr(sinks[2]), ptr(sinks[3]), 1, ptr(bws), g, stream())
+      bn_bwd_coefs(g_a, ctx.z0, st0, gamma0, g, ctx.train, sinks[2], sinks[3], True, bws, sums)
       coef = bws[lib.as_bn_bwd_coef_offset():]
       g_z0 = POOL.get(g, dev)
       call("as_conv4_wgrad_bnapply", ptr(ctx.in4), g4, ptr(g_a), ptr(ctx.z0), g, s33, 4, ptr(st0.scale), ptr(st0.shift),

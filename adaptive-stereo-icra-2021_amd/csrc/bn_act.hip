@@ -401,6 +401,92 @@ static int bn_act_bwd_impl(const float* g_a, const float* z, const float* scale,
   return AS_OK;
 }
 
+// ---- cross-replica ("synchronised") BatchNorm backward: stages 1+2a | all-reduce by the caller | 2b | 3 ----------
+// stage 2a: the fixed-order slab sum of bn_bwd_finalize_kernel alone; sums[64] = element count
+__global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const double* __restrict__ partial, int nblocks, long count,
+                                                           double* __restrict__ sums) {
+  __shared__ double red[16][64];
+  const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  double s = 0.0;
+#pragma unroll 8
+  for (int i = sl; i < nblocks; i += 16) s += partial[(long)i * 64 + j];
+  red[sl][j] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+    sums[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 64) sums[64] = (double)count;
+}
+
+// stage 2b: parameter gradients from THIS replica's sums (the gradient all-reduce adds the replicas'), stage-3
+// coefficients from the sums and the element count of ALL replicas
+__global__ void bn_bwd_finalize_synced_kernel(const double* __restrict__ local, const double* __restrict__ global,
+                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                              float* g_gamma, float* g_beta, float* coef, int accumulate) {
+  const int c = threadIdx.x;
+  if (c >= 32) return;
+  const double is = (double)invstd[c];
+  const double ldy = local[c], ldx = local[32 + c];
+  g_gamma[c] = accumulate ? g_gamma[c] + (float)(ldx * is) : (float)(ldx * is);
+  g_beta[c] = accumulate ? g_beta[c] + (float)ldy : (float)ldy;
+  const double count = global[64];
+  coef[c] = (float)(global[c] / count);
+  coef[32 + c] = (float)(global[32 + c] * is * is / count);
+  coef[64 + c] = invstd[c] * gamma[c];
+}
+
+extern "C" int as_bn_bwd_sums(const float* g_a, const float* z, const float* scale, const float* shift,
+                              const float* save_mean, float slope, float* workspace, const as_pcl* g,
+                              int nparts_given, double* sums, void* stream) {
+  AS_CHECK_ARG(as_pcl_ok(g), "as_bn_bwd_sums: bad geometry");
+  AS_CHECK_ARG(workspace && sums, "as_bn_bwd_sums: null pointer");
+  AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0 && ((uintptr_t)sums & 7) == 0, "as_bn_bwd_sums: 8-byte alignment required");
+  AS_CHECK_ARG(nparts_given >= 0 && nparts_given <= BNB_BLOCKS, "as_bn_bwd_sums: %d partials", nparts_given);
+  const long M = (long)g->B * g->D * g->H * g->W;
+  const long nch = row_chunks(g);
+  AS_CHECK_ARG(nch < (1L << 31), "as_bn_bwd_sums: volume too large");
+  const int nb = nparts_given > 0 ? nparts_given : bnb_blocks(nch);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  if (nparts_given == 0) {
+    AS_CHECK_ARG(g_a && z && scale && shift && save_mean, "as_bn_bwd_sums: null pointer");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, g_a, z, scale, shift, save_mean, slope,
+                       partial, as_make_dev(g), (int)nch, chunks_per_row(g));
+    AS_CHECK_LAUNCH("as_bn_bwd_sums(reduce)");
+  }
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(1), dim3(1024), 0, st, partial, nb, M, sums);
+  AS_CHECK_LAUNCH("as_bn_bwd_sums");
+  return AS_OK;
+}
+
+extern "C" int as_bn_bwd_finalize_synced(const double* local_sums, const double* global_sums, const float* save_invstd,
+                                         const float* gamma, float* g_gamma, float* g_beta, int accumulate,
+                                         float* workspace, void* stream) {
+  AS_CHECK_ARG(local_sums && global_sums && save_invstd && gamma && g_gamma && g_beta && workspace,
+               "as_bn_bwd_finalize_synced: null pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_synced_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, local_sums, global_sums,
+                     save_invstd, gamma, g_gamma, g_beta, workspace + (int64_t)BNB_BLOCKS * 128, accumulate);
+  AS_CHECK_LAUNCH("as_bn_bwd_finalize_synced");
+  return AS_OK;
+}
+
+extern "C" int as_bn_bwd_apply(const float* g_a, const float* z, const float* scale, const float* shift,
+                               const float* save_mean, float slope, float* g_z, const float* workspace,
+                               const as_pcl* g, void* stream) {
+  AS_CHECK_ARG(as_pcl_ok(g), "as_bn_bwd_apply: bad geometry");
+  AS_CHECK_ARG(g_a && z && scale && shift && save_mean && g_z && workspace, "as_bn_bwd_apply: null pointer");
+  const long nch = row_chunks(g);
+  AS_CHECK_ARG(nch < (1L << 31), "as_bn_bwd_apply: volume too large");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(elementwise_blocks(nch)), dim3(256), 0, (hipStream_t)stream, g_a, z, scale,
+                     shift, save_mean, workspace + (int64_t)BNB_BLOCKS * 128, slope, g_z, as_make_dev(g), (int)nch,
+                     chunks_per_row(g));
+  AS_CHECK_LAUNCH("as_bn_bwd_apply");
+  return AS_OK;
+}
+
 extern "C" int as_bn_act_bwd(const float* g_a, const float* z, const float* scale, const float* shift,
                              const float* save_mean, const float* save_invstd, const float* gamma,
                              float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,

@@ -42,6 +42,9 @@ def parse():
   ap.add_argument("--k", type=int, default=4)
   ap.add_argument("--maxdisp", type=int, default=192)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--sync-bn", action="store_true", help="N>1: train-mode BatchNorm over the batches of all ranks (the "
+                  "reference's whole-batch semantics; 34 small collectives per step, eager launches) instead of "
+                  "per-replica statistics")
   ap.add_argument("--no-graph", action="store_true", help="launch the ~540 kernels of a step eagerly instead of "
                                                           "replaying a captured hipGraph (single GPU only)")
   return ap.parse_args()
@@ -160,10 +163,10 @@ def main():
   B = args.batch
   left, right = syn.stereo_pair(B, args.height, args.width, seed=1 + rank)
   left, right = left.to(dev), right.to(dev)
-  adapter = OnlineAdapter(fnet, snet, args.height, args.width, lr=5e-5, clip_grad_norm=True)
+  adapter = OnlineAdapter(fnet, snet, args.height, args.width, lr=5e-5, clip_grad_norm=True, sync_bn=args.sync_bn)
 
   lib = nat.load()
-  use_graph = not args.no_graph
+  use_graph = not args.no_graph and adapter.bn_sync is None     # collectives inside forward/backward: not capturable
   log("setup done: %d pairs/GPU at %dx%d, world %d, %s" % (B, args.width, args.height, world,
                                                            "hipGraph replay" if use_graph else "eager launches"))
   # ---- forward + adaptation step ---------------------------------------------------------
@@ -287,7 +290,8 @@ def main():
                                args.width, args.height, args.maxdisp, args.k, (args.maxdisp + 1) // 2 ** args.k,
                                -(-args.height // 2 ** args.k), -(-args.width // 2 ** args.k)),
                "pairs_per_gpu": B, "global_batch": world * B,
-               "parallelism": "dp%d (per-replica BatchNorm statistics, one flat RCCL gradient all-reduce)" % world,
+               "parallelism": "dp%d (%s BatchNorm statistics, one flat RCCL gradient all-reduce)" % (
+                   world, "cross-replica" if adapter.bn_sync is not None else "per-replica"),
                "kernels": "all hand-written HIP (no MIOpen/rocBLAS on the path)"},
     "launch_mode": "hipGraph replay of the captured step" if use_graph else "eager",
     "eager_ms_per_step": round(1e3 * t_adapt_eager / args.steps, 3),

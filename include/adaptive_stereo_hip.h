@@ -173,6 +173,28 @@ int as_bn_act_bwd_given(const float* g_a, const float* z, const float* scale, co
                         float slope, int train, float* g_z, float* g_gamma, float* g_beta, int accumulate,
                         float* workspace, const as_pcl* g, int nparts, void* stream);
 
+/* Cross-replica ("synchronised") BatchNorm in data-parallel adaptation (the reference's train-mode
+ * BatchNorm, stereo_net.py:17,29, sees the whole batch).  Forward needs nothing new: the replicas exchange their
+ * convolution partials (count, mean, M2) and every one calls as_bn_finalize on the concatenation.  Backward splits
+ * as_bn_act_bwd at the point where the replicas must meet:
+ *   as_bn_bwd_sums: stage 1 (skipped when nparts_given > 0: the slabs are already in the workspace, see
+ *     as_conv32_fwd_bnbwd) + the fixed-order slab sum -> sums[65] doubles = [sum g_y][32], [sum g_y*(z-mean)][32],
+ *     element count.  The caller all-reduces (sum) a COPY of it.
+ *   as_bn_bwd_finalize_synced: g_gamma / g_beta from this replica's sums (the parameter-gradient all-reduce adds the
+ *     replicas' later), stage-3 coefficients from the all-reduced sums and count, left in the workspace at
+ *     as_bn_bwd_coef_offset().
+ *   as_bn_bwd_apply: stage 3 alone (g_z on the PCL interior); as_conv32_wgrad_bnapply / as_conv4_wgrad_bnapply take the
+ *     same coefficients instead when stage 3 rides on the weight gradient. */
+int as_bn_bwd_sums(const float* g_a, const float* z, const float* scale, const float* shift,
+                   const float* save_mean, float slope, float* workspace, const as_pcl* g,
+                   int nparts_given, double* sums, void* stream);
+int as_bn_bwd_finalize_synced(const double* local_sums, const double* global_sums, const float* save_invstd,
+                              const float* gamma, float* g_gamma, float* g_beta, int accumulate,
+                              float* workspace, void* stream);
+int as_bn_bwd_apply(const float* g_a, const float* z, const float* scale, const float* shift,
+                    const float* save_mean, float slope, float* g_z, const float* workspace,
+                    const as_pcl* g, void* stream);
+
 /* ---- a4 + a5 + a8: conv3d 32->1, soft-argmax, arg-max index, FCS ---------------
  * nn.Conv3d(32,1,3,padding=1) (stereo_net.py:162,187), F.softmax(dim=1) +
  * DisparityRegression (stereo_net.py:190-192,124-134), feature_contrast_mean

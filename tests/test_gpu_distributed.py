@@ -142,3 +142,101 @@ def test_two_rank_graph_replay_equals_eager(tmp_path):
   assert got["losses_equal"], got["losses"]
   assert got["params_equal"], got["max_diff"]
   assert got["ranks_equal"]
+
+
+def _named_grads_and_buffers(adapter, fnet, snet):
+  grads, bufs = {}, {}
+  for net_name, net in (("stereo", snet), ("feature", fnet)):
+    for name, p in net.named_parameters():
+      if p.grad is not None:
+        grads["%s.%s" % (net_name, name)] = p.grad.detach().cpu().clone()
+    for name, b in net.named_buffers():
+      bufs["%s.%s" % (net_name, name)] = b.detach().cpu().clone()
+  return grads, bufs
+
+
+def _sync_bn_worker(rank, world, port, out_path):
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  from adaptive_stereo.adaptation import OnlineAdapter
+  fnet, snet, fsd, ssd, left, right = _states()
+  fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+  fnet, snet = fnet.cuda(), snet.cuda()
+  adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5, sync_bn=True)
+  assert adapter.world == 2 and adapter.bn_sync is not None
+  with pytest.raises(RuntimeError):
+    adapter.capture(left[:2].cuda(), right[:2].cuda())
+  lo = rank * 2
+  res = adapter.step(left[lo:lo + 2].cuda(), right[lo:lo + 2].cuda())
+  torch.cuda.synchronize()
+  grads, bufs = _named_grads_and_buffers(adapter, fnet, snet)
+  params = adapter.arena.params.detach().cpu()
+  flat_bufs = torch.cat([b.double().reshape(-1) for _, b in sorted(bufs.items())])
+  gathered = [torch.zeros_like(params) for _ in range(world)]
+  gathered_b = [torch.zeros_like(flat_bufs) for _ in range(world)]
+  dist.all_gather(gathered, params)
+  dist.all_gather(gathered_b, flat_bufs)
+  if rank == 0:
+    torch.save({"loss": float(res["loss"]), "fcs": float(res["fcs"]), "grads": grads, "buffers": bufs,
+                "params_equal": bool(torch.equal(gathered[0], gathered[1])),
+                "buffers_equal": bool(torch.equal(gathered_b[0], gathered_b[1]))}, out_path)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_the_whole_batch_step(tmp_path):
+  """sync_bn=True: two ranks with two pairs each must reproduce ONE process stepping on all four pairs — the
+  reference's semantics, whose train-mode BatchNorm (stereo_net.py:17,29) and masked-mean loss (adapt.py:83) see the
+  whole batch.  Compared with this build's own single-process step (same kernels: only the merge order of the
+  BatchNorm partials differs) and with the oracle's whole-batch loss."""
+  from oracle import stereo_oracle as orc
+  from adaptive_stereo.adaptation import OnlineAdapter
+  out_path = str(tmp_path / "dp_syncbn.pt")
+  mp.spawn(_sync_bn_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+  got = torch.load(out_path)
+  assert got["params_equal"] and got["buffers_equal"], "ranks diverged"
+
+  fnet, snet, fsd, ssd, left, right = _states()
+  fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+  fnet, snet = fnet.cuda(), snet.cuda()
+  adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+  assert adapter.world == 1
+  one = adapter.step(left.cuda(), right.cuda())
+  torch.cuda.synchronize()
+  grads, bufs = _named_grads_and_buffers(adapter, fnet, snet)
+
+  assert abs(got["loss"] - float(one["loss"])) <= 1e-6 * max(1.0, abs(float(one["loss"]))), (got["loss"], float(one["loss"]))
+  assert abs(got["fcs"] - float(one["fcs"])) <= 1e-5 * max(1.0, abs(float(one["fcs"])))
+  assert set(got["grads"]) == set(grads)
+  gmax = max(float(g.abs().max()) for g in grads.values())
+  worst = 0.0
+  for key, ref in grads.items():
+    if float(ref.abs().max()) < 1e-6 * gmax:
+      continue                                   # rounding noise
+    wkey = key[:-len("bias")] + "weight"
+    if key.endswith(".bias") and wkey in grads and float(ref.abs().max()) < 1e-4 * float(grads[wkey].abs().max()):
+      continue                                   # a convolution bias in front of a BatchNorm: exactly zero in theory
+    rel = float((got["grads"][key].double() - ref.double()).norm() / ref.double().norm())
+    worst = max(worst, rel)
+    assert rel <= 2e-3, "%s: relative L2 error %.3e against the single-process step" % (key, rel)
+  for key, ref in bufs.items():
+    b = got["buffers"][key]
+    if not ref.is_floating_point():
+      assert int(b) == int(ref), key
+    else:
+      assert float((b - ref).abs().max()) <= 1e-6 + 1e-5 * float(ref.abs().max()), key
+
+  # the oracle on the whole batch in one process
+  fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
+  ref = orc.adapt_step(fp, sp, {}, left, right, K, 0, MAXDISP)
+  assert abs(got["loss"] - float(ref["loss"])) < 2e-5, (got["loss"], float(ref["loss"]))
+  assert abs(got["fcs"] - float(ref["fcs"])) < 1e-4 * max(1.0, abs(float(ref["fcs"])))
+  for net_name, ref_p in (("stereo", sp), ("feature", fp)):
+    for key, ref_t in ref_p.items():
+      if key.endswith(("running_mean", "running_var")):
+        b = got["buffers"]["%s.%s" % (net_name, key)]
+        assert float((b - ref_t.detach()).abs().max()) <= 2e-5 + 1e-3 * float(ref_t.detach().abs().max()), key
