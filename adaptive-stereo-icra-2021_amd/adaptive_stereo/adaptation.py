@@ -149,6 +149,7 @@ class OnlineAdapter(object):
     self.plan = hip_ops.StepPlan()     # one-launch weight packing / batch counters (recorded on the first step)
     self.infer_plan = hip_ops.StepPlan()   # same for the eval-mode forward (+ all BatchNorm affines in one launch)
     self._infer_graph = None
+    self._side = None                      # second stream for the right image's feature extraction
 
   # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
   @torch.no_grad()
@@ -164,12 +165,26 @@ class OnlineAdapter(object):
     self.feature_net.eval(); self.stereo_net.eval()
     self.infer_plan.begin()
     try:
-      fl, fr = self.feature_net(left), self.feature_net(right)
+      fl, fr = self._features_two_streams(left, right)
       out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     finally:
       self.infer_plan.end()
     fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
     return out, fcs
+
+  def _features_two_streams(self, left, right):
+    """The two feature extractions of a pair are independent and, at 1/16 resolution, far too small to fill the chip
+    (a 24x78 map is 59 workgroups): the right image's runs on a second HIP stream next to the left one's.  Inside a
+    captured graph the fork/join become two parallel branches."""
+    main = torch.cuda.current_stream()
+    if self._side is None:
+      self._side = torch.cuda.Stream()
+    self._side.wait_stream(main)
+    fl = self.feature_net(left)
+    with torch.cuda.stream(self._side):
+      fr = self.feature_net(right)
+    main.wait_stream(self._side)
+    return fl, fr
 
   @torch.no_grad()
   def capture_infer(self, left, right, warmup=2):
@@ -184,8 +199,8 @@ class OnlineAdapter(object):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-      self._infer_result = self._infer_eager(self._infer_left, self._infer_right)
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):   # same stream as the warm-up: the
+      self._infer_result = self._infer_eager(self._infer_left, self._infer_right)     # buffer pool is per stream
     self._infer_graph = graph
     return self
 
@@ -328,13 +343,13 @@ class OnlineAdapter(object):
     self.optimizer.step_count_at_capture = self.optimizer.step_count
     if self.world == 1:
       graph = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-        self._static_result = self._step_eager(self._static_left, self._static_right)
+      with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):   # the warm-up's stream: its
+        self._static_result = self._step_eager(self._static_left, self._static_right)   # pooled buffers are reused
       self._graph = graph
     else:
       if self.pg is not None or dist.is_initialized():
         dist.barrier(group=self.pg)
-      cap = torch.cuda.Stream()          # forward and backward must be captured on the same stream (autograd
+      cap = side                         # forward and backward must be captured on the same stream (autograd
       g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()   # replays backward there)
       with torch.cuda.graph(g1, stream=cap, capture_error_mode="thread_local"):
         self.feature_net.train(); self.stereo_net.train()

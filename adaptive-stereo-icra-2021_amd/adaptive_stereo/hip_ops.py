@@ -81,14 +81,20 @@ class PclPool(object):
   """Recycles PCL buffers.  Kernels only ever write the interior of a PCL tensor, so a buffer
   that was allocated zero-filled keeps a zero halo for life and can be handed out again without
   a memset (a full-resolution activation is 60 MB per pair: clearing ~30 of them per step would
-  cost more HBM traffic than the soft-argmax path moves in total)."""
+  cost more HBM traffic than the soft-argmax path moves in total).
+  Free lists are per HIP stream: a buffer returned while stream S is current is handed out again only to work
+  issued on S, which the stream orders after everything that touched the buffer before (other streams' uses
+  reached S through the event wait of their hand-over).  No cross-stream synchronisation is ever needed."""
 
   def __init__(self):
     self.free = {}
 
+  @staticmethod
+  def _key(device, g, channels):
+    return (str(device), torch.cuda.current_stream(device).cuda_stream, g.key(), channels)
+
   def get(self, g: Pcl, device, channels=32):
-    key = (str(device), g.key(), channels)
-    lst = self.free.get(key)
+    lst = self.free.get(self._key(device, g, channels))
     if lst:
       return lst.pop()
     return torch.zeros(g.numel() // 32 * channels, dtype=torch.float32, device=device)
@@ -96,7 +102,7 @@ class PclPool(object):
   def put(self, buf, g: Pcl, channels=32):
     if buf is None:
       return
-    self.free.setdefault((str(buf.device), g.key(), channels), []).append(buf)
+    self.free.setdefault(self._key(buf.device, g, channels), []).append(buf)
 
   def clear(self):
     self.free.clear()

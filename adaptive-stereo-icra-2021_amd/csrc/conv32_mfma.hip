@@ -69,6 +69,9 @@ __device__ inline void mfma16(f32x16& acc, const f32x4 (&a)[4], const f32x4 (&b)
 // t's sixteen MFMAs).  A runtime tap loop made hipcc (ROCm 7.2) (a) bounce the accumulator between
 // AGPRs and VGPRs at every loop-carried branch, draining the matrix pipe, and (b) wait vmcnt(3)
 // immediately after issuing the prefetch — 40 % of the fp32 MFMA peak instead of the pipelined rate.
+#ifndef AS_CONV32_PREFETCH
+#define AS_CONV32_PREFETCH 1
+#endif
 template <int NT>
 __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
   __shared__ float red[4][32];
@@ -84,22 +87,35 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
   const float* xa = p.x + (long)in_vox * 32 + h * 16;
   const float* wb = p.wp + lane * 4;       // packed [tap][q][lane][4]: each wave load is one contiguous KB
 
-  f32x16 acc;
-  conv_init_acc(acc, p.ep.bias, li);
+  // the bias is requested first and needed (accumulator init) only after the prologue; the load is unconditional
+  // so that no select forces a wait here
+  const float bias_v = p.ep.bias[li];                      // never null here: launch_conv32 substitutes 32 zeros
+  __builtin_amdgcn_sched_barrier(0);
 
-  f32x4 a[2][4], b[2][4];
-  load16(a[0], xa + (long)p.tap_off[0] * 32);
-  loadw(b[0], wb);
+  // Operands are requested PF taps ahead (a ring of PF+1 register sets): on the small maps (24x78 at 1/16 resolution)
+  // every wave of a launch is resident at once and the kernel's duration is ONE wave's chain of NT dependent
+  // load -> 16 MFMA rounds; with a single tap in flight a round took ~1800 cycles against 1024 of matrix work.
+  constexpr int PF = AS_CONV32_PREFETCH, RING = PF + 1;
+  f32x4 a[RING][4], b[RING][4];
+#pragma unroll
+  for (int tp = 0; tp < PF && tp < NT; ++tp) {
+    load16(a[tp % RING], xa + (long)p.tap_off[tp] * 32);
+    loadw(b[tp % RING], wb + tp * 1024);
+    __builtin_amdgcn_sched_barrier(0);                     // in tap order: vmcnt retires in issue order
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = bias_v;
 #pragma unroll
   for (int tp = 0; tp < NT; ++tp) {
-    if (tp + 1 < NT) {
-      load16(a[(tp + 1) & 1], xa + (long)p.tap_off[tp + 1] * 32);
-      loadw(b[(tp + 1) & 1], wb + (tp + 1) * 1024);
+    if (tp + PF < NT) {
+      load16(a[(tp + PF) % RING], xa + (long)p.tap_off[tp + PF] * 32);
+      loadw(b[(tp + PF) % RING], wb + (tp + PF) * 1024);
     }
     // keep the prefetch above the MFMAs: without the fences hipcc sinks every load next to its
     // use (2 loads -> vmcnt -> 4 MFMAs), trading the latency hiding for registers
     __builtin_amdgcn_sched_barrier(0);
-    mfma16(acc, a[tp & 1], b[tp & 1]);
+    mfma16(acc, a[tp % RING], b[tp % RING]);
     __builtin_amdgcn_sched_barrier(0);
   }
   TileStats ts;
@@ -326,7 +342,18 @@ static int check_conv(const as_pcl* gin, const as_pcl* gout, const as_conv_shape
   return AS_OK;
 }
 
-static int launch_conv32(const ConvArgs& a, hipStream_t st, const char* who) {
+__device__ float g_zero_bias[32];          // zero-initialised: the bias of a convolution that has none
+
+static int launch_conv32(const ConvArgs& args, hipStream_t st, const char* who) {
+  ConvArgs a = args;
+  if (a.ep.bias == nullptr) {
+    static const float* zeros = [] {
+      void* sym = nullptr;
+      return hipGetSymbolAddress(&sym, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? static_cast<const float*>(sym) : nullptr;
+    }();
+    if (zeros == nullptr) { as_set_error("%s: no address for the zero bias", who); return AS_ERR_LAUNCH; }
+    a.ep.bias = zeros;
+  }
   const dim3 grid(as_div_up(a.M, 128)), block(256);
   switch (a.ntaps) {
     case 27: hipLaunchKernelGGL(conv32_fwd_kernel<27>, grid, block, 0, st, a); break;
