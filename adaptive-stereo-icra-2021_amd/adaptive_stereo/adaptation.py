@@ -127,7 +127,8 @@ class OnlineAdapter(object):
   """feature_net + stereo_net + warper + optimiser bound together for the per-step sequence."""
 
   def __init__(self, feature_net, stereo_net, height, width, lr=5e-5, clip_grad_norm=True,
-               smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None, sync_bn=False):
+               smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None, sync_bn=False,
+               overlap_features=True):
     self.feature_net, self.stereo_net = feature_net, stereo_net
     self.scale = stereo_net.input_scale
     self.coarse_scale = stereo_net.input_scale + stereo_net.k
@@ -150,6 +151,7 @@ class OnlineAdapter(object):
     self.infer_plan = hip_ops.StepPlan()   # same for the eval-mode forward (+ all BatchNorm affines in one launch)
     self._infer_graph = None
     self._side = None                      # second stream for the right image's feature extraction
+    self.overlap_features = overlap_features
 
   # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
   @torch.no_grad()
@@ -176,6 +178,8 @@ class OnlineAdapter(object):
     """The two feature extractions of a pair are independent and, at 1/16 resolution, far too small to fill the chip
     (a 24x78 map is 59 workgroups): the right image's runs on a second HIP stream next to the left one's.  Inside a
     captured graph the fork/join become two parallel branches."""
+    if not self.overlap_features:
+      return self.feature_net(left), self.feature_net(right)
     main = torch.cuda.current_stream()
     if self._side is None:
       self._side = torch.cuda.Stream()
@@ -211,7 +215,10 @@ class OnlineAdapter(object):
     return self._step_eager(left, right)
 
   def _forward_maps(self, left, right):
-    fl, fr = self.feature_net(left), self.feature_net(right)
+    if self.bn_sync is None:
+      fl, fr = self._features_two_streams(left, right)      # backward follows: autograd replays each part on its stream
+    else:
+      fl, fr = self.feature_net(left), self.feature_net(right)   # collectives inside: one stream, one order
     out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     pred = out["pred_disp_l/{}".format(self.scale)]
     warped, mask = self.warper(right, pred, right_to_left=True)
@@ -225,6 +232,7 @@ class OnlineAdapter(object):
     self.arena.zero_grads()
     self.plan.begin()
     prev_sync = hip_ops.set_bn_sync(self.bn_sync)
+    hip_ops.rmw_order_reset(True)        # two streams update the same gradient sinks / running statistics: keep order
     try:
       total, mask, fcs_map, out, warped = self._forward_maps(left, right)
 
@@ -235,6 +243,7 @@ class OnlineAdapter(object):
       else:
         loss, fcs = self._distributed_backward(total, mask, fcs_map, left.shape[0])
     finally:
+      hip_ops.rmw_order_reset(False)
       hip_ops.set_bn_sync(prev_sync)
       self.plan.end()
 
@@ -260,9 +269,11 @@ class OnlineAdapter(object):
     if train:
       self.plan.begin()
     prev_sync = hip_ops.set_bn_sync(self.bn_sync if train else None)
+    two_streams = self.bn_sync is None or not train
+    hip_ops.rmw_order_reset(two_streams)
     try:
       with torch.set_grad_enabled(train):
-        fl, fr = self.feature_net(left), self.feature_net(right)
+        fl, fr = self._features_two_streams(left, right) if two_streams else (self.feature_net(left), self.feature_net(right))
         out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
         pred = out["pred_disp_l/{}".format(self.scale)]
         warped, mask = self.warper(right, pred, right_to_left=True)
@@ -272,11 +283,12 @@ class OnlineAdapter(object):
         replay_loss = None
         if replay is not None:
           rl, rr, rgt = replay
-          rfl, rfr = self.feature_net(rl), self.feature_net(rr)
+          rfl, rfr = self._features_two_streams(rl, rr) if two_streams else (self.feature_net(rl), self.feature_net(rr))
           rout = self.stereo_net(rl, rfl, rfr, "l", output_cost_volume=True)
           replay_loss = khamis_robust_loss(rout["pred_disp_l/{}".format(self.scale)], rgt)
           backprop = loss + er_loss_weight * replay_loss
     finally:
+      hip_ops.rmw_order_reset(False)
       hip_ops.set_bn_sync(prev_sync)
       if train:
         self.plan.end(final=False)
@@ -298,9 +310,11 @@ class OnlineAdapter(object):
     """backward + clip + Adam for a result of forward_loss(train=True) (adapt.py:381-394)."""
     self.plan.begin(resume=True)  # backward re-packs the (unchanged) weights: one launch
     prev_sync = hip_ops.set_bn_sync(self.bn_sync)
+    hip_ops.rmw_order_reset(self.bn_sync is None)
     try:
       result["backprop_loss"].backward()
     finally:
+      hip_ops.rmw_order_reset(False)
       hip_ops.set_bn_sync(prev_sync)
       self.plan.end()
     if self.world > 1:
@@ -356,19 +370,23 @@ class OnlineAdapter(object):
         self.arena.rebind_grads()
         self.arena.zero_grads()
         self.plan.begin()
+        hip_ops.rmw_order_reset(True)
         try:
           total, mask, fcs_map, out, warped = self._forward_maps(self._static_left, self._static_right)
           m8 = self._dp_local_sums(total, mask, fcs_map)
         finally:
+          hip_ops.rmw_order_reset(False)
           self.plan.end(final=False)
       torch.cuda.synchronize()
       dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
       torch.cuda.synchronize()
       with torch.cuda.graph(g2, pool=g1.pool(), stream=cap, capture_error_mode="thread_local"):
         self.plan.begin(resume=True)
+        hip_ops.rmw_order_reset(True)      # a new capture: events of the forward graph must not be waited on here
         try:
           self._dp_backward(total, m8)
         finally:
+          hip_ops.rmw_order_reset(False)
           self.plan.end()
       torch.cuda.synchronize()
       allreduce_gradients(self.arena.grads, self.pg)

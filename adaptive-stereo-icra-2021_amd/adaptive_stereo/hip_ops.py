@@ -112,6 +112,43 @@ POOL = PclPool()
 
 
 # ----------------------------------------------------------------------------------------
+# Read-modify-write ordering across HIP streams
+# ----------------------------------------------------------------------------------------
+class _RmwOrder(object):
+  """When independent parts of a step run on different HIP streams (the two feature extractions of a pair), the few
+  buffers both parts UPDATE IN PLACE — gradient sinks in the flat arena, BatchNorm running statistics — must be
+  touched in the order a single stream would: whoever is issued second waits for an event the first recorded after
+  its kernel.  Issue order is Python order, which is deterministic, so results stay bit-identical to the one-stream
+  step.  Inside a graph capture the events become edges between the parallel branches.  Disabled (no events, no
+  cost) unless a caller opens a multi-stream region."""
+  enabled = False
+  last = {}          # data_ptr -> (stream handle, event recorded after the last read-modify-write)
+
+
+def rmw_order_reset(enabled):
+  """Opens (True) or closes (False) a multi-stream region; forgets events of the previous region (an event recorded
+  outside a graph capture must not be waited on inside it)."""
+  _RmwOrder.enabled = bool(enabled)
+  _RmwOrder.last = {}
+
+
+def _rmw_wait(t):
+  if _RmwOrder.enabled and t is not None:
+    last = _RmwOrder.last.get(t.data_ptr())
+    cur = torch.cuda.current_stream()
+    if last is not None and last[0] != cur.cuda_stream:
+      cur.wait_event(last[1])
+
+
+def _rmw_done(t):
+  if _RmwOrder.enabled and t is not None:
+    cur = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _RmwOrder.last[t.data_ptr()] = (cur.cuda_stream, ev)
+
+
+# ----------------------------------------------------------------------------------------
 # Thin call helpers
 # ----------------------------------------------------------------------------------------
 def pack_weights(w, shape: ConvShape, transpose_flip: bool):
@@ -296,7 +333,9 @@ def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, s
   ws = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
   taps = shape.taps()
   if sink_w is not None and (sink_b is not None or not want_bias):
+    _rmw_wait(sink_w)
     call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(sink_w), ptr(sink_b), 1, ptr(ws), stream())
+    _rmw_done(sink_w)
     return None, None
   if shape.kd > 1:
     dW = _empty(32 * 32 * taps, dev).view(32, 32, shape.kd, shape.kh, shape.kw)
@@ -355,9 +394,11 @@ def bn_train_stats(stats: StatParts, gamma, beta, running_mean, running_var):
   st = BnState(gamma.device)
   if _BN_SYNC is not None:
     stats = _gathered_stats(stats, _BN_SYNC)
+  _rmw_wait(running_mean)
   call("as_bn_finalize", ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stats.nparts, ptr(gamma), ptr(beta),
        ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS, ptr(st.mean), ptr(st.invstd),
        ptr(st.scale), ptr(st.shift), stream())
+  _rmw_done(running_mean)
   return st
 
 
@@ -390,6 +431,16 @@ def bn_bwd_coefs(g_a, z, st: BnState, gamma, g: Pcl, train: bool, g_gamma, g_bet
   """Stages 1-2 of the BatchNorm backward (stage 1 may already be in ``sums``): parameter gradients into g_gamma /
   g_beta, stage-3 coefficients left in ``ws`` at as_bn_bwd_coef_offset()."""
   sync = _BN_SYNC if train else None
+  if accumulate:
+    _rmw_wait(g_gamma)
+  try:
+    _bn_bwd_coefs(g_a, z, st, gamma, g, train, g_gamma, g_beta, accumulate, ws, sums, sync)
+  finally:
+    if accumulate:
+      _rmw_done(g_gamma)
+
+
+def _bn_bwd_coefs(g_a, z, st, gamma, g, train, g_gamma, g_beta, accumulate, ws, sums, sync):
   if sync is None:
     if sums is not None:
       call("as_bn_act_bwd_given", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
@@ -422,8 +473,10 @@ def bn_act_bwd(g_a, z, st: BnState, gamma, g: Pcl, train: bool, sink_gamma=None,
   fn = "as_bn_act_bwd_given" if sums is not None else "as_bn_act_bwd"
   tail = (ptr(ws), g, sums.nparts, stream()) if sums is not None else (ptr(ws), g, stream())
   if sink_gamma is not None and sink_beta is not None:
+    _rmw_wait(sink_gamma)
     call(fn, ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
          LEAKY_SLOPE, int(train), ptr(g_z), ptr(sink_gamma), ptr(sink_beta), 1, *tail)
+    _rmw_done(sink_gamma)
     return g_z, None, None
   g_gamma, g_beta = _empty(32, dev), _empty(32, dev)
   call(fn, ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), ptr(gamma),
@@ -499,8 +552,10 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
     coef = ws[lib.as_bn_bwd_coef_offset():]
     g_z = POOL.get(g, dev)
     wws = _empty(lib.as_conv32_wgrad_workspace(g, g, shape), dev)
+    _rmw_wait(sw)
     call("as_conv32_wgrad_bnapply", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(st.scale), ptr(st.shift), ptr(st.mean),
          ptr(coef), LEAKY_SLOPE, ptr(g_z), ptr(sw), ptr(sb), 1, ptr(wws), stream())
+    _rmw_done(sw)
     g_gamma = g_beta = dW = db = None
   else:
     g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta, sums)
@@ -731,8 +786,10 @@ class FeatureExtractorFn(torch.autograd.Function):
       if i == 0:
         ws = _empty(lib.as_conv4_wgrad_workspace(gi, CONV5_S2), dev)
         if _sink(sinks, 0) is not None and _sink(sinks, 1) is not None:
+          _rmw_wait(sinks[0])
           call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_a), gi, CONV5_S2, 3, ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws),
                stream())
+          _rmw_done(sinks[0])
         else:
           dW = torch.empty_like(wd); db = _empty(32, dev)
           call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_a), gi, CONV5_S2, 3, ptr(dW), ptr(db), 0, ptr(ws), stream())

@@ -232,6 +232,36 @@ def test_graph_replay_equals_eager_steps():
   assert nb0 == nb1 == 5 and sc0 == sc1 == 5 and sd0 == sd1 == 5.0
 
 
+def test_two_stream_feature_extraction_equals_one_stream():
+  """The right image's feature extraction (forward and, through autograd, backward) runs on a second HIP stream next
+  to the left one's; the buffers both update in place (gradient sinks, BatchNorm running statistics) are ordered by
+  events (hip_ops._RmwOrder), so eager stepping, graph replay and inference must give the one-stream bits."""
+  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
+  H, W, B = 96, 256, 2
+  batches = [syn.stereo_pair(B, H, W, seed=s) for s in (61, 62, 63)]
+  batches = [(l.to(DEV), r.to(DEV)) for l, r in batches]
+  results = []
+  for overlap, use_graph in ((False, False), (True, False), (True, True)):
+    fnet, snet = build(meta)
+    adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5, overlap_features=overlap)
+    adapter.step(*batches[0])
+    if use_graph:
+      adapter.capture(*batches[0], warmup=1)
+    else:
+      adapter.step(*batches[0])
+    losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
+    out, fcs = adapter.infer(*batches[0])
+    torch.cuda.synchronize()
+    bufs = torch.cat([b.detach().double().reshape(-1) for net in (fnet, snet) for _, b in sorted(net.named_buffers())])
+    results.append((losses, adapter.arena.params.clone(), adapter.arena.grads.clone(), bufs,
+                    out["pred_disp_l/0"].clone(), fcs.clone()))
+  ref = results[0]
+  for got in results[1:]:
+    assert got[0] == ref[0], (got[0], ref[0])
+    for a, b in zip(got[1:], ref[1:]):
+      assert torch.equal(a, b)
+
+
 def test_direct_gradient_accumulation_equals_autograd_accumulation():
   """Backward kernels that add parameter gradients straight into the flat arena (hip_ops.grad_sinks) must leave
   the same bits there as autograd's own AccumulateGrad route (feature_net is used twice per step, so the
