@@ -42,6 +42,8 @@ def parse():
   ap.add_argument("--k", type=int, default=4)
   ap.add_argument("--maxdisp", type=int, default=192)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--one-stream", action="store_true", help="the two feature extractions of a pair back to back on one "
+                  "stream instead of side by side on two (for per-kernel profiles: rocprofv3 serialises queues)")
   ap.add_argument("--sync-bn", action="store_true", help="N>1: train-mode BatchNorm over the batches of all ranks (the "
                   "reference's whole-batch semantics; 34 small collectives per step, eager launches) instead of "
                   "per-replica statistics")
@@ -163,7 +165,8 @@ def main():
   B = args.batch
   left, right = syn.stereo_pair(B, args.height, args.width, seed=1 + rank)
   left, right = left.to(dev), right.to(dev)
-  adapter = OnlineAdapter(fnet, snet, args.height, args.width, lr=5e-5, clip_grad_norm=True, sync_bn=args.sync_bn)
+  adapter = OnlineAdapter(fnet, snet, args.height, args.width, lr=5e-5, clip_grad_norm=True, sync_bn=args.sync_bn,
+                          overlap_features=not args.one_stream)
 
   lib = nat.load()
   use_graph = not args.no_graph and adapter.bn_sync is None     # collectives inside forward/backward: not capturable

@@ -9,6 +9,8 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 trace=$(find gpurun_out/prof_$tag -name "e_kernel_trace.csv" | head -1)
 python tests/tools/steady_state.py $trace 10 "$tag steady state ($extra)" > gpurun_out/ss_$tag.txt
 python tests/tools/step_timeline.py $trace fastest > gpurun_out/timeline_$tag.txt
+python tests/tools/forward_window.py $trace 10 > gpurun_out/fw_$tag.txt
+python tests/tools/star_kernels.py $trace 10 > gpurun_out/star_$tag.txt
 cp $(find gpurun_out/prof_$tag -name "e_kernel_stats.csv" | head -1) gpurun_out/ks_$tag.csv
 rm -rf gpurun_out/prof_$tag
 tail -1 gpurun_out/be.log | cut -c1-120

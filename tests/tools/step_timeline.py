@@ -19,6 +19,6 @@ print("step wall %.1f us, %d kernels, busy %.1f us" % (
 prev_end = t0
 for r in win:
   s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-  print("%9.1f us  +%6.1f gap  %8.1f us  grid %-8s %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3,
-        r.get('Grid_Size_X', r.get('Grid_Size', '?')), r['Kernel_Name'][:90]))
-  prev_end = e
+  print("%9.1f us  +%6.1f gap  %8.1f us  q%-2s grid %-8s %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3,
+        r.get('Queue_Id', '?'), r.get('Grid_Size_X', r.get('Grid_Size', '?')), r['Kernel_Name'][:90]))
+  prev_end = max(prev_end, e)
