@@ -731,7 +731,7 @@ __global__ __launch_bounds__(512, 1) void conv32_wgrad_lds2_kernel(WgradLdsArgs 
   }
 }
 
-static bool wgrad_lds2(const as_pcl* gout) { return lds_ntiles(gout) >= 256 * 16; }   // the launch fills the chip
+static bool wgrad_lds2(const as_pcl* gout) { return lds_ntiles(gout) >= 256 * 12; }   // the launch fills the chip
 
 int conv32_wgrad_lds_slabs(const as_pcl* gout) {
   if (wgrad_lds2(gout)) return 256;                      // one double-buffered 8-wave workgroup per CU
