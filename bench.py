@@ -273,7 +273,10 @@ def main():
       return {"kernel": name, "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
               "frac": round(by / (ms * 1e-3) / 8e12, 4), "launches": n, "avg_launch_us": round(1e3 * ms / n, 2)}
     roofline["hbm_bound_kernels"] = [e for e in (hbm_entry(4, "bn_act_fwd_kernel"),
-                                                 hbm_entry(5, "bn_bwd_reduce + finalize + apply")) if e is not None]
+                                                 hbm_entry(5, "bn_bwd_reduce + finalize + apply (what is left of "
+                                                               "them: the 1/16-resolution and cost-volume layers, "
+                                                               "launch-latency bound; the full-resolution passes ride "
+                                                               "on the matrix-core kernels)")) if e is not None]
 
   out = {
     "metric": "stereo pairs/sec (fwd+adapt-step), KITTI 1242x375 D=192",
