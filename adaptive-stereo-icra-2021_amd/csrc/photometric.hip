@@ -44,16 +44,31 @@ struct SsimTerms { float mux, muy, A1, A2, B1, B2, n, d, raw; };
 
 __device__ inline SsimTerms ssim_at(const float* __restrict__ X, const float* __restrict__ Y, int y, int x, int H, int W) {
   float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+  if (y > 0 && y < H - 1 && x > 0 && x < W - 1) {
+    // interior (all but the one-pixel frame): three row bases, taps at constant offsets, no predicates; same order
+    const float* xr = X + (long)(y - 1) * W + (x - 1);
+    const float* yr = Y + (long)(y - 1) * W + (x - 1);
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= H) continue;
+    for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int xx = x + dx;
-      if (xx < 0 || xx >= W) continue;
-      const float a = X[(long)yy * W + xx], b = Y[(long)yy * W + xx];
-      sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+      for (int dx = 0; dx < 3; ++dx) {
+        const float a = xr[dx], b = yr[dx];
+        sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+      }
+      xr += W; yr += W;
+    }
+  } else {
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= W) continue;
+        const float a = X[(long)yy * W + xx], b = Y[(long)yy * W + xx];
+        sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+      }
     }
   }
   const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -94,10 +109,11 @@ __global__ __launch_bounds__(256) void monodepth_fwd_kernel(const float* __restr
                                                              int B, int H, int W, float sw,
                                                              float* __restrict__ total, float* __restrict__ l1,
                                                              float* __restrict__ ssim, float* __restrict__ smooth) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long plane = (long)H * W;
-  if (i >= (long)B * plane) return;
-  const int x = i % W, y = (i / W) % H, b = i / plane;
+  const int op = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;      // 32-bit index arithmetic: one image per grid row
+  if (op >= H * W) return;
+  const int y = op / W, x = op - y * W;
+  const long i = (long)b * plane + op;
   const float* I = img + (long)b * 3 * plane;
   const float* Wp = warped + (long)b * 3 * plane;
   float s_acc = 0.f, l_acc = 0.f;
@@ -136,8 +152,8 @@ __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
   const float* P = pred + (long)b * plane;
   const float den = mean_disp[b] + 1e-7f;
   double s_local = 0.0;
-  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < plane; o += (long)gridDim.x * 256) {
-    const int x = o % W, y = o / W;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < H * W; o += gridDim.x * 256) {
+    const int y = o / W, x = o - y * W;
     const long gi = (long)b * plane + o;
     const float gt = g_total ? g_total[gi] : 0.f;
     const float G_ssim = 0.85f * gt + (g_ssim ? g_ssim[gi] : 0.f);
@@ -188,11 +204,12 @@ __global__ __launch_bounds__(256) void monodepth_bwd_b_kernel(
     const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ warped,
     const float* __restrict__ mean_disp, const float* __restrict__ coef, const float* __restrict__ sum_gnd_pred,
     int B, int H, int W, float* __restrict__ g_pred, float* __restrict__ g_warped) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const long plane = (long)H * W;
-  if (i >= (long)B * plane) return;
-  const int x = i % W, y = (i / W) % H, b = i / plane;
-  const long o = (long)y * W + x;
+  const int op = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (op >= H * W) return;
+  const int y = op / W, x = op - y * W;
+  const long o = op;
+  const long i = (long)b * plane + op;
   const float* I = img + (long)b * 3 * plane;
   const float* Wp = warped + (long)b * 3 * plane;
   const float* cf = coef + (long)b * 10 * plane;
@@ -203,18 +220,30 @@ __global__ __launch_bounds__(256) void monodepth_bwd_b_kernel(
     for (int c = 0; c < 3; ++c) {
       const float xv = I[c * plane + o], yv = Wp[c * plane + o];
       float sa = 0.f, sb = 0.f, sc = 0.f;
+      if (y > 0 && y < H - 1 && x > 0 && x < W - 1) {
+        const float* ca = cf + (3 * c + 0) * plane + o - W - 1;
+        const float* cb = cf + (3 * c + 1) * plane + o - W - 1;
+        const float* cc = cf + (3 * c + 2) * plane + o - W - 1;
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
+        for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int xx = x + dx;
-          if (xx < 0 || xx >= W) continue;
-          const long q = (long)yy * W + xx;
-          sa += cf[(3 * c + 0) * plane + q];
-          sb += cf[(3 * c + 1) * plane + q];
-          sc += cf[(3 * c + 2) * plane + q];
+          for (int dx = 0; dx < 3; ++dx) { sa += ca[dx]; sb += cb[dx]; sc += cc[dx]; }
+          ca += W; cb += W; cc += W;
+        }
+      } else {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int yy = y + dy;
+          if (yy < 0 || yy >= H) continue;
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const long q = (long)yy * W + xx;
+            sa += cf[(3 * c + 0) * plane + q];
+            sb += cf[(3 * c + 1) * plane + q];
+            sc += cf[(3 * c + 2) * plane + q];
+          }
         }
       }
       float g = (sa + 2.f * sb * yv + sc * xv) / 9.f;
@@ -282,14 +311,14 @@ static int image_mean(const float* pred, int B, long plane, PhWs& w, hipStream_t
 extern "C" int as_monodepth_loss_fwd(const float* pred, const float* img, const float* warped, int B, int H, int W,
                                      float smoothness_weight, float* total, float* l1, float* ssim, float* smooth,
                                      float* workspace, void* stream) {
-  AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535,
+  AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535 && (long)H * W < (1L << 31),
                "as_monodepth_loss_fwd: bad argument");
   AS_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "as_monodepth_loss_fwd: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   PhWs w = carve(workspace, B);
   const long plane = (long)H * W;
   if (int e = image_mean(pred, B, plane, w, st)) return e;
-  hipLaunchKernelGGL(monodepth_fwd_kernel, dim3(as_div_up((long)B * plane, 256)), dim3(256), 0, st, pred, img, warped,
+  hipLaunchKernelGGL(monodepth_fwd_kernel, dim3(as_div_up(plane, 256), B), dim3(256), 0, st, pred, img, warped,
                      w.mean, B, H, W, smoothness_weight, total, l1, ssim, smooth);
   AS_CHECK_LAUNCH("as_monodepth_loss_fwd");
   return AS_OK;
@@ -299,7 +328,7 @@ extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, co
                                      const float* pred, const float* img, const float* warped, int B, int H, int W,
                                      float smoothness_weight, float* g_pred, float* g_warped,
                                      float* workspace, void* stream) {
-  AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535,
+  AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535 && (long)H * W < (1L << 31),
                "as_monodepth_loss_bwd: bad argument");
   AS_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "as_monodepth_loss_bwd: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -312,7 +341,7 @@ extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, co
   hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(B), dim3(64), 0, st, w.partial,
                      PH_BLOCKS_PER_IMAGE, B, 1.0, w.sum);
   AS_CHECK_LAUNCH("as_monodepth_loss_bwd(sum)");
-  hipLaunchKernelGGL(monodepth_bwd_b_kernel, dim3(as_div_up((long)B * plane, 256)), dim3(256), 0, st, g_total, g_l1,
+  hipLaunchKernelGGL(monodepth_bwd_b_kernel, dim3(as_div_up(plane, 256), B), dim3(256), 0, st, g_total, g_l1,
                      pred, img, warped, w.mean, w.coef, w.sum, B, H, W, g_pred, g_warped);
   AS_CHECK_LAUNCH("as_monodepth_loss_bwd(B)");
   return AS_OK;
