@@ -163,6 +163,43 @@ def test_gpu_matches_oracle_on_fresh_inputs():
   assert epe <= EPE_BAR, "EPE %.3e" % epe
 
 
+@pytest.mark.parametrize("side,with_volume", [("l", True), ("x", False)])
+def test_input_scale_one_and_output_dictionary(side, with_volume):
+  """The reference's "L1" configurations (experiments/training/*_L1_8X.sh: stereonet_input_scale 1, k 3) feed
+  half-resolution images: Dc = (maxdisp+1) // 2^(s+k) and every output key carries the scale
+  (stereo_net.py:170,198-205); side "x" and output_cost_volume=False only change the dictionary.  Forward against the
+  oracle in eval mode, one adaptation step in train mode."""
+  B, H, W, k, s, maxdisp = 2, 96, 288, 3, 1, 192
+  meta = dict(k=k, s=s, maxdisp=maxdisp, gain=50.0)
+  fnet, snet = build(meta)
+  left, right = syn.stereo_pair(B, H, W, seed=17, disparities=(2.0, 6.0))
+  fsd = {n: t.detach().cpu().clone() for n, t in fnet.state_dict().items()}
+  ssd = {n: t.detach().cpu().clone() for n, t in snet.state_dict().items()}
+  with torch.no_grad():
+    fl, fr = orc.feature_extractor(orc.make_params(fsd, False), left, k, False), None
+    fr = orc.feature_extractor(orc.make_params(fsd, False), right, k, False)
+    ref = orc.stereo_forward(orc.make_params(ssd, False), left, fl, fr, k, s, maxdisp, side, False, with_volume)
+  fnet.eval(); snet.eval()
+  with torch.no_grad():
+    ld, rd = left.to(DEV), right.to(DEV)
+    out = snet(ld, fnet(ld), fnet(rd), side, output_cost_volume=with_volume)
+  assert set(out.keys()) == set(ref.keys())
+  assert ("cost_volume_%s/%d" % (side, s + k) in out) == with_volume
+  for key in ("pred_disp_%s/%d" % (side, s + k), "pred_disp_%s/%d" % (side, s)):
+    assert out[key].shape == ref[key].shape
+    assert float((out[key].cpu() - ref[key]).abs().mean()) <= EPE_BAR, key
+  if with_volume:
+    key = "cost_volume_%s/%d" % (side, s + k)
+    assert out[key].shape == (B, (maxdisp + 1) // 2 ** (s + k), H // 2 ** k, W // 2 ** k)
+    assert float((out[key].cpu() - ref[key]).abs().max()) <= 3e-5 * 50.0 + 1e-4 * float(ref[key].abs().max())
+  if side == "l":
+    fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
+    ref_step = orc.adapt_step(fp, sp, {}, left, right, k, s, maxdisp)
+    got = OnlineAdapter(fnet, snet, H, W, lr=5e-5).step(ld, rd)
+    assert abs(float(got["loss"]) - float(ref_step["loss"])) < 2e-5
+    assert "pred_disp_l/%d" % s in got["outputs"] and "left_warped/%d" % s in got["outputs"]
+
+
 # ---- size-independent properties at the full benchmark size ------------------------------------
 def test_full_size_properties_kitti():
   B, H, W, k = 2, 375, 1242, 4
