@@ -27,6 +27,7 @@
 #include "as_common.h"
 #include "conv_epilogue.h"
 #include "conv32_lds.h"
+#include "conv3d_lds.h"
 
 static bool wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 
@@ -517,6 +518,7 @@ extern "C" int as_conv32_num_blocks(const as_pcl* gout) {
 extern "C" int as_conv32_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
   if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
   if (conv32_lds_applicable(gin, gout, s)) return conv32_lds_grid(gout);
+  if (conv3d_lds_applicable(gin, gout, s)) return conv3d_lds_grid(gout);
   return as_conv32_num_blocks(gout);
 }
 
@@ -530,6 +532,9 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
   if (conv32_lds_applicable(gin, gout, s))
     return conv32_lds_launch(x, gin, packed_w, bias, z, gout, s, epilogue, ep_scale, ep_shift, slope, residual,
                              stat_mean, stat_m2, stat_cnt, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+  if (conv3d_lds_applicable(gin, gout, s))
+    return conv3d_lds_launch(x, gin, packed_w, bias, z, gout, epilogue, ep_scale, ep_shift, slope, residual,
+                             stat_mean, stat_m2, stat_cnt, stream);
   ConvArgs a;
   a.x = x; a.wp = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = residual;

@@ -73,6 +73,12 @@ CONV_CASES = [
   (1, 8, 5, 9, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
   (2, 12, 6, 19, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
   (1, 3, 24, 78, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
+  # LDS-staged 3-D instance (conv3d_lds.hip): 128-position tiles over the flattened padded plane; a ragged plane whose
+  # last tile is shifted back; the k=4 and k=3 cost-volume geometries; first / last plane of the buffer (D = 1)
+  (1, 5, 9, 40, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
+  (2, 12, 24, 78, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
+  (1, 4, 47, 156, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
+  (2, 1, 4, 33, ConvShape(3, 3, 3, 1, 1, 1, 1, 1), (1, 1, 1)),
   (2, 1, 17, 37, ConvShape(1, 3, 3, 0, 1, 1, 1, 1), (0, 1, 1)),
   (1, 1, 21, 45, ConvShape(1, 3, 3, 0, 2, 2, 2, 1), (0, 8, 8)),
   (1, 1, 33, 40, ConvShape(1, 3, 3, 0, 8, 8, 8, 1), (0, 8, 8)),
