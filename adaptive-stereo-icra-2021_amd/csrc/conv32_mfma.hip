@@ -579,6 +579,7 @@ extern "C" int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* go
   int tg, rpc, nchunks;
   const int T = wgrad_plan(gout, s, &tg, &rpc, &nchunks);
   if (wgrad_lds_applicable(gin, gout, s)) nchunks = conv32_wgrad_lds_slabs(gout);
+  if (conv3d_wgrad_lds_applicable(gin, gout, s)) nchunks = conv3d_wgrad_lds_slabs(gout);
   return (int64_t)nchunks * T * 1024 + (int64_t)nchunks * 32;
 }
 
@@ -603,6 +604,18 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
     as_prof_mark(3, st, 1, 0.0);
     if (int e = conv32_wgrad_lds_launch(x, gin, gz, gout, s, workspace, partial_db, nullptr, stream)) return e;
     as_prof_mark(3, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
+                       workspace, partial_db, slabs, T, dW, db, accumulate);
+    AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
+    return AS_OK;
+  }
+  if (conv3d_wgrad_lds_applicable(gin, gout, s)) {
+    const int slabs = conv3d_wgrad_lds_slabs(gout);
+    float* partial_db = workspace + (int64_t)slabs * T * 1024;
+    hipStream_t st = (hipStream_t)stream;
+    as_prof_mark(1, st, 1, 0.0);
+    if (int e = conv3d_wgrad_lds_launch(x, gin, gz, gout, workspace, partial_db, stream)) return e;
+    as_prof_mark(1, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
                        workspace, partial_db, slabs, T, dW, db, accumulate);
     AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");

@@ -193,3 +193,163 @@ int conv3d_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
   AS_CHECK_LAUNCH("as_conv32_fwd(3-D LDS)");
   return AS_OK;
 }
+
+
+// =====================================================================================================
+// Weight gradient of the same instance:  dW[tap][ci][co] = sum_p X[p + off(tap)][ci] * G[p][co]  over all positions.
+// Same flattening: for one kd the nine (kh, kw) taps of a 128-position tile read ONE staged run of plane d+kd-1
+// (plain copy, as in conv32_wgrad_lds_kernel: a ds_read_b32 of one voxel's 32 channels by 32 lanes is conflict-free)
+// against the tile's G run.  G's halo is zero, so halo-column positions and whatever a clamped DMA group fetches
+// beyond a plane's last voxel contribute nothing: no masks, no ragged-edge code.
+// Workgroups come in triples (chunk c = blockIdx/3, kd = blockIdx%3): the three of a chunk walk the same tiles, each
+// for its own kd with nine accumulators (144 registers) that live across all of its tiles, and write the taps
+// 9*kd .. 9*kd+8 of slab c: the slabs have the [chunk][27][32][32] layout wgrad_reduce_kernel sums in fixed order.
+// The direct-load kernel needed one 256-byte wave load per operand per MFMA (57-65 TFLOP/s).
+struct Wgrad3dLdsArgs {
+  const float* x;
+  const float* gz;
+  float* partial;      // [chunks][27][32][32]
+  float* partial_db;   // [chunks][32]
+  PclDev g;
+  int tiles_per_plane, npos, ntiles, nchunks;
+  int run, xgroups;    // staged X voxels (130 + 2*Wp, rounded up to 8) and its 8-voxel DMA groups
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_lds_kernel(Wgrad3dLdsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xbuf = smem;
+  char* gbuf = smem + p.xgroups * 1024;
+  const unsigned lds_x = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds3_ptr_t)xbuf));
+  const unsigned lds_g = lds_x + (unsigned)(p.xgroups * 1024);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int Wp = p.g.Wp;
+  const int chunk = blockIdx.x / 3, kd = blockIdx.x - 3 * chunk;
+  const long plane_vox = (long)Wp * p.g.Hp;
+  const int first = p.g.ph * Wp + p.g.pw;
+  const int last_group = (int)plane_vox - 8;                       // last 8-voxel group that lies inside a plane
+  const int zero_group = (p.g.Hp - 1) * Wp;                        // 8 voxels of the bottom pad row: zeros
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  // operand addresses of step 0 (tile-invariant): position 32*wave + h, tap (kh, kw) at run voxel + kh*Wp + kw
+  const char* gaddr = gbuf + (32 * wave + h) * 128 + li * 4;
+  const char* xaddr[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) xaddr[t] = xbuf + (32 * wave + h + (t / 3) * Wp + (t % 3)) * 128 + li * 4;
+
+  for (int tile = chunk; tile < p.ntiles; tile += p.nchunks) {
+    const int plane = tile / p.tiles_per_plane, tt = tile - plane * p.tiles_per_plane;
+    const int b = plane / p.g.D, d = plane - b * p.g.D;
+    const int pos0 = first + 128 * tt;
+    const float* xplane = p.x + ((long)b * p.g.Dp + d + p.g.pd + kd - 1) * plane_vox * 32;
+    const float* gplane = p.gz + ((long)b * p.g.Dp + d + p.g.pd) * plane_vox * 32;
+    const int xs = pos0 - Wp - 1;
+    for (int i = wave; i < p.xgroups; i += 4)                       // clamped groups only ever multiply zero G
+      dma3_1kb(xplane + (long)min(xs + 8 * i, last_group) * 32, lane16, lds_x + (unsigned)(i * 1024));
+    const int g_end = first + p.npos;                               // first position past the last interior voxel
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = wave + 4 * k;
+      const int gp = pos0 + 8 * i;
+      dma3_1kb(gplane + (long)(gp < g_end ? gp : zero_group) * 32, lane16, lds_g + (unsigned)(i * 1024));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float bv[2], av[2][9];
+    bv[0] = *reinterpret_cast<const float*>(gaddr);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) av[0][t] = *reinterpret_cast<const float*>(xaddr[t]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 1 < 16) {
+        bv[(s + 1) & 1] = *reinterpret_cast<const float*>(gaddr + (s + 1) * 256);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) av[(s + 1) & 1][t] = *reinterpret_cast<const float*>(xaddr[t] + (s + 1) * 256);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bsum += bv[s & 1];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][t], bv[s & 1], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();          // all waves are done with the tile before the next DMA overwrites it
+  }
+
+  // reduce the four waves' accumulators through LDS, three taps per round (fixed order w0+w1+w2+w3)
+  float* slab = reinterpret_cast<float*>(smem);           // [3 waves][3 taps][16][64] floats = 36,864 B
+  float* out = p.partial + ((long)chunk * 27 + 9 * kd) * 1024;
+#pragma unroll
+  for (int round = 0; round < 3; ++round) {
+    if (wave > 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(((wave - 1) * 3 + g) * 16 + r) * 64 + lane] = acc[round * 3 + g][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[round * 3 + g][r];
+          v += slab[((0 * 3 + g) * 16 + r) * 64 + lane];
+          v += slab[((1 * 3 + g) * 16 + r) * 64 + lane];
+          v += slab[((2 * 3 + g) * 16 + r) * 64 + lane];
+          const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+          out[(round * 3 + g) * 1024 + ci * 32 + li] = v;
+        }
+    }
+    __syncthreads();
+  }
+  if (kd == 1) {                                            // the bias gradient once per chunk
+    float* dbs = reinterpret_cast<float*>(smem);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0) dbs[wave * 32 + li] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 32) p.partial_db[chunk * 32 + li] = dbs[li] + dbs[32 + li] + dbs[64 + li] + dbs[96 + li];
+  }
+}
+
+bool conv3d_wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!conv3d_lds_applicable(gin, gout, s)) return false;
+  const int Wp = gin->W + 2 * gin->pw;
+  return Wp >= 8 && (long)(conv3d_run(gin) + 7) / 8 * 1024 + 16384 <= 80 * 1024;     // two workgroups per CU
+}
+
+int conv3d_wgrad_lds_slabs(const as_pcl* gout) {
+  const int ntiles = conv3d_lds_grid(gout);
+  return ntiles < 170 ? ntiles : 170;                      // 510 workgroups: two per CU
+}
+
+int conv3d_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
+                            float* partial, float* partial_db, void* stream) {
+  Wgrad3dLdsArgs a;
+  a.x = x; a.gz = gz; a.partial = partial; a.partial_db = partial_db;
+  a.g = as_make_dev(gin);
+  a.tiles_per_plane = conv3d_tiles_per_plane(gin);
+  a.npos = (gin->H - 1) * a.g.Wp + gin->W;
+  a.ntiles = conv3d_lds_grid(gout);
+  a.nchunks = conv3d_wgrad_lds_slabs(gout);
+  a.run = conv3d_run(gin);
+  a.xgroups = (a.run + 7) / 8;
+  const int lds_bytes = a.xgroups * 1024 + 16384;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (e != hipSuccess) { as_set_error("as_conv32_wgrad(3-D LDS): %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3d_wgrad_lds_kernel, dim3(3 * a.nchunks), dim3(256), lds_bytes, (hipStream_t)stream, a);
+  AS_CHECK_LAUNCH("as_conv32_wgrad(3-D LDS)");
+  return AS_OK;
+}
