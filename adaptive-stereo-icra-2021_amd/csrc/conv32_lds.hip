@@ -138,12 +138,6 @@ __device__ inline void glb_load_w(f32x4 (&r)[4], const float* p) {
 //   MODE 3: MODE 2 + stage 1 of the following BatchNorm backward: the output IS that layer's g_a, so the sums
 //           sum g_y and sum g_y*(z-mean), g_y = g_a * lrelu'(z*scale+shift), are taken from the register tile
 //           (saves bn_bwd_reduce_kernel's pass over g_a and z: 477 MB per full-resolution layer at 4 pairs)
-// Kernel flavours (compile time, so that no path carries another one's waits):
-//   MODE 0: raw output + BatchNorm moments (training forward)   MODE 1: lrelu(acc*scale+shift) (eval forward)
-//   MODE 2: raw output, no moments (data gradients)             RES: + residual in the output geometry
-//   MODE 3: MODE 2 + stage 1 of the following BatchNorm backward: the output IS that layer's g_a, so the sums
-//           sum g_y and sum g_y*(z-mean), g_y = g_a * lrelu'(z*scale+shift), are taken from the register tile
-//           (saves bn_bwd_reduce_kernel's pass over g_a and z: 477 MB per full-resolution layer at 4 pairs)
 template <int MODE, bool RES>
 __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

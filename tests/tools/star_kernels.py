@@ -14,7 +14,9 @@ I1 = B * H * W * 4; A = B * 32 * H * W * 4
 # kernel substring -> (row, algorithmic bytes per launch, flops per launch); None = not applicable
 table = [
   ("cost_volume_fwd", "a2 fwd", 2 * F + V, None), ("cost_volume_bwd", "a2 bwd", V + 2 * F, None),
-  ("conv32_fwd_kernel<27>", "a3 conv3d fwd/dgrad", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("conv32_fwd_kernel<27>", "a3 conv3d fwd/dgrad (direct-load)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("conv3d_lds_kernel", "a3 conv3d fwd/dgrad (LDS)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("conv3d_wgrad_lds_kernel", "a3 conv3d wgrad (LDS)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
   ("conv32to1_fwd_kernel", "a4 conv3d_alone fwd", V + Lg, None),
   ("conv32to1_dgrad_kernel", "a4 dgrad", Lg + V, None), ("conv32to1_wgrad_kernel<27>", "a4 wgrad", V + Lg, None),
   ("softargmax_fwd", "a5+a8 softargmax+FCS fwd", Lg + 3 * P, None), ("softargmax_bwd", "a5 bwd", 2 * Lg + P, None),
