@@ -22,7 +22,8 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv32_lds_kernel<3, true>": 4 * vox * 128,            # + the next layer's pre-activation (fused BN-backward sums)
        "conv32_wgrad_lds_kernel": 2 * vox * 128, "conv32_wgrad_lds2_kernel<false>": 2 * vox * 128,
        "conv32_wgrad_lds2_kernel<true>": 4 * vox * 128,        # x, g_a, z read; g_z written (fused BN-backward apply)
-       "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128}
+       "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128,
+       "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128}
 out = {"shape": "2-D 3x3 stride 1, 32->32, 4 pairs x 375x1242 (one full-resolution refinement layer)",
        "pairs_per_launch": B, "algorithmic_flops_per_launch": flops,
        "command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 tests/tools/pmc_conv.py   (separate passes: SQ_* ; FETCH_SIZE ; WRITE_SIZE GRBM_GUI_ACTIVE)",
