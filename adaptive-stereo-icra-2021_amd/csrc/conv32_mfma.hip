@@ -147,6 +147,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 //   MFMA.  A workgroup owns (tap group, chunk of image rows); its 4 waves take rows
 //   round-robin, reduce through LDS and write one partial slab; a second kernel sums
 //   the slabs in a fixed order (deterministic — no float atomics).
+#define WG_SEG_STEPS 32            // multiple of the 8-step load groups
 template <int TG>
 struct WgradAcc { f32x16 a[TG]; };
 
@@ -156,8 +157,9 @@ struct WgradArgs {
   float* partial;     // [nchunks][ntaps][32][32]
   float* partial_db;  // [nchunks][32]
   PclDev gin, gout;
-  int rows;           // B*D*H
-  int rows_per_chunk;
+  int rows;           // work units: B*D*H rows x nseg segments
+  int nseg;           // segments of WG_SEG_STEPS voxel pairs per row
+  int rows_per_chunk; // units per workgroup
   int nchunks;
   int ntaps;
   int stride;
@@ -203,14 +205,18 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
   constexpr int WG_U = 8;
   const int nsteps = (W + 1) >> 1;
   const int xs = 32 * p.stride;
-  for (int row = r0 + wave; row < r1; row += 4) {
+  for (int unit = r0 + wave; unit < r1; unit += 4) {
+    // a wave's unit of work: one segment (WG_SEG_STEPS voxel pairs) of one row — whole rows left most of the chip
+    // idle on small batches (94 rows of 156 steps for the first stride-2 layer of one image)
+    const int row = unit / p.nseg, seg = unit - row * p.nseg;
     int t = row;
     const int y = t % H; t /= H;
     const int d = t % D;
     const int b = t / D;
     const float* xr = p.x + p.gin.vox(b, d, y * p.stride, 0) * 32 + li;
     const float* gr = p.gz + p.gout.vox(b, d, y, 0) * 32 + li;
-    for (int s0 = 0; s0 < nsteps; s0 += WG_U) {
+    const int s_end = min(nsteps, (seg + 1) * WG_SEG_STEPS);
+    for (int s0 = seg * WG_SEG_STEPS; s0 < s_end; s0 += WG_U) {
       float bv[WG_U], av[WG_U][TG];
 #pragma unroll
       for (int u = 0; u < WG_U; ++u) {
@@ -554,11 +560,12 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
   return AS_OK;
 }
 
+static int wgrad_segments(const as_pcl* gout) { return (((gout->W + 1) >> 1) + WG_SEG_STEPS - 1) / WG_SEG_STEPS; }
 static int wgrad_plan(const as_pcl* gout, const as_conv_shape* s, int* tg, int* rows_per_chunk, int* nchunks) {
   const int T = s->kd * s->kh * s->kw;
   *tg = (T % 3 == 0) ? 3 : (T % 5 == 0 ? 5 : 1);
-  const int rows = gout->B * gout->D * gout->H;
-  // aim at ~4 waves per SIMD over the chip (256 CUs x 4 SIMDs), at least 4 rows (one per
+  const int rows = gout->B * gout->D * gout->H * wgrad_segments(gout);       // work units (row segments)
+  // aim at ~4 waves per SIMD over the chip (256 CUs x 4 SIMDs), at least 4 units (one per
   // wave) per chunk, and cap the slab count so the partial buffer stays a few MB.
   const int groups = T / *tg;
   int want_chunks = (4096 + groups * 4 - 1) / (groups * 4);
@@ -624,7 +631,8 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
   WgradArgs a;
   a.x = x; a.gz = gz; a.partial = workspace; a.partial_db = workspace + (int64_t)nchunks * T * 1024;
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
-  a.rows = gout->B * gout->D * gout->H; a.rows_per_chunk = rpc; a.nchunks = nchunks; a.ntaps = T; a.stride = s->stride;
+  a.nseg = wgrad_segments(gout);
+  a.rows = gout->B * gout->D * gout->H * a.nseg; a.rows_per_chunk = rpc; a.nchunks = nchunks; a.ntaps = T; a.stride = s->stride;
   if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_wgrad")) return e;
   hipStream_t st = (hipStream_t)stream;
   as_prof_mark(1, st, 1, 0.0);
