@@ -113,6 +113,9 @@ _SIGNATURES = {
   "as_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_float, c_float, c_float, c_float, c_int, c_vp,
                            c_vp]),
+  "as_decode_rgb8": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+  "as_decode_plane": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_vp,
+                              c_vp]),
   "as_prof_enable": (c_int, [c_int]),
   "as_prof_reset": (c_int, []),
   "as_prof_read": (c_int, [c_int, _P(c_i64), _P(ctypes.c_double), _P(ctypes.c_double)]),

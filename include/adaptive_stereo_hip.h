@@ -311,6 +311,21 @@ int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
                  int step, const float* step_dev, void* stream);
 
+/* ---- dataset layer on the device ----------------------------------------------------
+ * What datasets/stereo_dataset.py:49-96 and utils/dataset_utils.py:26-57 do per sample on the host (ToTensor,
+ * flip_stereo_pair, crop, disparity decoding), over the raw decoded file contents uploaded once:
+ * as_decode_rgb8: src = uint8 [H0][W0][3] (PIL RGB) -> dst = float [3][H][W] = src/255 of the window (i0, j0, H, W);
+ *   hflip = 1: the image was mirrored BEFORE cropping (the caller also swaps left and right, dataset_utils.py:19-23).
+ * as_decode_plane: one-channel sample -> float [H][W]; dtype 0 = f32, 1 = u16, 2 = u8; vflip = 1 for bottom-up
+ *   files (PFM, utils/io.py:73); value = v*scale (KITTI png 1/256, KITTI-raw npy 1/128, PFM 1) or scale/v
+ *   (reciprocal = 1: Virtual KITTI depth in cm -> disparity, scale = baseline*focal/0.01).
+ * The multi-scale pyramid (stereo_dataset.py:98-135) is as_upsample_bilinear_fwd (a general align_corners=False
+ * resize) with gain 1 for colour and 1/2^s for disparity. */
+int as_decode_rgb8(const uint8_t* src, int H0, int W0, int i0, int j0, int H, int W, int hflip, float* dst,
+                   void* stream);
+int as_decode_plane(const void* src, int dtype, int H0, int W0, int i0, int j0, int H, int W, int hflip,
+                    int vflip, float scale, int reciprocal, float* dst, void* stream);
+
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------
  * When enabled, as_conv32_fwd and as_conv32_wgrad bracket their main kernel with HIP events on the
  * launch stream and account its algorithmic FLOPs (2 * voxels * 32 * 32 * taps).  Kernel ids:

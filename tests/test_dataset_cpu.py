@@ -1,0 +1,83 @@
+"""Dataset layer, host path against the oracle's restatement of the reference
+(datasets/stereo_dataset.py:49-143, utils/dataset_utils.py:19-57, utils/io.py:37-80)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, PKG  # noqa: F401  (puts the package on sys.path)
+from adaptive_stereo.datasets.stereo_dataset import StereoDataset
+from adaptive_stereo.utils import io as as_io
+from adaptive_stereo.utils.dataset_utils import flip_stereo_pair, read_lines
+from oracle import dataset_oracle as dorc
+from dataset_fixture import make_tree, write_pfm_bytes
+
+DATASETS = ["SceneFlowFlying", "KittiStereo2015", "KittiRaw", "VirtualKitti"]
+
+
+@pytest.mark.parametrize("little", [True, False])
+def test_pfm_reader_both_byte_orders_and_round_trip(tmp_path, little):
+  img = (np.random.RandomState(1).rand(9, 13) * 100).astype(np.float32)
+  p = str(tmp_path / "a.pfm")
+  write_pfm_bytes(p, img, little=little)
+  got, scale = as_io.read_pfm(p)
+  assert scale == 1.0 and np.array_equal(got, img)                  # top row first, as the reference returns it
+  raw, _ = as_io.read_pfm_raw(p)
+  assert np.array_equal(raw, np.flipud(img))                         # as stored: bottom row first
+  assert torch.equal(as_io.read_pfm_tensor(p), torch.from_numpy(img))
+  assert np.array_equal(dorc.pfm(p), img)
+  q = str(tmp_path / "b.pfm")
+  as_io.write_pfm(q, img)
+  assert np.array_equal(as_io.read_pfm(q)[0], img)
+  with open(str(tmp_path / "bad.pfm"), "wb") as f:
+    f.write(b"P6\n1 1\n255\n")
+  with pytest.raises(ValueError):
+    as_io.read_pfm(str(tmp_path / "bad.pfm"))
+
+
+def test_flip_stereo_pair_mirrors_and_swaps():
+  l, r = torch.arange(6.).view(1, 2, 3), torch.arange(6., 12.).view(1, 2, 3)
+  fl, fr = flip_stereo_pair(l, r)
+  assert torch.equal(fl, torch.flip(r, dims=(-1,))) and torch.equal(fr, torch.flip(l, dims=(-1,)))
+
+
+@pytest.mark.parametrize("dataset", DATASETS)
+@pytest.mark.parametrize("do_hflip,random_crop", [(False, False), (True, True)])
+def test_host_path_equals_the_oracle(tmp_path, dataset, do_hflip, random_crop):
+  data, splits = make_tree(str(tmp_path), dataset, n=4)
+  H, W, scales = 24, 40, [0, 1, 2]
+  ds = StereoDataset(data, dataset, "tiny", H, W, "train", scales=scales, do_hflip=do_hflip, random_crop=random_crop,
+                     splits_path=splits)
+  assert len(ds) == 4 and len(read_lines(os.path.join(splits, "tiny", "train_lines.txt"))) == 4
+  for idx in range(len(ds)):
+    random.seed(100 + idx)
+    got = ds[idx]
+    # replay the same draws: window first, then the flip decision (stereo_dataset.py:54-66)
+    random.seed(100 + idx)
+    window = ds._window(37, 61)
+    flip = bool(do_hflip and random.random() < 0.5)
+    paths = [os.path.join(data, p) for p in ds.lines[idx].split(" ")]
+    ref = dorc.sample(dataset, paths, H, W, scales, window, flip)
+    assert set(got.keys()) == set(ref.keys())
+    for key, exp in ref.items():
+      g = got[key]
+      assert g.dtype == torch.float32 and g.shape == exp.shape, key
+      if key.endswith("/0") and dataset != "VirtualKitti":
+        assert torch.equal(g, exp), key                    # integer decode, power-of-two scales: exact
+      else:
+        assert float((g - exp).abs().max()) <= 1e-6 * max(1.0, float(exp.abs().max())), key
+
+
+def test_only_one_disparity_and_calibration(tmp_path):
+  data, splits = make_tree(str(tmp_path), "KittiStereo2015", n=1)
+  ds = StereoDataset(data, "KittiStereo2015", "tiny", 16, 32, "train", scales=[0, 1], load_disp_right=False,
+                     splits_path=splits)
+  s = ds[0]
+  assert "gt_disp_r/0" not in s and "gt_disp_r/1" not in s and s["gt_disp_l/1"].shape == (1, 8, 16)
+  assert ds.get_baseline_meters() == 0.54
+  K = ds.get_intrinsics(375, 1242)
+  assert abs(float(K[0, 0]) - 0.5885 * 1242) < 1e-3 and abs(float(K[1, 1]) - 1.9501 * 375) < 1e-3
+  with pytest.raises(AssertionError):
+    StereoDataset(data, "KittiStereo2015", "tiny", 64, 32, "train", splits_path=splits)[0]     # crop larger than image
