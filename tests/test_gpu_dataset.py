@@ -55,3 +55,35 @@ def test_device_path_single_disparity_and_flip_rule(tmp_path):
     assert set(a) == set(b) == {"color_l/0", "color_r/0", "gt_disp_l/0"}
     for key in a:
       assert torch.equal(b[key].cpu(), a[key]), (seed, key)
+
+
+def test_dataset_to_evaluate_end_to_end(tmp_path):
+  """A KITTI-format tree -> StereoDataset (device path) -> torch DataLoader -> train.evaluate, as evaluate_model.py:34-70
+  wires them; expected metrics from the oracle's forward on the host-path samples (train.py:98-121: per batch, then mean)."""
+  import train as train_surface
+  from torch.utils.data import DataLoader
+  from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+  from adaptive_stereo.utils import synthetic as syn
+  from oracle import stereo_oracle as orc
+  K, MAXDISP, H, W = 3, 64, 64, 96
+  data, splits = make_tree(str(tmp_path), "KittiStereo2015", n=4, H0=70, W0=110, seed=3)
+  dev = StereoDataset(data, "KittiStereo2015", "tiny", H, W, "train", splits_path=splits, device="cuda:0")
+  host = StereoDataset(data, "KittiStereo2015", "tiny", H, W, "train", splits_path=splits)
+  loader = DataLoader(dev, batch_size=2, shuffle=False, num_workers=0)
+  fnet, snet = FeatureExtractorNetwork(K), StereoNet(K, 1, 0, maxdisp=MAXDISP)
+  fsd = syn.synthetic_state_dict(fnet.state_dict(), seed=123)
+  ssd = syn.synthetic_state_dict(snet.state_dict(), seed=123, logit_gain=5.0)
+  fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+  opt = train_surface.TrainOptions().parse(["--stereonet_k", str(K)])
+  m = train_surface.evaluate(fnet.to("cuda:0"), snet.to("cuda:0"), loader, opt)
+  epes, d3 = [], []
+  for i in (0, 2):
+    a, b = host[i], host[i + 1]
+    left, right = torch.stack([a["color_l/0"], b["color_l/0"]]), torch.stack([a["color_r/0"], b["color_r/0"]])
+    gt = torch.stack([a["gt_disp_l/0"], b["gt_disp_l/0"]])
+    out, _ = orc.forward_only(fsd, ssd, left, right, K, 0, MAXDISP)
+    v = gt > 0
+    err = (out["pred_disp_l/0"] - gt).abs()
+    epes.append(float(err[v].mean())); d3.append(float((v * (err > 3)).sum() / float(v.sum())))
+  assert abs(m["EPE"] - sum(epes) / 2) <= 1e-3 * max(1.0, sum(epes) / 2)
+  assert abs(m["D1_all_3px"] - sum(d3) / 2) <= 2e-3
