@@ -134,12 +134,14 @@ __device__ inline void glb_load_w(f32x4 (&r)[4], const float* p) {
 
 // Kernel flavours (compile time, so that no path carries another one's waits):
 //   MODE 0: raw output + BatchNorm moments (training forward)   MODE 1: lrelu(acc*scale+shift) (eval forward)
-//   MODE 2: raw output, no moments (data gradients)             RES: + residual in the output geometry
+//   MODE 2: raw output, no moments (data gradients)             RES 1: + residual in the output geometry
+//   RES 2: the residual IS the layer's input (a BasicBlock's skip connection in the eval forward): it is the centre
+//          row of the staged tile, read from LDS before the buffer is released — no third tensor stream at all
 //   MODE 3: MODE 2 + stage 1 of the following BatchNorm backward: the output IS that layer's g_a, so the sums
 //           sum g_y and sum g_y*(z-mean), g_y = g_a * lrelu'(z*scale+shift), are taken from the register tile
 //           (saves bn_bwd_reduce_kernel's pass over g_a and z: 477 MB per full-resolution layer at 4 pairs)
-template <int MODE, bool RES>
-__global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
+template <int MODE, int RES>
+__device__ __forceinline__ void conv32_lds_body(const ConvLdsArgs& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* tile_buf = smem;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_ptr_t)tile_buf));
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
     const long vox0 = p.gout.vox(b, 0, y, xw);
     const int vbase = 32 * wave + li + 8;
     float* z_base = p.ep.z + vox0 * 32;                 // wave-uniform
-    const float* res_base = RES ? p.ep.residual + vox0 * 32 : nullptr;
+    const float* res_base = RES == 1 ? p.ep.residual + vox0 * 32 : nullptr;
     const float* bnz_base = MODE == 3 ? p.bn_z + vox0 * 32 : nullptr;
     float zt[16];
     f32x16 acc;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
 #pragma unroll
       for (int tp = RESIDENT; tp < 9; ++tp)
         if (4 * tp - W_LEAD == c && c > 0) glb_load_w(w[tp], wb + offs + (tp - RESIDENT) * 1024);
-      if (RES && c == 22) {            // the residual tile, fetched while 14 chunks of MFMA work remain
+      if (RES == 1 && c == 22) {       // the residual tile, fetched while 14 chunks of MFMA work remain
 #define AS_LD(r) load_imm<AS_ROW_IMM(r)>(res[r], res_base, io_off);
         AS_FOR_ROWS(AS_LD)
 #undef AS_LD
@@ -244,7 +246,16 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
     // out: a later wait for it would, vmcnt being in-order, also wait for that DMA.  The residual registers
     // are operands of the wait so that no use of them can be scheduled above it.
     AS_TRACE(3);
-    if (RES) {
+    if (RES == 2) {
+      // centre row (row 1) of the staged tile, voxel 8 + 32*wave + row(r, h), channel li: chunk li>>2 sits in slot
+      // (li>>2) ^ ((v>>1)&7); the 32 lanes of a half read one voxel's 128 bytes (a permutation of its 8 slots)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int v = 8 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+        res[r] = *reinterpret_cast<const float*>(tile_buf + (TL_W + v) * 128 + ((((li >> 2) ^ ((v >> 1) & 7))) << 4) + (li & 3) * 4);
+      }
+    }
+    if (RES == 1) {
       asm volatile("s_waitcnt vmcnt(0)"
                    : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]),
                      "+v"(res[7]), "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]),
@@ -339,6 +350,12 @@ __global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) {
   }
 }
 
+template <int MODE, bool RES>
+__global__ __launch_bounds__(256, 2) void conv32_lds_kernel(ConvLdsArgs p) { conv32_lds_body<MODE, RES ? 1 : 0>(p); }
+
+// eval forward of a BasicBlock: fused BatchNorm + LeakyReLU, skip connection taken from the staged input (RES 2)
+__global__ __launch_bounds__(256, 2) void conv32_lds_skip_kernel(ConvLdsArgs p) { conv32_lds_body<1, 2>(p); }
+
 // ---- host ---------------------------------------------------------------------------------------
 bool conv32_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
   if (s->kd != 1 || s->kh != 3 || s->kw != 3 || s->stride != 1) return false;
@@ -384,11 +401,14 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
   const void* fn = nullptr;
 #define AS_LDS_PICK(M, R) (R ? reinterpret_cast<const void*>(conv32_lds_kernel<M, true>) : reinterpret_cast<const void*>(conv32_lds_kernel<M, false>))
   const bool has_res = residual != nullptr;
+  // eval forward of a BasicBlock: the residual is the input itself (same buffer, same padded geometry)
+  const bool res_self = mode == 1 && residual == x && gin->ph == gout->ph && gin->pw == gout->pw && gin->pd == gout->pd;
   fn = mode == 0 ? AS_LDS_PICK(0, has_res) : mode == 1 ? AS_LDS_PICK(1, has_res) : mode == 2 ? AS_LDS_PICK(2, has_res)
                                                                                               : AS_LDS_PICK(3, has_res);
+  if (res_self) fn = reinterpret_cast<const void*>(conv32_lds_skip_kernel);
 #undef AS_LDS_PICK
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-  const int fi = mode * 2 + (has_res ? 1 : 0);
+  static bool attr_set[9] = {false, false, false, false, false, false, false, false, false};
+  const int fi = res_self ? 8 : mode * 2 + (has_res ? 1 : 0);
   if (!attr_set[fi]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES);
     if (e != hipSuccess) {
