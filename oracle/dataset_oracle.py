@@ -4,7 +4,11 @@ Follows adaptive_stereo/datasets/stereo_dataset.py:49-143 and utils/dataset_util
 and torch-CPU ops, independently of the product code under adaptive-stereo-icra-2021_amd/: full-size float images,
 flip, crop, F.interpolate pyramid.  Parity is pinned by construction here (the reference module itself cannot be
 imported in this container: torchvision, imageio and cv2 are absent): every step is one documented library call —
-ToTensor = uint8/255, imageio/cv2 PNG decode = the stored integers, PFM = big/little-endian float32 rows bottom-up."""
+ToTensor = uint8/255, imageio/cv2 PNG decode = the stored integers, PFM = big/little-endian float32 rows bottom-up.
+
+PARITY UNPINNED: the reference holds no fixtures or tests for its dataset layer and its module cannot run here, so
+this restatement is checked against nothing but its own reading of the reference source (unlike
+oracle/stereo_oracle.py, which is pinned by fixtures generated from the reference)."""
 import re
 
 import numpy as np
