@@ -10,13 +10,15 @@ What is different here (by design, not semantics):
     feature_net — the reference's param-group order, adapt.py:208-209).  Module parameters are views
     into the arena, ``.grad`` tensors are views into the gradient arena, so autograd accumulates in
     place, the clip is one sum-of-squares kernel over a slice, Adam is one kernel per group, and —
-    with more than one GPU — the whole gradient arena (+3 scalars) is ONE RCCL all-reduce over xGMI.
+    with more than one GPU — the whole gradient arena (+4 scalars) is ONE RCCL all-reduce over xGMI per step.
   * the masked mean is a fused reduction (no boolean-index host sync); the step issues no host sync.
 
 Data parallel semantics (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL):
   independent stereo pairs are sharded over ranks; the loss is the mean over the valid pixels of
-  the WHOLE batch (adapt.py:83), so each rank back-propagates sum_r / N_total (N_total from a 1-float
-  all-reduce issued before backward) and gradients are summed.  BatchNorm statistics are per-replica
+  the WHOLE batch (adapt.py:83) = (sum over ranks of the local masked sums) / N_total.  Backward is linear in the
+  incoming gradient, so each rank back-propagates its local SUM, gradients and the four step scalars (valid count, loss
+  sum, FCS sum, FCS count) are all-reduced in one message, and the summed gradients are divided by N_total before
+  clip + Adam.  BatchNorm statistics are per-replica
   (each rank normalises with its own shard's statistics), as in torch DDP without SyncBatchNorm.
 """
 import torch
@@ -51,7 +53,11 @@ class FlatArena(object):
     self.numel = offset
     dev = params[0].device
     self.params = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-    self.grads = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+    # gradients and, behind them, the step's four scalars [valid-pixel count, loss sum, FCS sum, FCS count]: ONE
+    # contiguous buffer, so that data-parallel stepping needs a single all-reduce per step (grads_and_scalars)
+    self.grads_and_scalars = torch.zeros(self.numel + 4, dtype=torch.float32, device=dev)
+    self.grads = self.grads_and_scalars[:self.numel]
+    self.step_scalars = self.grads_and_scalars[self.numel:]
     with torch.no_grad():
       for _, _, p, off, n in self.entries:
         self.params[off:off + n].copy_(p.detach().reshape(-1))
@@ -145,7 +151,7 @@ class OnlineAdapter(object):
     # per-replica statistics, as DistributedDataParallel without SyncBatchNorm.  Eager stepping only.
     self.bn_sync = hip_ops.BnSync(process_group) if (sync_bn and self.world > 1) else None
     dev = self.arena.params.device
-    self.scalars = torch.zeros(4, dtype=torch.float32, device=dev)   # [count, loss_sum, fcs_sum, pairs]
+    self.scalars = self.arena.step_scalars       # [valid count, loss sum, FCS sum, FCS count], behind the gradients
     self._graph = None
     self.plan = hip_ops.StepPlan()     # one-launch weight packing / batch counters (recorded on the first step)
     self.infer_plan = hip_ops.StepPlan()   # same for the eval-mode forward (+ all BatchNorm affines in one launch)
@@ -341,8 +347,9 @@ class OnlineAdapter(object):
     queries events while a capture is open; only this thread's calls have to be capture-safe.)  Every entry point of the C ABI only enqueues work on the current
     stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the device.  Inputs
     are copied into static buffers before each replay.
-    One GPU: a single graph.  Data parallel: three graphs (forward + local sums | backward | clip + Adam + EMA)
-    with the two RCCL all-reduces issued between them on the same stream, outside any capture."""
+    One GPU: a single graph.  Data parallel: two graphs (forward + backward of the local loss sum | 1/N_total scaling
+    + clip + Adam + EMA) with the step's single RCCL all-reduce issued between them on the same stream, outside any
+    capture."""
     if self.bn_sync is not None:
       raise RuntimeError("OnlineAdapter.capture: cross-replica BatchNorm puts collectives inside forward and backward; "
                          "a step cannot be captured with sync_bn=True (step() runs eagerly)")
@@ -363,8 +370,8 @@ class OnlineAdapter(object):
     else:
       if self.pg is not None or dist.is_initialized():
         dist.barrier(group=self.pg)
-      cap = side                         # forward and backward must be captured on the same stream (autograd
-      g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()   # replays backward there)
+      cap = side                         # forward and backward are captured on the same stream (autograd replays
+      g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()              # backward where forward ran)
       with torch.cuda.graph(g1, stream=cap, capture_error_mode="thread_local"):
         self.feature_net.train(); self.stereo_net.train()
         self.arena.rebind_grads()
@@ -374,30 +381,20 @@ class OnlineAdapter(object):
         try:
           total, mask, fcs_map, out, warped = self._forward_maps(self._static_left, self._static_right)
           m8 = self._dp_local_sums(total, mask, fcs_map)
-        finally:
-          hip_ops.rmw_order_reset(False)
-          self.plan.end(final=False)
-      torch.cuda.synchronize()
-      dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
-      torch.cuda.synchronize()
-      with torch.cuda.graph(g2, pool=g1.pool(), stream=cap, capture_error_mode="thread_local"):
-        self.plan.begin(resume=True)
-        hip_ops.rmw_order_reset(True)      # a new capture: events of the forward graph must not be waited on here
-        try:
           self._dp_backward(total, m8)
         finally:
           hip_ops.rmw_order_reset(False)
           self.plan.end()
       torch.cuda.synchronize()
-      allreduce_gradients(self.arena.grads, self.pg)
+      allreduce_gradients_and_scalars(self.arena, self.pg)
       torch.cuda.synchronize()
-      with torch.cuda.graph(g3, pool=g1.pool(), stream=cap, capture_error_mode="thread_local"):
+      with torch.cuda.graph(g2, pool=g1.pool(), stream=cap, capture_error_mode="thread_local"):
         loss, fcs = self._dp_results()
         self.optimizer.step(clip=self.clip)
         self.fcs_smoothed.mul_(self.fcs_ema_weight).add_(fcs.detach(), alpha=1.0 - self.fcs_ema_weight)
         out["left_warped/{}".format(self.scale)] = warped
         self._static_result = {"loss": loss.detach(), "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
-      self._graph = (g1, g2, g3)
+      self._graph = (g1, g2)
     # capture only records: the python-side counter advanced, the device-side one did not
     self.optimizer.step_count = self.optimizer.step_count_at_capture
     return self
@@ -407,12 +404,10 @@ class OnlineAdapter(object):
     if self.world == 1:
       self._graph.replay()
     else:
-      g1, g2, g3 = self._graph
+      g1, g2 = self._graph
       g1.replay()
-      dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
+      allreduce_gradients_and_scalars(self.arena, self.pg)
       g2.replay()
-      allreduce_gradients(self.arena.grads, self.pg)
-      g3.replay()
     self.optimizer.step_count += 1          # host mirror of the device-side counter
     return self._static_result
 
@@ -430,18 +425,21 @@ class OnlineAdapter(object):
     return m8
 
   def _dp_backward(self, total, m8):
-    """Phase 2: d(global mean)/d(total) on this rank = mask / N_total (self.scalars is all-reduced by now)."""
-    total.backward(m8.to(torch.float32) / self.scalars[0])
+    """Phase 1 tail: the gradient of this rank's masked loss SUM (d sum / d total = mask).  The whole-batch masked
+    mean of the reference (adapt.py:83) is (sum over ranks of these sums) / N_total, and backward is linear in the
+    incoming gradient: the division by N_total waits until gradients and counts have been all-reduced together."""
+    total.backward(m8.to(torch.float32))
 
   def _dp_results(self):
+    """Phase 2 head (after the all-reduce): scales the summed gradients by 1/N_total; returns (loss, FCS)."""
     s = self.scalars
+    self.arena.grads.div_(s[0])
     return s[1] / s[0], s[2] / s[3]
 
   def _distributed_backward(self, total, mask, fcs_map, pairs):
     m8 = self._dp_local_sums(total, mask, fcs_map)
-    dist.all_reduce(self.scalars, op=dist.ReduceOp.SUM, group=self.pg)
     self._dp_backward(total, m8)
-    allreduce_gradients(self.arena.grads, self.pg)
+    allreduce_gradients_and_scalars(self.arena, self.pg)
     return self._dp_results()
 
 
@@ -458,6 +456,13 @@ def allreduce_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count, group
     fill_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
+
+
+def allreduce_gradients_and_scalars(arena, group=None):
+    """THE collective of a data-parallel adaptation step: one all-reduce(sum) of the flat gradient arena with the
+    step's four scalars riding behind it (313,702 floats at k=4; latency-bound on xGMI, hence one message)."""
+    dist.all_reduce(arena.grads_and_scalars, op=dist.ReduceOp.SUM, group=group)
+    return arena.grads_and_scalars
 
 
 def allreduce_gradients(flat_grads, group=None):

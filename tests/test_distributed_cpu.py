@@ -71,7 +71,7 @@ def _worker(rank, world, port, result_path):
   os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
   dist.init_process_group("gloo", rank=rank, world_size=world)
   torch.set_num_threads(2)
-  from adaptive_stereo.adaptation import FlatArena, allreduce_step_scalars, allreduce_gradients
+  from adaptive_stereo.adaptation import FlatArena, fill_step_scalars, allreduce_gradients_and_scalars
   from oracle import stereo_oracle as orc
   k, maxdisp, fsd, ssd, left, right = _build()
   fp0, sp0 = orc.make_params(fsd, True), orc.make_params(ssd, True)
@@ -83,13 +83,16 @@ def _worker(rank, world, port, result_path):
 
   lo, hi = rank * (2 // world), (rank + 1) * (2 // world)
   total, mask, fcs = _loss_terms(fp, sp, left[lo:hi], right[lo:hi], k, maxdisp)
-  scal = torch.zeros(4)
-  s = allreduce_step_scalars(scal, (total.detach() * mask).sum(), mask.sum().float(), fcs.sum(), float(fcs.numel()))
+  # the product's recipe (OnlineAdapter._distributed_backward): gradient of this rank's masked loss SUM, then ONE
+  # all-reduce of [gradients | valid count, loss sum, FCS sum, FCS count], then the division by N_total
   arena.zero_grads()
-  total.backward(mask.float() / s[0])
+  s = fill_step_scalars(arena.step_scalars, (total.detach() * mask).sum(), mask.sum().float(), fcs.sum(), float(fcs.numel()))
+  total.backward(mask.float())
   # autograd accumulated into the arena views in place
   assert float(arena.grads.abs().sum()) > 0
-  allreduce_gradients(arena.grads)
+  assert arena.grads_and_scalars.numel() == arena.numel + 4 and arena.step_scalars.data_ptr() == arena.grads.data_ptr() + 4 * arena.numel
+  allreduce_gradients_and_scalars(arena)
+  arena.grads.div_(s[0])
   if rank == 0:
     torch.save({"grads": arena.grads.clone(), "loss": float(s[1] / s[0]), "fcs": float(s[2] / s[3]),
                 "bounds": arena.group_bounds, "n": arena.numel}, result_path)
