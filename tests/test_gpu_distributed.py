@@ -96,7 +96,7 @@ def test_two_rank_adaptation_step_on_one_gpu(tmp_path):
 
 
 def _graph_worker(rank, world, port, out_path):
-  """Eager data-parallel stepping vs the three-graph replay (forward | backward | update, collectives between)."""
+  """Eager data-parallel stepping vs the two-graph replay (forward + backward of the local sum | update, the all-reduce between)."""
   for p in (REPO, PKG):
     if p not in sys.path:
       sys.path.insert(0, p)
