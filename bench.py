@@ -42,6 +42,7 @@ def parse():
   ap.add_argument("--k", type=int, default=4)
   ap.add_argument("--maxdisp", type=int, default=192)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-online", action="store_true", help="skip the extra batch-1 (online setting) measurement")
   ap.add_argument("--one-stream", action="store_true", help="the two feature extractions of a pair back to back on one "
                   "stream instead of side by side on two (for per-kernel profiles: rocprofv3 serialises queues)")
   ap.add_argument("--sync-bn", action="store_true", help="N>1: train-mode BatchNorm over the batches of all ranks (the "
@@ -305,6 +306,33 @@ def main():
     "fwd_ms_per_step": round(1e3 * t_fwd / args.steps, 3),
     "roofline": roofline,
   }
+  if world == 1 and B != 1 and not args.no_online:
+    # The reference adapts online, one pair per step (experiments/adaptation/adapt_*.sh: --batch_size 1): the same
+    # step at batch 1 next to the headline configuration (fresh networks, its own captured graphs).
+    f1, s1 = FeatureExtractorNetwork(args.k), StereoNet(args.k, 1, 0, maxdisp=args.maxdisp)
+    f1.load_state_dict(fsd); s1.load_state_dict(ssd)
+    a1 = OnlineAdapter(f1.to(dev), s1.to(dev), args.height, args.width, lr=5e-5, clip_grad_norm=True,
+                       overlap_features=not args.one_stream)
+    l1, r1 = left[:1].contiguous(), right[:1].contiguous()
+    for _ in range(max(2, args.warmup // 2)):
+      a1.step(l1, r1)
+    if use_graph:
+      a1.capture(l1, r1, warmup=1)
+      a1.step(l1, r1)
+    torch.cuda.synchronize()
+    t1 = timed(lambda: a1.step(l1, r1), args.steps, 1)
+    for _ in range(2):
+      a1.infer(l1, r1)
+    if use_graph:
+      a1.capture_infer(l1, r1)
+      a1.infer(l1, r1)
+    torch.cuda.synchronize()
+    t1f = timed(lambda: a1.infer(l1, r1), args.steps, 1)
+    out["online_batch1"] = {"pairs_per_s": round(args.steps / t1, 3), "ms_per_step": round(1e3 * t1 / args.steps, 3),
+                            "fwd_pairs_per_s": round(args.steps / t1f, 3), "fwd_ms_per_step": round(1e3 * t1f / args.steps, 3),
+                            "note": "one pair per step (the reference's online setting), same kernels and graphs"}
+    log("online (batch 1): %.2f ms/step, forward %.2f ms" % (1e3 * t1 / args.steps, 1e3 * t1f / args.steps))
+    del a1, f1, s1
   if world == 1 and not args.no_cpu_baseline:
     out["cpu_baseline"] = cpu_baseline(args, fsd, ssd)
     log("cpu baseline done")
