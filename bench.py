@@ -42,7 +42,10 @@ def parse():
   ap.add_argument("--k", type=int, default=4)
   ap.add_argument("--maxdisp", type=int, default=192)
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--no-online", action="store_true", help="skip the extra batch-1 (online setting) measurement")
+  ap.add_argument("--online", action="store_true", help="also measure the step at one pair per step (the reference's "
+                  "online setting) -> \"online_batch1\"; off by default so that a kernel trace of the default command "
+                  "holds launches of ONE size")
+  ap.add_argument("--no-online", action="store_true", help=argparse.SUPPRESS)     # accepted for older scripts
   ap.add_argument("--one-stream", action="store_true", help="the two feature extractions of a pair back to back on one "
                   "stream instead of side by side on two (for per-kernel profiles: rocprofv3 serialises queues)")
   ap.add_argument("--sync-bn", action="store_true", help="N>1: train-mode BatchNorm over the batches of all ranks (the "
@@ -306,7 +309,7 @@ def main():
     "fwd_ms_per_step": round(1e3 * t_fwd / args.steps, 3),
     "roofline": roofline,
   }
-  if world == 1 and B != 1 and not args.no_online:
+  if world == 1 and B != 1 and args.online and not args.no_online:
     # The reference adapts online, one pair per step (experiments/adaptation/adapt_*.sh: --batch_size 1): the same
     # step at batch 1 next to the headline configuration (fresh networks, its own captured graphs).
     f1, s1 = FeatureExtractorNetwork(args.k), StereoNet(args.k, 1, 0, maxdisp=args.maxdisp)
