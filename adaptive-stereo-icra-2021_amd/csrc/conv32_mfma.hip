@@ -158,7 +158,8 @@ struct WgradArgs {
   float* partial_db;  // [nchunks][32]
   PclDev gin, gout;
   int rows;           // work units: B*D*H rows x nseg segments
-  int nseg;           // segments of WG_SEG_STEPS voxel pairs per row
+  int nseg;           // segments per row
+  int seg_steps;      // voxel pairs per segment (a multiple of the 8-step load groups)
   int rows_per_chunk; // units per workgroup
   int nchunks;
   int ntaps;
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
     const int b = t / D;
     const float* xr = p.x + p.gin.vox(b, d, y * p.stride, 0) * 32 + li;
     const float* gr = p.gz + p.gout.vox(b, d, y, 0) * 32 + li;
-    const int s_end = min(nsteps, (seg + 1) * WG_SEG_STEPS);
-    for (int s0 = seg * WG_SEG_STEPS; s0 < s_end; s0 += WG_U) {
+    const int s_end = min(nsteps, (seg + 1) * p.seg_steps);
+    for (int s0 = seg * p.seg_steps; s0 < s_end; s0 += WG_U) {
       float bv[WG_U], av[WG_U][TG];
 #pragma unroll
       for (int u = 0; u < WG_U; ++u) {
@@ -560,11 +561,30 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
   return AS_OK;
 }
 
-static int wgrad_segments(const as_pcl* gout) { return (((gout->W + 1) >> 1) + WG_SEG_STEPS - 1) / WG_SEG_STEPS; }
+// Rows are cut into segments only while whole rows would leave SIMDs idle (rows x tap groups < 1024 waves): every
+// extra segment is an extra partial slab to write and reduce.
+static int wgrad_segments(const as_pcl* gout, const as_conv_shape* s, int* seg_steps) {
+  const int T = s->kd * s->kh * s->kw;
+  const int groups = T / ((T % 3 == 0) ? 3 : (T % 5 == 0 ? 5 : 1));
+  const int nsteps = (gout->W + 1) >> 1;
+  const long waves = (long)gout->B * gout->D * gout->H * groups;
+  int nseg = 1;
+  if (waves < 1024) {
+    nseg = (int)((2048 + waves - 1) / waves);
+    const int most = (nsteps + WG_SEG_STEPS - 1) / WG_SEG_STEPS;         // segments of at least WG_SEG_STEPS pairs
+    if (nseg > most) nseg = most;
+    if (nseg < 1) nseg = 1;
+  }
+  int steps = (nsteps + nseg - 1) / nseg;
+  steps = (steps + 7) / 8 * 8;
+  *seg_steps = steps;
+  return (nsteps + steps - 1) / steps;
+}
 static int wgrad_plan(const as_pcl* gout, const as_conv_shape* s, int* tg, int* rows_per_chunk, int* nchunks) {
   const int T = s->kd * s->kh * s->kw;
   *tg = (T % 3 == 0) ? 3 : (T % 5 == 0 ? 5 : 1);
-  const int rows = gout->B * gout->D * gout->H * wgrad_segments(gout);       // work units (row segments)
+  int seg_steps;
+  const int rows = gout->B * gout->D * gout->H * wgrad_segments(gout, s, &seg_steps);       // work units (row segments)
   // aim at ~4 waves per SIMD over the chip (256 CUs x 4 SIMDs), at least 4 units (one per
   // wave) per chunk, and cap the slab count so the partial buffer stays a few MB.
   const int groups = T / *tg;
@@ -631,7 +651,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
   WgradArgs a;
   a.x = x; a.gz = gz; a.partial = workspace; a.partial_db = workspace + (int64_t)nchunks * T * 1024;
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
-  a.nseg = wgrad_segments(gout);
+  a.nseg = wgrad_segments(gout, s, &a.seg_steps);
   a.rows = gout->B * gout->D * gout->H * a.nseg; a.rows_per_chunk = rpc; a.nchunks = nchunks; a.ntaps = T; a.stride = s->stride;
   if (int e = fill_taps(gin, s, a.tap_off, "as_conv32_wgrad")) return e;
   hipStream_t st = (hipStream_t)stream;
