@@ -107,16 +107,27 @@ class StereoDataset(Dataset):
 
   # -- device path: raw samples up, HIP gather kernels ------------------------------------------------
   def _getitem_device(self, index):
-    from .. import _native as nat
-    dev = self.device
+    raw = self.parse(index)
+    i, j = self._window(raw[0].shape[0], raw[0].shape[1])
+    flip = bool(self.do_hflip and random.random() < 0.5)
+    return self.decode(raw, i, j, flip)
+
+  def parse(self, index):
+    """Host half of the device path: file parsing only (PIL / PFM / NPY) -> (rgb_l, rgb_r uint8 [H0,W0,3], disp_l,
+    disp_r RawPlane or None).  No random decisions, no torch: safe to run in worker threads (datasets/prefetch.py)."""
     rgb_l_path, rgb_r_path, disp_l_path, disp_r_path = self._paths(index)
     raw_l = _rgb8(Image.open(rgb_l_path))
     raw_r = _rgb8(Image.open(rgb_r_path))
-    H0, W0 = raw_l.shape[0], raw_l.shape[1]
-    i, j = self._window(H0, W0)
-    flip = bool(self.do_hflip and random.random() < 0.5)
     disp_l = self.load_raw_disp_fn(disp_l_path) if self.load_disp_left else None
     disp_r = self.load_raw_disp_fn(disp_r_path) if self.load_disp_right else None
+    return raw_l, raw_r, disp_l, disp_r
+
+  def decode(self, raw, i, j, flip):
+    """Device half: upload the raw samples and run crop / flip / conversion / pyramid on the current HIP stream."""
+    from .. import _native as nat
+    dev = self.device
+    raw_l, raw_r, disp_l, disp_r = raw
+    H0, W0 = raw_l.shape[0], raw_l.shape[1]
     flip_disp = flip and disp_l is not None and disp_r is not None           # stereo_dataset.py:69-70
     if flip:
       raw_l, raw_r = raw_r, raw_l                                             # mirrored in the kernel, swapped here
@@ -125,8 +136,8 @@ class StereoDataset(Dataset):
     h, w = self.height, self.width
     st = nat.stream()
 
-    def colour(raw):
-      src = torch.from_numpy(raw).to(dev, non_blocking=True)
+    def colour(arr):
+      src = torch.from_numpy(arr).to(dev, non_blocking=True)
       dst = torch.empty(3, h, w, dtype=torch.float32, device=dev)
       nat.call("as_decode_rgb8", nat.ptr(src), H0, W0, i, j, h, w, int(flip), nat.ptr(dst), st)
       return dst

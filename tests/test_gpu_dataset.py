@@ -87,3 +87,30 @@ def test_dataset_to_evaluate_end_to_end(tmp_path):
     epes.append(float(err[v].mean())); d3.append(float((v * (err > 3)).sum() / float(v.sum())))
   assert abs(m["EPE"] - sum(epes) / 2) <= 1e-3 * max(1.0, sum(epes) / 2)
   assert abs(m["D1_all_3px"] - sum(d3) / 2) <= 2e-3
+
+
+def test_device_prefetcher_equals_direct_indexing(tmp_path):
+  """Thread-pool parsing + side-stream decoding one batch ahead: same batches, same random decisions, as indexing the
+  dataset sample by sample (ragged last batch, drop_last, shuffle with a seed)."""
+  from adaptive_stereo.datasets.prefetch import DevicePrefetcher
+  data, splits = make_tree(str(tmp_path), "KittiStereo2015", n=7, H0=40, W0=70, seed=5)
+  kw = dict(scales=[0, 1], do_hflip=True, random_crop=True, splits_path=splits, device="cuda:0")
+  ds = StereoDataset(data, "KittiStereo2015", "tiny", 32, 64, "train", **kw)
+  random.seed(11)
+  ref = [ds[i] for i in range(len(ds))]
+  random.seed(11)
+  got = list(DevicePrefetcher(ds, batch_size=3, num_threads=4))
+  assert [b["color_l/0"].shape[0] for b in got] == [3, 3, 1] and len(DevicePrefetcher(ds, 3)) == 3
+  torch.cuda.synchronize()
+  k = 0
+  for b in got:
+    for r in range(b["color_l/0"].shape[0]):
+      for key in ref[k]:
+        assert torch.equal(b[key][r], ref[k][key]), (k, key)
+      k += 1
+  assert len(list(DevicePrefetcher(ds, batch_size=3, drop_last=True))) == 2 == len(DevicePrefetcher(ds, 3, drop_last=True))
+  random.seed(5); a = [b["color_l/0"].sum().item() for b in DevicePrefetcher(ds, 2, shuffle=True, seed=3)]
+  random.seed(5); c = [b["color_l/0"].sum().item() for b in DevicePrefetcher(ds, 2, shuffle=True, seed=3)]
+  assert len(a) == 4 and a == c                        # same shuffle seed and same draws: same epoch
+  with pytest.raises(ValueError):
+    DevicePrefetcher(StereoDataset(data, "KittiStereo2015", "tiny", 32, 64, "train", splits_path=splits), 2)

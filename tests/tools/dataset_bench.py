@@ -46,7 +46,21 @@ e0.record()
 for _ in range(20): kernels()
 e1.record(); torch.cuda.synchronize()
 t_k = e0.elapsed_time(e1) / 20 * 1e-3
+from adaptive_stereo.datasets.prefetch import DevicePrefetcher
+def run_prefetch(threads, epochs=4):
+  random.seed(2)
+  n = 0
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(epochs):
+    for batch in DevicePrefetcher(dev, batch_size=4, num_threads=threads):
+      n += batch["color_l/0"].shape[0]
+  torch.cuda.synchronize()
+  return (time.perf_counter() - t0) / n
+run_prefetch(8, 1)
+t_pf = {th: run_prefetch(th) for th in (1, 4, 8, 16)}
 print("KITTI 375x1242 -> 320x960 crop, flip, scales 0-3, both views + both disparities, PNG files on tmpfs:")
 print("  host path (reference's torch ops, 1 process): %6.1f ms/sample = %6.1f samples/s" % (1e3 * t_host, 1 / t_host))
 print("  device path (PIL parse + upload + HIP kernels): %6.1f ms/sample = %6.1f samples/s" % (1e3 * t_dev, 1 / t_dev))
 print("  device kernels alone (16 launches per sample): %6.3f ms/sample = %6.0f samples/s" % (1e3 * t_k, 1 / t_k))
+print("  DevicePrefetcher (thread-pool parsing, side-stream decode, batches of 4): " + ", ".join(
+    "%d threads %.0f samples/s" % (th, 1 / t) for th, t in t_pf.items()))
