@@ -114,3 +114,27 @@ def test_device_prefetcher_equals_direct_indexing(tmp_path):
   assert len(a) == 4 and a == c                        # same shuffle seed and same draws: same epoch
   with pytest.raises(ValueError):
     DevicePrefetcher(StereoDataset(data, "KittiStereo2015", "tiny", 32, 64, "train", splits_path=splits), 2)
+
+
+def test_prefetched_stream_drives_the_adaptation_step(tmp_path):
+  """KITTI-format tree -> DevicePrefetcher (batch 1, the reference's online setting) -> OnlineAdapter.step: the losses
+  equal those of stepping on the same samples taken by direct indexing (the decode stream hands over through events)."""
+  from adaptive_stereo.adaptation import OnlineAdapter
+  from adaptive_stereo.datasets.prefetch import DevicePrefetcher
+  from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+  from adaptive_stereo.utils import synthetic as syn
+  K, MAXDISP, H, W = 3, 64, 64, 96
+  data, splits = make_tree(str(tmp_path), "KittiRaw", n=4, H0=70, W0=110, seed=9)
+  ds = StereoDataset(data, "KittiRaw", "tiny", H, W, "train", splits_path=splits, device="cuda:0", load_disp_right=False)
+
+  def run(batches):
+    fnet, snet = FeatureExtractorNetwork(K), StereoNet(K, 1, 0, maxdisp=MAXDISP)
+    fnet.load_state_dict(syn.synthetic_state_dict(fnet.state_dict(), seed=123))
+    snet.load_state_dict(syn.synthetic_state_dict(snet.state_dict(), seed=123, logit_gain=5.0))
+    adapter = OnlineAdapter(fnet.to("cuda:0"), snet.to("cuda:0"), H, W, lr=5e-5)
+    return [float(adapter.step(b["color_l/0"], b["color_r/0"])["loss"]) for b in batches]
+
+  direct = [{k: v.unsqueeze(0) for k, v in ds[i].items()} for i in range(len(ds))]
+  a = run(direct)
+  b = run(DevicePrefetcher(ds, batch_size=1, num_threads=2))
+  assert a == b and all(x == x and 0.0 < x < 10.0 for x in a), (a, b)
