@@ -342,7 +342,7 @@ class OnlineAdapter(object):
 
   # -- hipGraph capture of the whole step ------------------------------------------------------------
   def capture(self, left, right, warmup=3):
-    """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~360 kernel launches) into
+    """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~320 kernel launches) into
     hipGraphs and replays them from then on.  (capture_error_mode="thread_local": the process-group watchdog thread
     queries events while a capture is open; only this thread's calls have to be capture-safe.)  Every entry point of the C ABI only enqueues work on the current
     stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the device.  Inputs

@@ -51,7 +51,7 @@ def parse():
   ap.add_argument("--sync-bn", action="store_true", help="N>1: train-mode BatchNorm over the batches of all ranks (the "
                   "reference's whole-batch semantics; 34 small collectives per step, eager launches) instead of "
                   "per-replica statistics")
-  ap.add_argument("--no-graph", action="store_true", help="launch the ~540 kernels of a step eagerly instead of "
+  ap.add_argument("--no-graph", action="store_true", help="launch the ~320 kernels of a step eagerly instead of "
                                                           "replaying a captured hipGraph (single GPU only)")
   return ap.parse_args()
 
