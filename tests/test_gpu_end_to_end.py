@@ -242,6 +242,40 @@ def test_full_size_properties_kitti():
     assert float(l_tot[1].abs().max()) == 0.0 and float(l_tot[2].abs().max()) < 1e-6   # identical images: L1 = SSIM dist = 0
 
 
+@pytest.mark.parametrize("H,W,k", [(375, 1242, 3), (540, 960, 3), (540, 960, 4)])
+def test_full_size_properties_other_configurations(H, W, k):
+  """The remaining sizes of SURVEY 8's table at full size (k=3: the 3-D layers on 47x156 / 68x120 planes, 24 disparities):
+  shapes, batch independence and determinism of the eval forward bit for bit, and one adaptation step whose training
+  forward is independent of the batch composition in everything that does not pass a BatchNorm (the cost volume)."""
+  B = 2
+  meta = dict(k=k, s=0, maxdisp=192, gain=1.0)
+  fnet, snet = build(meta)
+  fnet.eval(); snet.eval()
+  left, right = syn.stereo_pair(B, H, W, seed=13)
+  ld, rd = left.to(DEV), right.to(DEV)
+  Hc, Wc, Dc = -(-H // 2 ** k), -(-W // 2 ** k), 193 // 2 ** k
+  key = "cost_volume_l/%d" % k
+  with torch.no_grad():
+    fl, fr = fnet(ld), fnet(rd)
+    assert tuple(fl.shape) == (B, 32, Hc, Wc)
+    out = snet(ld, fl, fr, "l", output_cost_volume=True)
+    assert tuple(out[key].shape) == (B, Dc, Hc, Wc) and tuple(out["pred_disp_l/0"].shape) == (B, 1, H, W)
+    out0 = snet(ld[1:], fl[1:], fr[1:], "l", output_cost_volume=True)
+    assert torch.equal(out0[key], out[key][1:])
+    assert torch.equal(out0["pred_disp_l/0"], out["pred_disp_l/0"][1:])
+    again = snet(ld, fl, fr, "l", output_cost_volume=True)
+    assert torch.equal(again[key], out[key]) and torch.equal(again["pred_disp_l/0"], out["pred_disp_l/0"])
+    pred_c = out["pred_disp_l/%d" % k] / 2 ** k
+    assert float(pred_c.min()) >= 0.0 and float(pred_c.max()) <= Dc - 1 + 1e-4
+    assert bool(torch.isfinite(out["pred_disp_l/0"]).all())
+  adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+  r1 = adapter.step(ld, rd)
+  r2 = adapter.step(ld, rd)
+  torch.cuda.synchronize()
+  assert 0.0 < float(r2["loss"]) < 10.0 and float(r1["loss"]) == float(r1["loss"])
+  assert bool(torch.isfinite(adapter.arena.params).all()) and bool(torch.isfinite(adapter.arena.grads).all())
+
+
 def test_graph_replay_equals_eager_steps():
   """A captured hipGraph of the adaptation step must reproduce eager stepping bit for bit
   (same kernels, same order; the Adam step count lives on the device)."""
