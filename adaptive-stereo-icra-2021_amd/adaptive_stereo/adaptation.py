@@ -163,7 +163,10 @@ class OnlineAdapter(object):
   @torch.no_grad()
   def infer(self, left, right):
     if self._infer_graph is not None:
-      self._infer_left.copy_(left); self._infer_right.copy_(right)
+      if left.data_ptr() != self._infer_left.data_ptr():
+        self._infer_left.copy_(left)
+      if right.data_ptr() != self._infer_right.data_ptr():
+        self._infer_right.copy_(right)
       self._infer_graph.replay()
       return self._infer_result
     return self._infer_eager(left, right)
@@ -399,8 +402,20 @@ class OnlineAdapter(object):
     self.optimizer.step_count = self.optimizer.step_count_at_capture
     return self
 
+  def graph_inputs(self):
+    """The captured step's own input buffers (after capture()): a producer that decodes or copies the next pair
+    straight into them — and then passes them to step() — saves the two device copies a replay otherwise starts with."""
+    return self._static_left, self._static_right
+
+  def infer_inputs(self):
+    """Same for the captured inference graph (after capture_infer())."""
+    return self._infer_left, self._infer_right
+
   def _replay(self, left, right):
-    self._static_left.copy_(left); self._static_right.copy_(right)
+    if left.data_ptr() != self._static_left.data_ptr():
+      self._static_left.copy_(left)
+    if right.data_ptr() != self._static_right.data_ptr():
+      self._static_right.copy_(right)
     if self.world == 1:
       self._graph.replay()
     else:

@@ -292,7 +292,15 @@ def test_graph_replay_equals_eager_steps():
       adapter.capture(*batches[0], warmup=1)        # warm-up inside capture() advances the state by one step
     else:
       adapter.step(*batches[0])
-    losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
+    if use_graph:
+      # second pair through the graph's own input buffers (no device copy at the start of the replay), the others by copy
+      gl, gr = adapter.graph_inputs()
+      losses = [float(adapter.step(*batches[1])["loss"])]
+      gl.copy_(batches[2][0]); gr.copy_(batches[2][1])
+      losses.append(float(adapter.step(gl, gr)["loss"]))
+      losses.append(float(adapter.step(*batches[3])["loss"]))
+    else:
+      losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
     torch.cuda.synchronize()
     results.append((losses, adapter.arena.params.clone(), adapter.optimizer.exp_avg_sq.clone(),
                     int(snet.filter[0][0].bn.num_batches_tracked), adapter.optimizer.step_count,
