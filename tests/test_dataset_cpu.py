@@ -81,3 +81,28 @@ def test_only_one_disparity_and_calibration(tmp_path):
   assert abs(float(K[0, 0]) - 0.5885 * 1242) < 1e-3 and abs(float(K[1, 1]) - 1.9501 * 375) < 1e-3
   with pytest.raises(AssertionError):
     StereoDataset(data, "KittiStereo2015", "tiny", 64, 32, "train", splits_path=splits)[0]     # crop larger than image
+
+
+def test_prefetcher_batching_logic_without_a_gpu():
+  """Batch composition of DevicePrefetcher (order, ragged tail, drop_last, seeded shuffle) is host logic."""
+  from adaptive_stereo.datasets.prefetch import DevicePrefetcher
+
+  class Fake(object):
+    device = "cuda:0"
+    def __len__(self): return 10
+
+  pf = DevicePrefetcher(Fake(), batch_size=4)
+  assert list(pf._batches()) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]] and len(pf) == 3
+  pf = DevicePrefetcher(Fake(), batch_size=4, drop_last=True)
+  assert list(pf._batches()) == [[0, 1, 2, 3], [4, 5, 6, 7]] and len(pf) == 2
+  a = list(DevicePrefetcher(Fake(), batch_size=3, shuffle=True, seed=7)._batches())
+  b = list(DevicePrefetcher(Fake(), batch_size=3, shuffle=True, seed=7)._batches())
+  assert a == b and sorted(sum(a, [])) == list(range(10)) and a != [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
+  pf = DevicePrefetcher(Fake(), batch_size=3, shuffle=True, seed=7)
+  first, second = list(pf._batches()), list(pf._batches())
+  assert first != second                                  # a new permutation every epoch, reproducible from the seed
+
+  class Host(Fake):
+    device = None
+  with pytest.raises(ValueError):
+    DevicePrefetcher(Host(), 2)
