@@ -6,8 +6,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 fwd = rows[adam[-1] + 1:]
-starts = [i for i, r in enumerate(fwd) if 'pack_in4' in r['Kernel_Name']]
-win = fwd[starts[-3]:]
+ends = [i for i, r in enumerate(fwd) if 'conv32to1_2d_fwd_kernel' in r['Kernel_Name']]
+win = fwd[ends[-2] + 1:ends[-1] + 1]
 t0 = int(win[0]['Start_Timestamp'])
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in win)
 print("wall %.1f us, busy %.1f us, %d kernels" % ((int(win[-1]['End_Timestamp']) - t0) / 1e3, busy / 1e3, len(win)))

@@ -6,12 +6,10 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 fwd = rows[adam[-1] + 1:]
-# forward steps start with pack_in4 of the feature extractor; keep the last `steps` of them
-starts = [i for i, r in enumerate(fwd) if 'pack_in4' in r['Kernel_Name']]
-per = len(starts) // 3 if False else None
-# each inference has 3 pack_in4 launches (left, right, refinement)
-first = starts[-3 * steps]
-win = fwd[first:]
+# an inference ends with the refinement's 32->1 output convolution; keep the last `steps` of them
+ends = [i for i, r in enumerate(fwd) if 'conv32to1_2d_fwd_kernel' in r['Kernel_Name']]
+first = ends[-steps - 1] + 1
+win = fwd[first:ends[-1] + 1]
 t0, t1 = int(win[0]['Start_Timestamp']), int(win[-1]['End_Timestamp'])
 agg = collections.defaultdict(lambda: [0, 0])
 for r in win:
