@@ -177,19 +177,21 @@ class OnlineAdapter(object):
     self.feature_net.eval(); self.stereo_net.eval()
     self.infer_plan.begin()
     try:
-      if left.shape[0] <= self.infer_batched_features_max:
-        # eval mode is stateless and batch-independent (bit for bit): both images go through the feature extractor
-        # as ONE batch — half the launches of a chain that is latency-bound (measured better than two streams at
-        # every batch size: +5 % at one pair, +1 % at eight)
-        both = self.feature_net(_adjacent_or_cat(left, right))
-        fl, fr = both[:left.shape[0]], both[left.shape[0]:]
-      else:
-        fl, fr = self._features_two_streams(left, right)
+      fl, fr = self._features_eval(left, right)
       out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     finally:
       self.infer_plan.end()
     fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
     return out, fcs
+
+  def _features_eval(self, left, right):
+    """Eval mode is stateless and batch-independent (bit for bit): both images go through the feature extractor as ONE
+    batch — half the launches of a chain that is latency-bound (measured better than two streams at every batch size:
+    +5 % at one pair, +1 % at eight)."""
+    if left.shape[0] > self.infer_batched_features_max:
+      return self._features_two_streams(left, right)
+    both = self.feature_net(_adjacent_or_cat(left, right))
+    return both[:left.shape[0]], both[left.shape[0]:]
 
   def _features_two_streams(self, left, right):
     """The two feature extractions of a pair are independent and, at 1/16 resolution, far too small to fill the chip
@@ -291,7 +293,10 @@ class OnlineAdapter(object):
     hip_ops.rmw_order_reset(two_streams)
     try:
       with torch.set_grad_enabled(train):
-        fl, fr = self._features_two_streams(left, right) if two_streams else (self.feature_net(left), self.feature_net(right))
+        if not train:
+          fl, fr = self._features_eval(left, right)
+        else:
+          fl, fr = self._features_two_streams(left, right) if two_streams else (self.feature_net(left), self.feature_net(right))
         out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
         pred = out["pred_disp_l/{}".format(self.scale)]
         warped, mask = self.warper(right, pred, right_to_left=True)
@@ -344,7 +349,7 @@ class OnlineAdapter(object):
     """monodepth_single_loss in eval mode, as StateMachine.validate uses it (adapt.py:121-142)."""
     was_f, was_s = self.feature_net.training, self.stereo_net.training
     self.feature_net.eval(); self.stereo_net.eval()
-    fl, fr = self.feature_net(left), self.feature_net(right)
+    fl, fr = self._features_eval(left, right)
     out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     pred = out["pred_disp_l/{}".format(self.scale)]
     warped, mask = self.warper(right, pred, right_to_left=True)
