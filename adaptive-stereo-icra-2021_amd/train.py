@@ -67,7 +67,13 @@ class TrainOptions(object):
 
 
 def process_batch(feature_net, stereo_net, left, right, opt, output_cost_volume=False):
-  left_feat, right_feat = feature_net(left), feature_net(right)
+  """Reference train.py:19-22.  In eval mode the feature extractor is stateless and batch-independent (bit for bit), so
+  both images pass it as one batch (half the launches); in train mode each image keeps its own BatchNorm statistics."""
+  if not feature_net.training and left.shape == right.shape:
+    both = feature_net(torch.cat([left, right]))
+    left_feat, right_feat = both[:left.shape[0]], both[left.shape[0]:]
+  else:
+    left_feat, right_feat = feature_net(left), feature_net(right)
   return stereo_net(left, left_feat, right_feat, "l", output_cost_volume=output_cost_volume)
 
 
