@@ -590,3 +590,43 @@ def test_conv4_wgrad_fused_with_bn_backward_apply():
   halo = ops.pcl_view(gz, g).clone(); ops.pcl_interior(halo, g).zero_()
   assert float(halo.abs().max()) == 0.0
   assert torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
+
+
+def test_conv3d_lds_random_geometries():
+  """The flattened-plane 3-D kernels (forward, data gradient, weight gradient, moments) over a sweep of geometries around
+  their applicability edges: the narrowest row (W + 2 = 34), planes of just over one tile, every remainder class of the
+  shifted last tile, one and several disparity planes, batch > 1 — against torch conv3d and its autograd."""
+  shape = ConvShape(3, 3, 3, 1, 1, 1, 1, 1)
+  rng = torch.Generator().manual_seed(2024)
+  geoms = [(1, 1, 4, 32), (1, 2, 5, 32), (2, 3, 4, 33), (1, 1, 3, 62), (1, 4, 7, 45), (3, 2, 6, 41), (1, 5, 9, 64),
+           (1, 1, 2, 126), (2, 2, 3, 100), (1, 3, 13, 37), (1, 2, 24, 78), (1, 1, 5, 188)]
+  lib = nat.load()
+  for (B, D, H, W) in geoms:
+    g = Pcl(B, D, H, W, 1, 1, 1)
+    assert lib.as_conv32_stat_parts(g, g, shape) == B * D * (((H - 1) * (W + 2) + W + 127) // 128), (B, D, H, W)
+    x = torch.randn(B, 32, D, H, W, generator=rng).requires_grad_(True)
+    w = (torch.randn(32, 32, 3, 3, 3, generator=rng) / (32 * 27) ** 0.5).requires_grad_(True)
+    b = (torch.randn(32, generator=rng) * 0.1).requires_grad_(True)
+    z_ref = F.conv3d(x, w, b, padding=1)
+    gz = torch.randn(z_ref.shape, generator=rng)
+    z_ref.backward(gz)
+    xb = ops.ncdhw_to_pcl(x.detach().to(DEV), g)
+    wd = w.detach().to(DEV)
+    stats = ops.conv32_stat_parts(g, g, shape, DEV)
+    zb = ops.conv32(xb, g, ops.pack_weights(wd, shape, False), b.detach().to(DEV), g, shape, stats=stats)
+    tag = "B%d D%d H%d W%d" % (B, D, H, W)
+    close(ops.pcl_to_ncdhw(zb, g), z_ref, 2e-5, 1e-5, tag + " fwd")
+    full = ops.pcl_view(zb, g).clone(); ops.pcl_interior(full, g).zero_()
+    assert float(full.abs().max()) == 0.0, tag + ": wrote into the halo"
+    st = ops.bn_train_stats(stats, torch.ones(32, device=DEV), torch.zeros(32, device=DEV), torch.zeros(32, device=DEV),
+                            torch.ones(32, device=DEV))
+    zr = z_ref.detach()
+    close(st.mean, zr.mean(dim=(0, 2, 3, 4)), 3e-6, 1e-5, tag + " mean")
+    close(st.invstd, 1.0 / torch.sqrt(zr.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5), 0, 3e-5, tag + " invstd")
+    gzb = ops.ncdhw_to_pcl(gz.to(DEV), g)
+    gxb = ops.conv32(gzb, g, ops.pack_weights(wd, shape, True), None, g, shape)
+    close(ops.pcl_to_ncdhw(gxb, g), x.grad, 3e-5, 1e-5, tag + " dgrad")
+    dW, db = ops.conv32_wgrad(xb, g, gzb, g, shape)
+    for name, got, exp in ((" wgrad", dW, w.grad), (" bias grad", db, b.grad)):
+      rel = float((got.cpu().double() - exp.double()).norm() / exp.double().norm())
+      assert rel < 1e-5, "%s%s: relative L2 error %.2e" % (tag, name, rel)
