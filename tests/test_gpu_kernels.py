@@ -630,3 +630,24 @@ def test_conv3d_lds_random_geometries():
     for name, got, exp in ((" wgrad", dW, w.grad), (" bias grad", db, b.grad)):
       rel = float((got.cpu().double() - exp.double()).norm() / exp.double().norm())
       assert rel < 1e-5, "%s%s: relative L2 error %.2e" % (tag, name, rel)
+
+
+@pytest.mark.parametrize("B,H,W,dil", [(2, 19, 300, 1), (1, 23, 257, 4), (1, 33, 140, 8), (1, 5, 128, 2)])
+def test_conv32_lds_skip_from_staged_tile(B, H, W, dil):
+  """Eval forward of a BasicBlock on the LDS-staged kernel: when the residual IS the input buffer the skip connection
+  is read from the staged tile (conv32_lds_skip_kernel).  Must equal torch, and — bit for bit — the same call with the
+  residual handed over as a separate copy (the three-stream flavour)."""
+  shape, halo = ConvShape(1, 3, 3, 0, dil if dil > 1 else 1, dil if dil > 1 else 1, dil, 1), (0, 8, 8)
+  x, w, b = rnd(B, 32, 1, H, W, seed=1), rnd(32, 32, 3, 3, seed=2, scale=0.06), rnd(32, seed=3, scale=0.1)
+  sc, sh = rnd(32, seed=4) * 0.5 + 1.0, rnd(32, seed=5) * 0.3
+  ref = x + F.leaky_relu(_conv_ref(x, w, b, shape) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1), 0.2)
+  g = Pcl(B, 1, H, W, *halo)
+  xb = ops.ncdhw_to_pcl(x.to(DEV), g)
+  wp = ops.pack_weights(w.to(DEV), shape, False)
+  args = dict(epilogue=1, scale=sc.to(DEV), shift=sh.to(DEV))
+  out_self = ops.conv32(xb, g, wp, b.to(DEV), g, shape, residual=xb, **args)
+  out_copy = ops.conv32(xb, g, wp, b.to(DEV), g, shape, residual=xb.clone(), **args)
+  close(ops.pcl_to_ncdhw(out_self, g), ref, 3e-5, 1e-5, "skip from the staged tile")
+  assert torch.equal(out_self, out_copy)
+  full = ops.pcl_view(out_self, g).clone(); ops.pcl_interior(full, g).zero_()
+  assert float(full.abs().max()) == 0.0
