@@ -106,6 +106,9 @@ _SIGNATURES = {
                                     c_vp, c_vp, c_vp]),
   "as_masked_sum_workspace": (c_i64, [c_i64]),
   "as_masked_sum": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+  "as_khamis_workspace": (c_i64, [c_i64]),
+  "as_khamis_fwd": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+  "as_khamis_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
   "as_eval_metrics_workspace": (c_i64, [c_i64]),
   "as_eval_metrics": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_sumsq_workspace": (c_i64, [c_i64]),

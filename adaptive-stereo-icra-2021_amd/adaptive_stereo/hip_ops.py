@@ -1089,3 +1089,32 @@ class MaskedMeanFn(torch.autograd.Function):
 
 def masked_mean(values, mask):
   return MaskedMeanFn.apply(values, mask)
+
+
+# ----------------------------------------------------------------------------------------
+# a13: khamis_robust_loss (utils/loss_functions.py:6-15), the supervised term of the ER modes (adapt.py:339-349)
+# ----------------------------------------------------------------------------------------
+class KhamisLossFn(torch.autograd.Function):
+  """pred, gt (same shape) -> scalar sum_{gt>0}(sqrt((gt-pred)^2+4)/2 - 1) / max(count(gt>0), 1)."""
+
+  @staticmethod
+  def forward(ctx, pred, gt):
+    pred, gt = f32c(pred), f32c(gt)
+    if pred.shape != gt.shape:
+      raise RuntimeError("KhamisLossFn: pred %s and gt %s differ in shape" % (tuple(pred.shape), tuple(gt.shape)))
+    n = pred.numel()
+    out2 = _empty(2, pred.device)
+    ws = _empty(nat.load().as_khamis_workspace(n), pred.device)
+    call("as_khamis_fwd", ptr(pred), ptr(gt), n, ptr(out2), ptr(ws), stream())
+    ctx.save_for_backward(pred, gt, out2)
+    return out2[0].clone()
+
+  @staticmethod
+  def backward(ctx, g):
+    pred, gt, out2 = ctx.saved_tensors
+    if ctx.needs_input_grad[1]:
+      raise NotImplementedError("KhamisLossFn: gradient w.r.t. the ground truth is not part of any path")
+    g = f32c(g).reshape(1)
+    g_pred = torch.empty_like(pred)
+    call("as_khamis_bwd", ptr(pred), ptr(gt), ptr(g), ptr(out2), pred.numel(), ptr(g_pred), stream())
+    return g_pred, None

@@ -1,13 +1,13 @@
 """Loss functions with the reference's signatures (adaptive_stereo/utils/loss_functions.py).
 
 monodepth_loss is one fused HIP stencil kernel forward and two backward (hip_ops.MonodepthLossFn)
-instead of ~20 element-wise/pooling launches.  khamis_robust_loss is a masked reduction used only
-by the experience-replay modes (adapt.py:339-349).
+instead of ~20 element-wise/pooling launches.  khamis_robust_loss is one masked HIP reduction (forward) and one element-wise HIP pass (backward),
+used by the experience-replay modes (adapt.py:339-349) and the supervised multiscale loss.
 """
 import torch
 
 from .. import _native as nat
-from ..hip_ops import MonodepthLossFn
+from ..hip_ops import MonodepthLossFn, KhamisLossFn
 
 
 def monodepth_loss(pred_disp, true_img, warped_img, smoothness_weight=0.001):
@@ -33,12 +33,10 @@ def SSIM(x, y):
 
 
 def khamis_robust_loss(pred_disp, gt_disp):
-  """sum_{gt>0}(sqrt((gt-pred)^2+4)/2 - 1) / max(n,1) (reference :6-15), without a boolean-index sync."""
+  """sum_{gt>0}(sqrt((gt-pred)^2+4)/2 - 1) / max(n,1) (reference :6-15): one HIP reduction pass forward, one
+  element-wise pass backward (hip_ops.KhamisLossFn), no boolean-index sync."""
   nat.require_gpu(pred_disp, gt_disp)
-  mask = (gt_disp > 0).detach()
-  per_pixel = torch.sqrt((gt_disp - pred_disp) ** 2 + 4) / 2 - 1
-  num_valid = mask.sum().clamp(min=1)
-  return (per_pixel * mask).sum() / num_valid
+  return KhamisLossFn.apply(pred_disp, gt_disp.detach())
 
 
 def khamis_robust_loss_multiscale(inputs, outputs, scales=[0], gt_disp_scale=0):

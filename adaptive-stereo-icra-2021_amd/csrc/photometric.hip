@@ -415,3 +415,80 @@ extern "C" int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, flo
   AS_CHECK_LAUNCH("as_masked_sum(finalize)");
   return AS_OK;
 }
+
+// ---- a13: khamis_robust_loss (reference utils/loss_functions.py:6-15; ER modes, adapt.py:339-349) ------------------
+// loss = sum_{gt>0} (sqrt((gt-pred)^2 + 4)/2 - 1) / max(count(gt>0), 1).  One streaming pass, per-element value in fp32
+// exactly as the reference's element-wise chain forms it, fixed-order fp64 two-stage sum (deterministic).
+__global__ __launch_bounds__(256) void khamis_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                          long n, double* __restrict__ partial) {
+  __shared__ double red[2][4];
+  double s = 0.0, c = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = gt[i];
+    if (g > 0.f) {
+      const float d = g - pred[i];
+      const float v = __fsub_rn(__fdiv_rn(__fsqrt_rn(__fadd_rn(__fmul_rn(d, d), 4.f)), 2.f), 1.f);
+      s += (double)v; c += 1.0;
+    }
+  }
+  s = wave_sum_d(s); c = wave_sum_d(c);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ void khamis_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out2) {
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+  s = wave_sum_d(s); c = wave_sum_d(c);
+  if (threadIdx.x == 0) {
+    const double nv = c > 1.0 ? c : 1.0;
+    out2[0] = (float)s / (float)nv;      // the reference divides the fp32 sum by the count, in fp32
+    out2[1] = (float)nv;
+  }
+}
+// g_pred = g_loss * d loss / d pred = -g_loss/count * (gt-pred) / (2 sqrt((gt-pred)^2+4)) where gt>0, else 0
+__global__ __launch_bounds__(256) void khamis_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                          const float* __restrict__ g_loss,
+                                                          const float* __restrict__ out2, long n,
+                                                          float* __restrict__ g_pred) {
+  const float scale = g_loss[0] / out2[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = gt[i];
+    float r = 0.f;
+    if (g > 0.f) {
+      const float d = g - pred[i];
+      r = -scale * d / (2.f * sqrtf(d * d + 4.f));
+    }
+    g_pred[i] = r;
+  }
+}
+
+extern "C" int64_t as_khamis_workspace(int64_t n) { return n > 0 ? 4 * MS_BLOCKS : -1; }
+
+extern "C" int as_khamis_fwd(const float* pred, const float* gt, int64_t n, float* out2, float* workspace, void* stream) {
+  AS_CHECK_ARG(pred && gt && out2 && workspace && n > 0, "as_khamis_fwd: bad argument");
+  AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_khamis_fwd: workspace must be 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  long nb = (n + 255) / 256;
+  if (nb > MS_BLOCKS) nb = MS_BLOCKS;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(khamis_fwd_kernel, dim3((int)nb), dim3(256), 0, st, pred, gt, (long)n, partial);
+  AS_CHECK_LAUNCH("as_khamis_fwd");
+  hipLaunchKernelGGL(khamis_finalize_kernel, dim3(1), dim3(64), 0, st, partial, (int)nb, out2);
+  AS_CHECK_LAUNCH("as_khamis_fwd(finalize)");
+  return AS_OK;
+}
+
+extern "C" int as_khamis_bwd(const float* pred, const float* gt, const float* g_loss, const float* out2, int64_t n,
+                             float* g_pred, void* stream) {
+  AS_CHECK_ARG(pred && gt && g_loss && out2 && g_pred && n > 0, "as_khamis_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(khamis_bwd_kernel, dim3((int)nb), dim3(256), 0, st, pred, gt, g_loss, out2, (long)n, g_pred);
+  AS_CHECK_LAUNCH("as_khamis_bwd");
+  return AS_OK;
+}

@@ -92,29 +92,46 @@ def host_threads():
   return max(1, min(n, int(os.environ.get("AS_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(args, fsd, ssd, budget_s=12.0):
-  """The oracle (a port of the reference's CPU path) on this host's cores; bounded sample:
-  one warm-up then as many repetitions as fit in ~budget_s seconds per mode (at least one)."""
+def cpu_model_string():
+  try:
+    for line in open("/proc/cpuinfo"):
+      if line.lower().startswith("model name"):
+        return line.split(":", 1)[1].strip()
+  except OSError:
+    pass
+  import platform
+  return platform.processor() or platform.machine()
+
+
+def cpu_baseline(args, fsd, ssd, budget_s=10.0):
+  """The oracle (a port of the reference's CPU path) on this host's cores: all threads of the box's CPU share
+  AND one thread; a bounded sample per leg — 3 warm-ups (1 for the one-thread legs, whose single repetition already takes
+  seconds) then as many repetitions as fit in ~budget_s seconds (at least one, at most 10); medians reported."""
   from adaptive_stereo.utils import synthetic as syn
   from oracle import stereo_oracle as orc
-  torch.set_num_threads(host_threads())
   left, right = syn.stereo_pair(1, args.height, args.width, seed=1)
-  fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
-  state = {}
 
-  def sample(fn):
-    fn()                                        # warm-up
-    n, t0 = 0, time.perf_counter()
+  def sample(fn, warmups, budget):
+    for _ in range(warmups):
+      fn()
+    times, t_begin = [], time.perf_counter()
     while True:
-      fn(); n += 1
-      dt = time.perf_counter() - t0
-      if dt >= budget_s or n >= 10:
-        return dt / n, n
+      t0 = time.perf_counter(); fn(); times.append(time.perf_counter() - t0)
+      if time.perf_counter() - t_begin >= budget or len(times) >= 10:
+        times.sort()
+        return times[len(times) // 2], len(times)
 
-  t_adapt, n_adapt = sample(lambda: orc.adapt_step(fp, sp, state, left, right, args.k, 0, args.maxdisp))
-  log("cpu baseline: adapt %.3f s/step (%d reps)" % (t_adapt, n_adapt))
-  t_fwd, n_fwd = sample(lambda: orc.forward_only(fsd, ssd, left, right, args.k, 0, args.maxdisp))
-  log("cpu baseline: forward %.3f s (%d reps)" % (t_fwd, n_fwd))
+  legs = {}
+  for threads, warmups, budget in ((host_threads(), 3, budget_s), (1, 1, budget_s / 2)):
+    torch.set_num_threads(threads)
+    fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
+    state = {}
+    t_adapt, n_adapt = sample(lambda: orc.adapt_step(fp, sp, state, left, right, args.k, 0, args.maxdisp), warmups, budget)
+    t_fwd, n_fwd = sample(lambda: orc.forward_only(fsd, ssd, left, right, args.k, 0, args.maxdisp), warmups, budget)
+    log("cpu baseline, %d thread(s): adapt %.3f s/step (%d reps), forward %.3f s (%d reps)" % (threads, t_adapt, n_adapt,
+                                                                                             t_fwd, n_fwd))
+    legs[threads] = (t_adapt, n_adapt, t_fwd, n_fwd, warmups)
+  torch.set_num_threads(host_threads())
   # parity in the same run (SURVEY 8d): the GPU forward of this pair against the CPU oracle's
   from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
   ref_out, _ = orc.forward_only(fsd, ssd, left, right, args.k, 0, args.maxdisp)
@@ -127,16 +144,28 @@ def cpu_baseline(args, fsd, ssd, budget_s=12.0):
   key = "cost_volume_l/%d" % args.k
   epe = float((out["pred_disp_l/0"].cpu() - ref_out["pred_disp_l/0"]).abs().mean())
   srt = torch.sort(ref_out[key], dim=1, descending=True)[0]
-  decided = (srt[:, 0] - srt[:, 1]) > 2e-5            # pixels whose arg-max the reference itself resolves beyond fp32 noise
+  gap = srt[:, 0] - srt[:, 1]
   am, ref_am = out[key]._as_argmax.cpu().long(), torch.argmax(ref_out[key], dim=1)
-  parity = {"disparity_epe_vs_cpu": epe, "epe_bar": 1e-3, "argmax_equal": bool((am[decided] == ref_am[decided]).all()),
-            "argmax_pixels_compared": int(decided.sum()), "argmax_pixels_total": int(decided.numel())}
-  log("parity: EPE %.2e, arg-max equal on %d of %d pixels: %s" % (epe, parity["argmax_pixels_compared"],
-                                                                 parity["argmax_pixels_total"], parity["argmax_equal"]))
-  return {"value": round(1.0 / t_adapt, 4), "unit": "stereo pairs/s (fwd+adapt-step)", "cores": torch.get_num_threads(),
-          "kind": "port", "fwd_value": round(1.0 / t_fwd, 4), "parity": parity,
-          "sample": "oracle/stereo_oracle.py (PyTorch CPU fp32), batch 1 at %dx%d: 1 warm-up + %d adapt steps, "
-                    "1 warm-up + %d forwards" % (args.width, args.height, n_adapt, n_fwd)}
+  bad = am != ref_am
+  parity = {"disparity_epe_vs_cpu": epe, "epe_bar": 1e-3, "argmax_mismatches": int(bad.sum()),
+            "argmax_pixels": int(bad.numel()), "argmax_equal": not bool(bad.any()),
+            "ref_top2_gap_max_at_mismatch": float(gap[bad].max()) if bool(bad.any()) else 0.0,
+            "ref_top2_gap_min": float(gap.min()),
+            "logit_max_abs_err": float((out[key].cpu() - ref_out[key]).abs().max())}
+  log("parity: EPE %.2e, arg-max mismatches %d of %d pixels (reference's smallest top-2 gap %.2e, largest at a mismatch "
+      "%.2e)" % (epe, parity["argmax_mismatches"], parity["argmax_pixels"], parity["ref_top2_gap_min"],
+                 parity["ref_top2_gap_max_at_mismatch"]))
+  many = host_threads()
+  t_adapt, n_adapt, t_fwd, n_fwd, wu = legs[many]
+  t1_adapt, n1_adapt, t1_fwd, n1_fwd, wu1 = legs[1]
+  return {"value": round(1.0 / t_adapt, 4), "unit": "stereo pairs/s (fwd+adapt-step)", "cores": many,
+          "kind": "port", "fwd_value": round(1.0 / t_fwd, 4),
+          "one_thread": {"value": round(1.0 / t1_adapt, 4), "fwd_value": round(1.0 / t1_fwd, 4), "cores": 1},
+          "cpu_model": cpu_model_string(), "host_cores_visible": os.cpu_count(), "torch": torch.__version__,
+          "parity": parity,
+          "sample": "oracle/stereo_oracle.py (PyTorch CPU fp32), batch 1 at %dx%d, medians: %d threads: %d warm-ups + %d "
+                    "adapt steps, %d warm-ups + %d forwards; 1 thread: %d warm-up + %d adapt step(s), %d warm-up + %d "
+                    "forward(s)" % (args.width, args.height, many, wu, n_adapt, wu, n_fwd, wu1, n1_adapt, wu1, n1_fwd)}
 
 
 def main():

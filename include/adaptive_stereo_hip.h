@@ -290,6 +290,15 @@ int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* 
 int64_t as_masked_sum_workspace(int64_t n);
 int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream);
 
+/* ---- a13: khamis_robust_loss — utils/loss_functions.py:6-15 (ER modes, adapt.py:339-349) -------
+ * out2[0] = sum_{gt>0}(sqrt((gt-pred)^2+4)/2 - 1) / max(count(gt>0),1), out2[1] = max(count,1).
+ * as_khamis_bwd: g_pred = *g_loss * d out2[0] / d pred (g_loss: device scalar; out2 from the forward).
+ * pred, gt: any shape with n elements.  workspace: as_khamis_workspace(n) floats, 8-byte aligned. */
+int64_t as_khamis_workspace(int64_t n);
+int as_khamis_fwd(const float* pred, const float* gt, int64_t n, float* out2, float* workspace, void* stream);
+int as_khamis_bwd(const float* pred, const float* gt, const float* g_loss, const float* out2, int64_t n,
+                  float* g_pred, void* stream);
+
 /* ---- evaluation reductions — train.py:98-106 ------------------------------------
  * out6 = [sum |pred-gt| over gt>0, count(gt>0), count(gt>0 & |err|>2), >3, >4, >5]; EPE = out6[0]/out6[1],
  * D1_all_tpx = out6[t]/out6[1].  pred, gt: any shape with n elements.  workspace: as_eval_metrics_workspace(n). */

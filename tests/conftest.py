@@ -20,6 +20,23 @@ def pytest_configure(config):
   config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+# What the parity tests SAW (not only that they passed): arg-max mismatch counts, EPE, gradient errors ... one line per
+# note at the end of the run (also with -q), so the numbers are in every test log.
+PARITY_NOTES = []
+
+
+def parity_note(test, **numbers):
+  PARITY_NOTES.append((test, numbers))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+  if not PARITY_NOTES:
+    return
+  terminalreporter.write_line("parity numbers seen by this run (%d notes):" % len(PARITY_NOTES))
+  for test, numbers in PARITY_NOTES:
+    terminalreporter.write_line("  parity %s %s" % (test, json.dumps(numbers, sort_keys=True)))
+
+
 class Golden(object):
   """One tests/golden/<case>.npz: arrays produced by the reference itself."""
 

@@ -651,3 +651,42 @@ def test_conv32_lds_skip_from_staged_tile(B, H, W, dil):
   assert torch.equal(out_self, out_copy)
   full = ops.pcl_view(out_self, g).clone(); ops.pcl_interior(full, g).zero_()
   assert float(full.abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- a13
+@pytest.mark.parametrize("shape,invalid", [((1, 1, 17, 33), "some"), ((2, 1, 96, 256), "some"), ((3, 1, 5, 7), "all"),
+                                           ((1, 1, 375, 1242), "none")])
+def test_khamis_robust_loss_fwd_bwd(shape, invalid):
+  """as_khamis_fwd / as_khamis_bwd (reference utils/loss_functions.py:6-15) against the oracle and its autograd:
+  ragged sizes, no valid pixel at all (the reference divides by max(n, 1)) and a full KITTI-size map."""
+  from adaptive_stereo.utils.loss_functions import khamis_robust_loss
+  pred = (rnd(*shape, seed=1) * 30 + 40).requires_grad_(True)
+  gt = rnd(*shape, seed=2) * 30 + 41
+  if invalid == "some":
+    gt[..., ::3, ::5] = 0.0
+    gt[..., 1::4, 2::7] = -3.0             # negative ground truth is invalid too (gt > 0)
+  elif invalid == "all":
+    gt = -gt.abs()
+  ref = orc.khamis_robust_loss(pred, gt)
+  pd = pred.detach().to(DEV).requires_grad_(True)
+  got = khamis_robust_loss(pd, gt.to(DEV))
+  assert got.dim() == 0
+  assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (float(got), float(ref))
+  (got * 0.7).backward()
+  if invalid == "all":
+    assert float(got) == 0.0 and float(pd.grad.abs().max()) == 0.0
+    return
+  (ref * 0.7).backward()
+  close(pd.grad, pred.grad, 1e-9, 2e-6, "khamis g_pred")
+  assert float(pd.grad[gt.to(DEV) <= 0].abs().max() if bool((gt <= 0).any()) else 0.0) == 0.0
+
+
+def test_khamis_robust_loss_matches_reference_fixture(golden_loader):
+  """The reference's own value on the fixture's construction (tests/golden/make_golden.py: gt = pred + 0.5 with a grid
+  of invalid pixels; the value does not depend on pred beyond rounding)."""
+  from adaptive_stereo.utils.loss_functions import khamis_robust_loss
+  gold = golden_loader("crop_96x256_k4_b1")
+  pred = torch.from_numpy(gold.z["full__train/pred_refined"]).to(DEV)
+  gt = (pred + 0.5).clone()
+  gt[:, :, ::3, ::5] = 0.0
+  assert abs(float(khamis_robust_loss(pred, gt)) - gold.scalar("train/khamis")) < 1e-6
