@@ -134,7 +134,7 @@ class OnlineAdapter(object):
 
   def __init__(self, feature_net, stereo_net, height, width, lr=5e-5, clip_grad_norm=True,
                smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None, sync_bn=False,
-               overlap_features=True):
+               overlap_features=True, force_data_parallel=False):
     self.feature_net, self.stereo_net = feature_net, stereo_net
     self.scale = stereo_net.input_scale
     self.coarse_scale = stereo_net.input_scale + stereo_net.k
@@ -147,6 +147,12 @@ class OnlineAdapter(object):
     self.optimizer = FusedClipAdam(self.arena, lr)
     self.pg = process_group
     self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    # dp: the data-parallel step (local loss sums, one all-reduce of [gradients | 4 scalars], 1/N_total after it).  On
+    # with more than one rank; force_data_parallel runs the very same sequence in a process group of ONE rank, which is
+    # how a one-GPU box exercises RCCL's communicator, its stream ordering and the two-graph replay.
+    self.dp = self.world > 1 or bool(force_data_parallel)
+    if self.dp and not (dist.is_available() and dist.is_initialized()):
+      raise RuntimeError("OnlineAdapter(force_data_parallel=True) needs an initialised torch.distributed process group")
     # sync_bn: train-mode BatchNorm over the batches of all ranks (= the reference's single-process batch); default is
     # per-replica statistics, as DistributedDataParallel without SyncBatchNorm.  Eager stepping only.
     self.bn_sync = hip_ops.BnSync(process_group) if (sync_bn and self.world > 1) else None
@@ -157,6 +163,8 @@ class OnlineAdapter(object):
     self.infer_plan = hip_ops.StepPlan()   # same for the eval-mode forward (+ all BatchNorm affines in one launch)
     self._infer_graph = None
     self._side = None                      # second stream for the right image's feature extraction
+    self._capture_origin = None            # handle of the stream a capture opened by capture()/capture_infer() runs on
+    self.fork_fallbacks = 0                # times _features_two_streams declined to fork (foreign or nested capture)
     self.overlap_features = overlap_features
     self.infer_batched_features_max = 1 << 30     # pairs per call up to which inference batches left and right images
 
@@ -200,6 +208,12 @@ class OnlineAdapter(object):
     if not self.overlap_features:
       return self.feature_net(left), self.feature_net(right)
     main = torch.cuda.current_stream()
+    if torch.cuda.is_current_stream_capturing() and main.cuda_stream != self._capture_origin:
+      # A capture this object did not open, or a stream that was itself forked inside one: a fork from an already
+      # forked stream makes hipStreamEndCapture of ROCm 7.2 crash the process (seen once: DESIGN 4).  One stream, the
+      # same kernels in the one-stream order — bit-identical results (test_two_stream_feature_extraction_equals_one_stream).
+      self.fork_fallbacks += 1
+      return self.feature_net(left), self.feature_net(right)
     if self._side is None:
       self._side = torch.cuda.Stream()
     self._side.wait_stream(main)
@@ -213,6 +227,7 @@ class OnlineAdapter(object):
   def capture_infer(self, left, right, warmup=2):
     """Captures the eval-mode forward (~75 launches) into a hipGraph; infer() replays it from then on.  The graph
     reads the weights where they live (the flat arena), so it stays valid across adaptation steps."""
+    self._refuse_nested_capture("capture_infer")
     pair = torch.cat([left, right])                      # one buffer: the two images are its halves, so the batched
     self._infer_left, self._infer_right = pair[:left.shape[0]], pair[left.shape[0]:]   # feature pass needs no copy
     side = torch.cuda.Stream()
@@ -223,8 +238,12 @@ class OnlineAdapter(object):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):   # same stream as the warm-up: the
-      self._infer_result = self._infer_eager(self._infer_left, self._infer_right)     # buffer pool is per stream
+    self._capture_origin = side.cuda_stream
+    try:
+      with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):   # same stream as the warm-up: the
+        self._infer_result = self._infer_eager(self._infer_left, self._infer_right)     # buffer pool is per stream
+    finally:
+      self._capture_origin = None
     self._infer_graph = graph
     return self
 
@@ -256,7 +275,7 @@ class OnlineAdapter(object):
     try:
       total, mask, fcs_map, out, warped = self._forward_maps(left, right)
 
-      if self.world == 1:
+      if not self.dp:
         loss = masked_mean(total, mask)
         fcs = fcs_map.mean()
         loss.backward()
@@ -280,7 +299,12 @@ class OnlineAdapter(object):
   def forward_loss(self, left, right, train=True, replay=None, er_loss_weight=0.05):
     """Forward + losses (+ FCS EMA).  With train=False the networks run in eval mode without gradients
     (State.DONE, adapt.py:309-311).  ``replay`` = (left, right, gt) adds the experience-replay Khamis
-    term (adapt.py:339-349)."""
+    term (adapt.py:339-349).
+
+    Data parallel: the reported loss, replay loss and FCS are those of the WHOLE batch (all ranks' pairs), from one
+    24-byte all-reduce of [valid count, loss sum, FCS sum, FCS count, replay gt count, replay loss sum] — the OOD gate
+    and the state machine must decide identically on every rank, and the reference's loss is the masked mean over the
+    valid pixels of the whole batch (adapt.py:83), not a mean of per-rank means."""
     from .utils.loss_functions import khamis_robust_loss
     self.feature_net.train(train); self.stereo_net.train(train)
     if train:
@@ -315,33 +339,60 @@ class OnlineAdapter(object):
       hip_ops.set_bn_sync(prev_sync)
       if train:
         self.plan.end(final=False)
-    fcs = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)]).mean()
-    if self.world > 1:
-      # the OOD gate and the state machine must take the same decision on every rank: gate on the mean
-      fcs = fcs.clone()
-      dist.all_reduce(fcs, op=dist.ReduceOp.SUM, group=self.pg)
-      fcs /= self.world
+    fcs_map = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
+    fcs = fcs_map.mean()
+    dp_terms = None
+    if self.dp:
+      m8 = self._dp_local_sums(total, mask, fcs_map)        # this rank's [count, loss sum, FCS sum, FCS count]
+      six = torch.zeros(6, dtype=torch.float32, device=total.device)
+      six[:4] = self.scalars
+      if replay_loss is not None:
+        n_gt = (replay[2] > 0).sum().to(torch.float32).clamp(min=1.0)
+        six[4] = n_gt; six[5] = replay_loss.detach() * n_gt
+      dist.all_reduce(six, op=dist.ReduceOp.SUM, group=self.pg)
+      loss = six[1] / six[0]
+      fcs = six[2] / six[3]
+      if replay_loss is not None:
+        # whole-batch Khamis loss = (sum over ranks of the local sums) / (count over ranks); the gradient arena is
+        # divided by the valid-pixel count N after its all-reduce, so this rank back-propagates
+        # sum_r(monodepth) + w * (N / M) * sum_r(khamis) = ... + w * (N / M) * n_r * khamis_r
+        dp_terms = (total, m8, replay_loss, er_loss_weight * six[0] / six[4] * n_gt, six[0])
+        replay_loss = six[5] / six[4]
+      else:
+        dp_terms = (total, m8, None, None, six[0])
     if self.fcs_smoothed is None:
       self.fcs_smoothed = fcs.detach().clone()
     else:
       self.fcs_smoothed.mul_(self.fcs_ema_weight).add_(fcs.detach(), alpha=1.0 - self.fcs_ema_weight)
     out["left_warped/{}".format(self.scale)] = warped
     return {"loss": loss.detach(), "replay_loss": None if replay_loss is None else replay_loss.detach(),
-            "backprop_loss": backprop, "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
+            "backprop_loss": backprop, "dp_terms": dp_terms, "fcs": fcs, "fcs_smoothed": self.fcs_smoothed,
+            "outputs": out}
 
   def backward_update(self, result):
-    """backward + clip + Adam for a result of forward_loss(train=True) (adapt.py:381-394)."""
+    """backward + clip + Adam for a result of forward_loss(train=True) (adapt.py:381-394).  Data parallel: every rank
+    back-propagates its local loss SUM (backward is linear in the incoming gradient), ONE all-reduce sums the gradient
+    arena, and the division by the whole batch's valid-pixel count follows it — the same whole-batch masked mean that
+    step() implements (_distributed_backward), not a mean of per-rank means."""
     self.plan.begin(resume=True)  # backward re-packs the (unchanged) weights: one launch
     prev_sync = hip_ops.set_bn_sync(self.bn_sync)
     hip_ops.rmw_order_reset(self.bn_sync is None)
     try:
-      result["backprop_loss"].backward()
+      if self.dp:
+        total, m8, replay_loss, replay_coef, n_total = result["dp_terms"]
+        if replay_loss is None:
+          total.backward(m8.to(torch.float32))
+        else:
+          torch.autograd.backward([total, replay_loss], [m8.to(torch.float32), replay_coef.reshape(replay_loss.shape)])
+      else:
+        result["backprop_loss"].backward()
     finally:
       hip_ops.rmw_order_reset(False)
       hip_ops.set_bn_sync(prev_sync)
       self.plan.end()
-    if self.world > 1:
-      allreduce_gradients(self.arena.grads.div_(self.world), self.pg)
+    if self.dp:
+      allreduce_gradients_and_scalars(self.arena, self.pg)     # the same single message step() sends
+      self.arena.grads.div_(n_total)
     self.optimizer.step(clip=self.clip)
 
   @torch.no_grad()
@@ -353,7 +404,20 @@ class OnlineAdapter(object):
     out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     pred = out["pred_disp_l/{}".format(self.scale)]
     warped, mask = self.warper(right, pred, right_to_left=True)
-    loss = masked_mean(monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0], mask)
+    total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+    if self.dp:
+      # every rank scores its own buffered pair; the state machine must see ONE number on all ranks: the masked mean
+      # over the pairs of all ranks (buffers fill in lock-step: the OOD gate is decided on all-reduced scalars)
+      m8 = mask.to(torch.uint8).contiguous()
+      n = total.numel()
+      ws = torch.empty(nat.load().as_masked_sum_workspace(n), dtype=torch.float32, device=total.device)
+      two = torch.empty(2, dtype=torch.float32, device=total.device)
+      tc = total.contiguous()
+      nat.call("as_masked_sum", nat.ptr(tc), nat.ptr(m8), n, nat.ptr(two), nat.ptr(ws), nat.stream())
+      dist.all_reduce(two, op=dist.ReduceOp.SUM, group=self.pg)
+      loss = two[0] / two[1]
+    else:
+      loss = masked_mean(total, mask)
     self.feature_net.train(was_f); self.stereo_net.train(was_s)
     return float(loss)
 
@@ -370,6 +434,7 @@ class OnlineAdapter(object):
     if self.bn_sync is not None:
       raise RuntimeError("OnlineAdapter.capture: cross-replica BatchNorm puts collectives inside forward and backward; "
                          "a step cannot be captured with sync_bn=True (step() runs eagerly)")
+    self._refuse_nested_capture("capture")
     self._static_left, self._static_right = left.clone(), right.clone()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -379,7 +444,25 @@ class OnlineAdapter(object):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     self.optimizer.step_count_at_capture = self.optimizer.step_count
-    if self.world == 1:
+    self._capture_origin = side.cuda_stream
+    try:
+      self._capture_graphs(side)
+    finally:
+      self._capture_origin = None
+    # capture only records: the python-side counter advanced, the device-side one did not
+    self.optimizer.step_count = self.optimizer.step_count_at_capture
+    return self
+
+  def _refuse_nested_capture(self, what):
+    if torch.cuda.is_current_stream_capturing():
+      raise RuntimeError("OnlineAdapter.%s: the current stream is already being captured; a capture inside a capture "
+                         "(and the stream fork it implies) crashes hipStreamEndCapture on ROCm 7.2 — capture from an "
+                         "ordinary stream, or call step()/infer() inside your own capture (they then run the "
+                         "one-stream order)" % what)
+
+  def _capture_graphs(self, side):
+    left, right = self._static_left, self._static_right
+    if not self.dp:
       graph = torch.cuda.CUDAGraph()
       with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):   # the warm-up's stream: its
         self._static_result = self._step_eager(self._static_left, self._static_right)   # pooled buffers are reused
@@ -412,9 +495,6 @@ class OnlineAdapter(object):
         out["left_warped/{}".format(self.scale)] = warped
         self._static_result = {"loss": loss.detach(), "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
       self._graph = (g1, g2)
-    # capture only records: the python-side counter advanced, the device-side one did not
-    self.optimizer.step_count = self.optimizer.step_count_at_capture
-    return self
 
   def graph_inputs(self):
     """The captured step's own input buffers (after capture()): a producer that decodes or copies the next pair
@@ -430,7 +510,7 @@ class OnlineAdapter(object):
       self._static_left.copy_(left)
     if right.data_ptr() != self._static_right.data_ptr():
       self._static_right.copy_(right)
-    if self.world == 1:
+    if not self.dp:
       self._graph.replay()
     else:
       g1, g2 = self._graph

@@ -6,9 +6,15 @@ flip, crop, F.interpolate pyramid.  Parity is pinned by construction here (the r
 imported in this container: torchvision, imageio and cv2 are absent): every step is one documented library call —
 ToTensor = uint8/255, imageio/cv2 PNG decode = the stored integers, PFM = big/little-endian float32 rows bottom-up.
 
-PARITY UNPINNED: the reference holds no fixtures or tests for its dataset layer and its module cannot run here, so
-this restatement is checked against nothing but its own reading of the reference source (unlike
-oracle/stereo_oracle.py, which is pinned by fixtures generated from the reference)."""
+PARITY: PINNED for exactly two parts, UNPINNED for the rest.
+  * pinned — ``pfm`` / the SceneFlow branch of ``load_disp``: tests/test_dataset_cpu.py runs them on the reference's own
+    sample (resources/0008.pfm, copied as tests/golden/dataset/0008.pfm) against the output of the reference's readPFM
+    (utils/io.py:37-80, imported from /root/reference by tests/golden/make_dataset_golden.py), bit for bit;
+  * pinned — manifest handling (one sample per line, four paths per line): the data set lengths the reference's own test
+    asserts (test/test_stereo_dataset.py:24-97) re-counted from the reference's manifests, tests/golden/dataset/;
+  * unpinned — crop / flip / pyramid / PNG and NPY decoders: the reference's dataset module cannot be imported here
+    (torchvision, imageio, cv2 are absent) and the reference holds no fixtures for them, so those functions rest on
+    this file's reading of the reference source alone."""
 import re
 
 import numpy as np

@@ -106,3 +106,71 @@ def test_prefetcher_batching_logic_without_a_gpu():
     device = None
   with pytest.raises(ValueError):
     DevicePrefetcher(Host(), 2)
+
+
+# ---- pinned against what the reference itself holds (tests/golden/make_dataset_golden.py) ----------------------------
+PIN = os.path.join(REPO, "tests", "golden", "dataset")
+
+
+def _pfm_expected():
+  return np.load(os.path.join(PIN, "pfm_0008_expected.npz"))
+
+
+def check_against_reference_pfm(img, scale):
+  """img: what a reader returned for tests/golden/dataset/0008.pfm; expected: the reference's readPFM output."""
+  exp = _pfm_expected()
+  assert tuple(img.shape) == tuple(int(v) for v in exp["shape"]) == (540, 960) and img.dtype == np.float32
+  assert float(scale) == float(exp["scale"])
+  d = img.astype(np.float64)
+  assert d.sum() == float(exp["sum"]) and (d * d).sum() == float(exp["sumsq"])       # same samples: exact sums
+  assert np.array_equal(img[0], exp["first_row"]) and np.array_equal(img[-1], exp["last_row"])     # top row first
+  assert np.array_equal(img.reshape(-1)[::int(exp["sub_stride"])], exp["sub"])
+  assert float(img.min()) == float(exp["min"]) and float(img.max()) == float(exp["max"])
+
+
+def test_pfm_reader_matches_the_reference_reader_on_its_own_sample():
+  """resources/0008.pfm of the reference (a real 960x540 SceneFlow disparity) through the product's reader and through
+  the dataset oracle: both must return, bit for bit, what the reference's readPFM returned (utils/io.py:37-80)."""
+  path = os.path.join(PIN, "0008.pfm")
+  img, scale = as_io.read_pfm(path)
+  check_against_reference_pfm(np.ascontiguousarray(img), scale)
+  check_against_reference_pfm(as_io.read_pfm_tensor(path).numpy(), scale)
+  check_against_reference_pfm(np.ascontiguousarray(dorc.pfm(path)), 1.0)
+  raw, _ = as_io.read_pfm_raw(path)
+  assert np.array_equal(np.flipud(raw), img)
+  # the SceneFlow decoder of the dataset layer returns it as [1,H,W] (utils/dataset_utils.py:26-27)
+  from adaptive_stereo.utils.dataset_utils import get_disp_loader
+  t = get_disp_loader("SceneFlowFlying")(path)
+  assert tuple(t.shape) == (1, 540, 960)
+  check_against_reference_pfm(t[0].numpy(), scale)
+  assert torch.equal(dorc.load_disp("SceneFlowFlying", path), t)
+
+
+def test_split_lengths_asserted_by_the_reference_test():
+  """test/test_stereo_dataset.py:24-97 of the reference asserts the data set lengths; the KITTI-2015 manifests (the
+  benchmark's data set) are committed as fixture data, the others are re-counted from /root/reference where it exists
+  and otherwise checked against the counts recorded (with the manifests' sha256) when the fixture was made."""
+  import hashlib
+  import json
+  rec = json.load(open(os.path.join(PIN, "split_lengths.json")))
+  rows = {(r["split"], r["subsplit"]): r for r in rec["rows"]}
+  assert {k: r["expected_by_reference_test"] for k, r in rows.items()} == {
+      ("sceneflow_driving", "train"): 1540, ("sceneflow_driving", "val"): 330, ("sceneflow_driving", "test"): 330,
+      ("sceneflow_flying", "train"): 19031, ("sceneflow_flying", "val"): 3359, ("sceneflow_flying", "test"): 4370,
+      ("kitti_stereo_2012", "train"): 194, ("kitti_stereo_2012", "val"): 194, ("kitti_stereo_2012", "test"): 194,
+      ("kitti_stereo_2015", "train"): 200, ("kitti_stereo_2015", "val"): 200, ("kitti_stereo_2015", "test"): 200}
+  assert all(r["counted_by_product"] == r["expected_by_reference_test"] for r in rows.values())
+  local = os.path.join(PIN, "splits")
+  for sub in ("train", "val", "test"):
+    d = StereoDataset("/nonexistent", "KittiStereo2015", "kitti_stereo_2015", 320, 960, sub, scales=[0],
+                      do_hflip=False, random_crop=False, splits_path=local)
+    assert len(d) == 200
+    path = os.path.join(local, "kitti_stereo_2015", "%s_lines.txt" % sub)
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == rows[("kitti_stereo_2015", sub)]["sha256"]
+    first = d._paths(0)
+    assert len(first) == 4 and first[0].endswith("image_2/000000_10.png") and first[1].endswith("image_3/000000_10.png")
+  ref_splits = "/root/reference/splits"
+  if os.path.isdir(ref_splits):
+    for (split, sub), r in rows.items():
+      d = StereoDataset("/nonexistent", r["dataset"], split, 320, 960, sub, scales=[0], splits_path=ref_splits)
+      assert len(d) == r["expected_by_reference_test"], (split, sub, len(d))

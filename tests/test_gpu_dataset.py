@@ -3,6 +3,8 @@ the oracle: same random decisions, same sample dictionary, on the GPU."""
 import os
 import random
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -138,3 +140,36 @@ def test_prefetched_stream_drives_the_adaptation_step(tmp_path):
   a = run(direct)
   b = run(DevicePrefetcher(ds, batch_size=1, num_threads=2))
   assert a == b and all(x == x and 0.0 < x < 10.0 for x in a), (a, b)
+
+
+def test_device_decoder_on_the_reference_sample_pfm(tmp_path):
+  """The reference's own sample (resources/0008.pfm, 960x540 SceneFlow disparity) through the DEVICE path — raw samples
+  uploaded bottom row first, flipped / cropped / mirrored by as_decode_plane — against the reference's readPFM output
+  stored in tests/golden/dataset/pfm_0008_expected.npz (bit for bit: the decoder only moves float32 samples)."""
+  import shutil
+  from PIL import Image
+  from conftest import REPO
+  pin = os.path.join(REPO, "tests", "golden", "dataset")
+  exp = np.load(os.path.join(pin, "pfm_0008_expected.npz"))
+  data = str(tmp_path / "data"); os.makedirs(data)
+  for name in ("l.png", "r.png"):
+    Image.fromarray(np.random.RandomState(3).randint(0, 256, size=(540, 960, 3)).astype(np.uint8)).save(os.path.join(data, name))
+  shutil.copyfile(os.path.join(pin, "0008.pfm"), os.path.join(data, "d.pfm"))
+  splits = str(tmp_path / "splits" / "one"); os.makedirs(splits)
+  with open(os.path.join(splits, "train_lines.txt"), "w") as f:
+    f.write("l.png r.png d.pfm d.pfm\n")
+  ds = StereoDataset(data, "SceneFlowFlying", "one", 540, 960, "train", scales=[0], splits_path=str(tmp_path / "splits"),
+                     device="cuda")
+  full = ds[0]["gt_disp_l/0"].cpu().numpy()[0]
+  assert full.shape == (540, 960)
+  assert np.array_equal(full[0], exp["first_row"]) and np.array_equal(full[-1], exp["last_row"])
+  assert np.array_equal(full.reshape(-1)[::int(exp["sub_stride"])], exp["sub"])
+  d = full.astype(np.float64)
+  assert d.sum() == float(exp["sum"]) and (d * d).sum() == float(exp["sumsq"])
+  # centre crop to the reference's training size (320x960) and a mirrored, swapped pair: rows/columns of the same image
+  crop = StereoDataset(data, "SceneFlowFlying", "one", 320, 960, "train", scales=[0], splits_path=str(tmp_path / "splits"),
+                       device="cuda")
+  assert np.array_equal(crop[0]["gt_disp_l/0"].cpu().numpy()[0], full[110:430])
+  raw = crop.parse(0)
+  mirrored = crop.decode(raw, 110, 0, True)["gt_disp_l/0"].cpu().numpy()[0]
+  assert np.array_equal(mirrored, full[110:430, ::-1])

@@ -240,3 +240,161 @@ def test_two_rank_sync_batchnorm_equals_the_whole_batch_step(tmp_path):
       if key.endswith(("running_mean", "running_var")):
         b = got["buffers"]["%s.%s" % (net_name, key)]
         assert float((b - ref_t.detach()).abs().max()) <= 2e-5 + 1e-3 * float(ref_t.detach().abs().max()), key
+
+
+def _loop_worker(rank, world, port, out_path):
+  """control.AdaptationLoop under data parallelism (VS mode): batch 0 is novel -> every rank routes its pairs into its
+  reservoir and nobody updates; batch 1 is not novel -> OVS validation (one number on all ranks), then forward_loss +
+  backward_update.  That update must equal, bit for bit, OnlineAdapter.step() on batch 1 (the whole-batch masked mean,
+  adapt.py:83) — the two entry points share every kernel and differ only in where the all-reduce sits."""
+  import random
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  random.seed(123)                                   # adapt.py:28: the reservoir's decisions are rank-identical
+  from adaptive_stereo.adaptation import OnlineAdapter
+  from adaptive_stereo.control import AdaptationLoop, State
+  from adaptive_stereo.utils import synthetic as syn
+  _, _, fsd, ssd, left, right = _states()
+  left1, right1 = syn.stereo_pair(4, H, W, seed=10, disparities=(5.0, 2.0, 7.0, 4.0))
+  lo = rank * 2
+  b0 = (left[lo:lo + 2].cuda(), right[lo:lo + 2].cuda())
+  b1 = (left1[lo:lo + 2].cuda(), right1[lo:lo + 2].cuda())
+
+  def fresh():
+    fnet, snet, _, _, _, _ = _states()
+    fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+    return OnlineAdapter(fnet.cuda(), snet.cuda(), H, W, lr=5e-5)
+
+  loop = AdaptationLoop(fresh(), mode="VS", ovs_buffer_size=4, ovs_validate_hz=1, val_improve_retries=2,
+                        ood_threshold=1e9)
+  r0 = loop.process(b0[0], b0[1], 0)
+  assert r0["added_to_ovs"] and not r0["updated"] and loop.state_machine.ovs_buffer_size() == 1
+  before = loop.adapter.arena.params.clone()
+  loop.ood_threshold = -1e9
+  r1 = loop.process(b1[0], b1[1], 1)                 # validates the OVS first (ovs_validate_hz=1), then updates
+  torch.cuda.synchronize()
+  assert r1["updated"] and not r1["added_to_ovs"] and r1["state"] == State.IN_PROGRESS
+  assert not torch.equal(before, loop.adapter.arena.params)
+  ovs_value = float(loop.state_machine.ovs.buf[0][0])
+
+  plain = fresh()
+  ref = plain.step(b1[0], b1[1])
+  torch.cuda.synchronize()
+  same = bool(torch.equal(plain.arena.params, loop.adapter.arena.params))
+  vals = torch.tensor([ovs_value, float(r1["loss"]), float(ref["loss"]), float(r1["fcs"]), float(ref["fcs"])], dtype=torch.float64)
+  gathered = [torch.zeros_like(vals) for _ in range(world)]
+  dist.all_gather(gathered, vals)
+  params = loop.adapter.arena.params.detach().cpu()
+  gp = [torch.zeros_like(params) for _ in range(world)]
+  dist.all_gather(gp, params)
+  if rank == 0:
+    torch.save({"same_as_step": same, "vals": [g.tolist() for g in gathered], "ranks_equal": bool(torch.equal(gp[0], gp[1])),
+                "grad_norm": float(loop.adapter.optimizer.grad_norm()), "max_diff": float((plain.arena.params - loop.adapter.arena.params).abs().max())},
+               out_path)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_adaptation_loop_uses_the_whole_batch_mean(tmp_path):
+  from oracle import stereo_oracle as orc
+  from adaptive_stereo.utils import synthetic as syn
+  out_path = str(tmp_path / "dp_loop.pt")
+  mp.spawn(_loop_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+  got = torch.load(out_path)
+  assert got["ranks_equal"], "ranks diverged"
+  assert got["same_as_step"], "forward_loss + backward_update differs from step(): max |dw| %.3e" % got["max_diff"]
+  v0, v1 = got["vals"]
+  assert v0 == v1, "ranks report different OVS value / loss / FCS: %s vs %s" % (v0, v1)
+  assert v0[1] == v0[2] and v0[3] == v0[4], v0          # loop's loss and FCS == step()'s
+
+  # the whole-batch masked mean of the oracle (per-replica BatchNorm statistics, DESIGN 5) on batch 1
+  _, _, fsd, ssd, _, _ = _states()
+  left, right = syn.stereo_pair(4, H, W, seed=10, disparities=(5.0, 2.0, 7.0, 4.0))
+  fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
+  totals, masks = [], []
+  for r in range(2):
+    fpr, spr = dict(fp), dict(sp)
+    for d in (fpr, spr):
+      for k in list(d.keys()):
+        if orc.is_buffer_key(k):
+          d[k] = d[k].clone()
+    l, rr = left[2 * r:2 * r + 2], right[2 * r:2 * r + 2]
+    fl, fr = orc.feature_extractor(fpr, l, K, True), orc.feature_extractor(fpr, rr, K, True)
+    out = orc.stereo_forward(spr, l, fl, fr, K, 0, MAXDISP, "l", True, True)
+    warped, mask = orc.linear_warp(rr, out["pred_disp_l/0"], True)
+    totals.append(orc.monodepth_loss(out["pred_disp_l/0"], l, warped, 1e-3)[0]); masks.append(mask)
+  loss = sum((t * m).sum() for t, m in zip(totals, masks)) / sum(float(m.sum()) for m in masks)
+  loss.backward()
+  gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for k, p in sp.items() if p.requires_grad and p.grad is not None)))
+  assert abs(v0[1] - float(loss)) < 2e-5, (v0[1], float(loss))
+  assert abs(got["grad_norm"] - gnorm) <= 1e-2 * gnorm, (got["grad_norm"], gnorm)
+
+
+def _rccl_worker(rank, world, port, out_path):
+  """ONE rank, backend "nccl" (= RCCL) on cuda:0: communicator init with device_id (as bench.py does), the step's single
+  all-reduce on the compute stream, and the two-graph replay with the collective issued between the graphs."""
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+  from adaptive_stereo.adaptation import OnlineAdapter, allreduce_gradients_and_scalars
+  from adaptive_stereo.utils import synthetic as syn
+  batches = [syn.stereo_pair(2, H, W, seed=s, disparities=(3.0, 6.0)) for s in (31, 32, 33, 34)]
+  batches = [(l.cuda(), r.cuda()) for l, r in batches]
+
+  def fresh(**kw):
+    fnet, snet, fsd, ssd, _, _ = _states()
+    fnet.load_state_dict(fsd); snet.load_state_dict(ssd)
+    return OnlineAdapter(fnet.cuda(), snet.cuda(), H, W, lr=5e-5, **kw)
+
+  # the collective itself: over one rank the sum is the identity, bit for bit, and it is ordered on the current stream
+  probe = fresh(force_data_parallel=True)
+  probe.arena.grads_and_scalars.copy_(torch.arange(probe.arena.numel + 4, dtype=torch.float32, device="cuda") * 1e-3)
+  before = probe.arena.grads_and_scalars.clone()
+  allreduce_gradients_and_scalars(probe.arena)
+  torch.cuda.synchronize()
+  identity = bool(torch.equal(before, probe.arena.grads_and_scalars))
+
+  results = {}
+  for mode in ("single", "dp_eager", "dp_graph"):
+    adapter = fresh(force_data_parallel=(mode != "single"))
+    assert adapter.dp == (mode != "single") and adapter.world == 1
+    adapter.step(*batches[0])
+    if mode == "dp_graph":
+      adapter.capture(*batches[0], warmup=1)
+      assert isinstance(adapter._graph, tuple) and len(adapter._graph) == 2      # two graphs, the all-reduce between
+    else:
+      adapter.step(*batches[0])
+    losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]          # three (replayed) steps
+    torch.cuda.synchronize()
+    results[mode] = (losses, adapter.arena.params.detach().cpu().clone(), adapter.optimizer.step_count,
+                     float(adapter.optimizer.step_dev))
+  torch.save({"identity": identity, "results": results}, out_path)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_rccl_single_rank_allreduce_and_two_graph_replay(tmp_path):
+  """RCCL on the one GPU this box has: a one-rank "nccl" process group drives the data-parallel step — eagerly and as two
+  replayed hipGraphs with the all-reduce between them.  Graph replay must equal eager data-parallel stepping bit for
+  bit; both must agree with the ordinary single-GPU step to rounding (the data-parallel step divides the summed
+  gradient by the valid-pixel count after the all-reduce, the single-GPU step scales the incoming gradient before
+  backward: the same real number, rounded at a different place)."""
+  out_path = str(tmp_path / "rccl1.pt")
+  mp.spawn(_rccl_worker, args=(1, _free_port(), out_path), nprocs=1, join=True)
+  got = torch.load(out_path)
+  assert got["identity"], "a one-rank RCCL all-reduce must leave the buffer unchanged"
+  (ls, ps, cs, ds), (le, pe, ce, de), (lg, pg_, cg, dg) = (got["results"][m] for m in ("single", "dp_eager", "dp_graph"))
+  assert (ce, de) == (cg, dg) == (5, 5.0) and (cs, ds) == (5, 5.0)
+  assert le == lg, (le, lg)
+  assert torch.equal(pe, pg_), float((pe - pg_).abs().max())
+  assert all(abs(a - b) <= 1e-6 * max(1.0, abs(a)) for a, b in zip(ls, le)), (ls, le)
+  # five Adam steps at lr 5e-5: identical up to sign flips of noise-level gradients (2 lr each)
+  assert float((ps - pe).abs().max()) <= 5 * 2.1 * 5e-5
+  assert float((ps - pe).abs().mean()) <= 0.05 * 5e-5          # ... and those are rare

@@ -583,3 +583,44 @@ def test_inference_plan_and_graph_equal_plain_forward():
   assert torch.equal(out["pred_disp_l/0"], new_pred) and torch.equal(out["cost_volume_l/4"], new_logits)
   stale_pred, _ = ref_pred, None
   assert not torch.equal(plain(l1, r1)[0], stale_pred), "the adaptation step should have changed the network"
+
+
+def test_capture_refuses_nesting_and_foreign_captures_run_one_stream():
+  """A fork from an already forked stream inside a capture makes hipStreamEndCapture of ROCm 7.2 crash the process
+  (recorded once: DESIGN 4).  Two guards: capture() / capture_infer() raise when the current stream is already being
+  captured, and inside a capture this object did not open — here on a stream that was itself forked from the capture's
+  origin — the two feature extractions run in the one-stream order instead of forking again.  The captured graph must
+  still reproduce the eager forward bit for bit."""
+  meta = dict(k=4, s=0, maxdisp=192, gain=5.0)
+  H, W, B = 96, 256, 2
+  fnet, snet = build(meta)
+  adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+  adapter.infer_batched_features_max = 0               # force the two-stream feature path in inference
+  l, r = (t.to(DEV) for t in syn.stereo_pair(B, H, W, seed=71))
+  ref, _ = adapter._infer_eager(l, r)
+  ref_pred = ref["pred_disp_l/0"].clone()
+  assert adapter.fork_fallbacks == 0                   # eager: forked onto the side stream as usual
+  origin, forked = torch.cuda.Stream(), torch.cuda.Stream()
+  with torch.cuda.stream(forked):
+    for _ in range(2):
+      adapter._infer_eager(l, r)                       # warm the per-stream buffer pool outside the capture
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, stream=origin, capture_error_mode="thread_local"):
+    with pytest.raises(RuntimeError, match="already being captured"):
+      adapter.capture_infer(l, r)
+    with pytest.raises(RuntimeError, match="already being captured"):
+      adapter.capture(l, r)
+    forked.wait_stream(origin)
+    with torch.cuda.stream(forked):                    # a stream forked inside somebody else's capture
+      out, _ = adapter._infer_eager(l, r)
+    origin.wait_stream(forked)
+  assert adapter.fork_fallbacks == 1
+  out["pred_disp_l/0"].zero_()
+  graph.replay()
+  torch.cuda.synchronize()
+  assert torch.equal(out["pred_disp_l/0"], ref_pred)
+  # and the object's own captures still fork (two parallel branches) and still work
+  adapter.capture_infer(l, r)
+  got, _ = adapter.infer(l, r)
+  assert adapter.fork_fallbacks == 1 and torch.equal(got["pred_disp_l/0"], ref_pred)
