@@ -38,6 +38,14 @@ class ConvShape(ctypes.Structure):
     return self.kd * self.kh * self.kw
 
 
+class BnMerge(ctypes.Structure):
+  """as_bn_merge: a layer's BatchNorm still in per-workgroup partials + where its finalized state goes; the consumer
+  kernel (as_agg3d_fwd / as_agg_tail_fwd) merges them itself."""
+  _fields_ = [(n, c_vp) for n in ("stat_mean", "stat_m2", "stat_cnt", "gamma", "beta", "running_mean", "running_var",
+                                 "save_mean", "save_invstd", "scale", "shift")] + \
+             [("nparts", ctypes.c_int32), ("momentum", c_float), ("eps", c_float)]
+
+
 _P = ctypes.POINTER
 _SIGNATURES = {
   # name: (restype, [argtypes])
@@ -76,6 +84,12 @@ _SIGNATURES = {
   "as_conv32_bnbwd_parts": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_fwd_bnbwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float,
                                   c_vp, c_vp]),
+  "as_agg3d_ok": (c_int, [_P(Pcl)]),
+  "as_agg3d_parts": (c_int, [_P(Pcl)]),
+  "as_agg3d_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, _P(BnMerge), c_vp, c_vp, c_int, c_vp, c_vp, c_float, c_vp, c_vp,
+                           c_vp, c_vp]),
+  "as_agg_tail_ok": (c_int, [_P(Pcl)]),
+  "as_agg_tail_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(BnMerge), c_vp, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_conv3d_out_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp]),
   "as_conv3d_out_bwd_workspace": (c_i64, [_P(Pcl)]),
   "as_conv3d_out_bwd": (c_int, [c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),

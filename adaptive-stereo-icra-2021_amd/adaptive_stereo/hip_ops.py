@@ -575,6 +575,74 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
 
 
 # ----------------------------------------------------------------------------------------
+# a3, second generation (csrc/agg3d.hip): rolling-window 3-D aggregation layer with the previous layer's BatchNorm +
+# LeakyReLU applied to the operand in LDS, that BatchNorm merged from the previous launch's partials by the consumer
+# ----------------------------------------------------------------------------------------
+_AGG3D = True            # False: the first-generation path (conv3d_lds + finalize + element-wise pass per layer)
+_AGG_TAIL = True         # False: conv3d_alone and the soft-argmax as two launches (conv32to1_fwd + softargmax_fwd)
+
+
+def set_agg3d(flag: bool):
+  """Switches the cost-aggregation forward between the rolling-window kernels and the first-generation path
+  (A/B measurements and parity tests); returns the previous setting."""
+  global _AGG3D
+  prev, _AGG3D = _AGG3D, bool(flag)
+  return prev
+
+
+def set_agg_tail(flag: bool):
+  global _AGG_TAIL
+  prev, _AGG_TAIL = _AGG_TAIL, bool(flag)
+  return prev
+
+
+def agg3d_ok(g: Pcl):
+  return _AGG3D and nat.load().as_agg3d_ok(g) == 1
+
+
+class PendingBn(object):
+  """A train-mode BatchNorm whose statistics are still per-workgroup partials (written by the producing convolution):
+  the kernel that consumes the layer's output merges them itself (csrc/bn_merge.h) and writes ``state`` (a BnState: the
+  backward pass reads it) and the running statistics.  Keeps every tensor it points to alive."""
+
+  def __init__(self, stats: StatParts, gamma, beta, running_mean, running_var):
+    self.stats, self.gamma, self.beta, self.rm, self.rv = stats, gamma, beta, running_mean, running_var
+    self.state = BnState(gamma.device)
+    st = self.state
+    self.block = nat.BnMerge(ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), ptr(gamma), ptr(beta), ptr(running_mean),
+                             ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stats.nparts,
+                             BN_MOMENTUM, BN_EPS)
+
+  def finalize(self):
+    """The same result through the stand-alone finalize launch (no fused consumer available)."""
+    _rmw_wait(self.rm)
+    st = self.state
+    call("as_bn_finalize", ptr(self.stats.mean), ptr(self.stats.m2), ptr(self.stats.cnt), self.stats.nparts, ptr(self.gamma),
+         ptr(self.beta), ptr(self.rm), ptr(self.rv), BN_MOMENTUM, BN_EPS, ptr(st.mean), ptr(st.invstd), ptr(st.scale),
+         ptr(st.shift), stream())
+    _rmw_done(self.rm)
+    return st
+
+
+def agg3d(x, g: Pcl, packed_w, bias, z=None, in_state=None, in_bn=None, a_out=None, epilogue=0, ep_state=None, stats=None):
+  """One aggregation layer (as_agg3d_fwd).  x is the previous layer's raw output when ``in_state`` (BnState: finalized
+  affine) or ``in_bn`` (PendingBn: partials, merged by the kernel) is given: its BatchNorm + LeakyReLU is applied on the
+  fly, and a_out (optional) receives the activated tensor.  ``stats`` (StatParts) receives this layer's BatchNorm
+  partials.  Returns z."""
+  z = z if z is not None else POOL.get(g, x.device)
+  sm, s2, sc = (stats.mean, stats.m2, stats.cnt) if stats is not None else (None, None, None)
+  if in_bn is not None:
+    _rmw_wait(in_bn.rm)
+  call("as_agg3d_fwd", ptr(x), g, ptr(packed_w), ptr(bias), ptr(in_state.scale) if in_state is not None else None,
+       ptr(in_state.shift) if in_state is not None else None, in_bn.block if in_bn is not None else None, ptr(a_out), ptr(z),
+       int(epilogue), ptr(ep_state.scale) if ep_state is not None else None,
+       ptr(ep_state.shift) if ep_state is not None else None, LEAKY_SLOPE, ptr(sm), ptr(s2), ptr(sc), stream())
+  if in_bn is not None:
+    _rmw_done(in_bn.rm)
+  return z
+
+
+# ----------------------------------------------------------------------------------------
 # a2-a5 (+a8): cost volume -> 4x(conv3d+BN+LeakyReLU) -> conv3d 32->1 -> soft-argmax
 # Reference: StereoNet.forward, adaptive_stereo/models/stereo_net.py:173-192
 # ----------------------------------------------------------------------------------------
@@ -599,19 +667,70 @@ class CostAggregationFn(torch.autograd.Function):
     vol = POOL.get(g, dev)
     call("as_cost_volume_fwd", ptr(fl), ptr(fr), ptr(vol), g, stream())
     xs, zs, sts = [vol], [], []
-    for l in range(4):
-      w, b, gamma, beta = params[4 * l:4 * l + 4]
-      rm, rv = bn_buffers[l]
-      z, a, st = block_forward(xs[-1], g, CONV3D_333, w, b, gamma, beta, rm, rv, train, False, need_bwd)
-      zs.append(z); sts.append(st); xs.append(a)
+    tail_in = None
+    if agg3d_ok(g) and ((train and _BN_SYNC is None) or (not train and not need_bwd)):
+      # rolling-window layers: in train mode layer l+1 applies layer l's BatchNorm + LeakyReLU to its operand in LDS (and
+      # writes the activated tensor back only when a backward pass will need it); each launch finalizes its own BatchNorm
+      lib = nat.load()
+      nparts = lib.as_agg3d_parts(g)
+      x, prev = vol, None
+      for l in range(4):
+        w, b, gamma, beta = params[4 * l:4 * l + 4]
+        rm, rv = bn_buffers[l]
+        wp = pack_weights(w, CONV3D_333, False)
+        if train:
+          a_prev = POOL.get(g, dev) if (prev is not None and need_bwd) else None
+          pending = PendingBn(StatParts(nparts, dev), gamma, beta, rm, rv)
+          z = agg3d(x, g, wp, b, in_bn=prev, a_out=a_prev, stats=pending.stats)
+          if prev is not None:
+            xs.append(a_prev)                   # a_l (None when nothing will read it)
+            if not need_bwd:
+              POOL.put(x, g)                    # z_l was only this layer's operand
+          zs.append(z); sts.append(pending.state)
+          x, prev = z, pending
+        else:
+          st = bn_eval_stats(gamma, beta, rm, rv)
+          a = agg3d(x, g, wp, b, epilogue=1, ep_state=st)          # BatchNorm folded into the epilogue
+          zs.append(None); sts.append(st); xs.append(a)
+          x = a
+      if train:
+        tail_in = (x, prev)                     # z4 + its pending BatchNorm: finalized and applied by the tail kernel
+    else:
+      for l in range(4):
+        w, b, gamma, beta = params[4 * l:4 * l + 4]
+        rm, rv = bn_buffers[l]
+        z, a, st = block_forward(xs[-1], g, CONV3D_333, w, b, gamma, beta, rm, rv, train, False, need_bwd)
+        zs.append(z); sts.append(st); xs.append(a)
 
     w_out, b_out = params[16], params[17]
     logits = torch.empty(B, D, H, W, dtype=torch.float32, device=dev)
-    call("as_conv3d_out_fwd", ptr(xs[4]), g, ptr(w_out), ptr(b_out), ptr(logits), stream())
     pred = torch.empty(B, H, W, dtype=torch.float32, device=dev)
     argmax = torch.empty(B, H, W, dtype=torch.int32, device=dev)
     fcs = torch.empty(B, H, W, dtype=torch.float32, device=dev)
-    call("as_softargmax_fwd", ptr(logits), B, D, H, W, ptr(pred), ptr(argmax), ptr(fcs), stream())
+    fused_tail = _AGG_TAIL and nat.load().as_agg_tail_ok(g) == 1
+    if tail_in is not None:
+      z4, bn4 = tail_in
+      if fused_tail:
+        # one launch: layer 4's BatchNorm (merged from its partials) + LeakyReLU on the way in, 32->1 convolution,
+        # soft-argmax, arg-max, FCS
+        a4 = POOL.get(g, dev) if need_bwd else None
+        _rmw_wait(bn4.rm)
+        call("as_agg_tail_fwd", ptr(z4), g, None, None, bn4.block, ptr(a4), ptr(w_out), ptr(b_out), LEAKY_SLOPE,
+             ptr(logits), ptr(pred), ptr(argmax), ptr(fcs), stream())
+        _rmw_done(bn4.rm)
+        keep_alive = bn4                        # (its tensors are referenced by the launch just issued)
+      else:
+        a4 = bn_act(z4, bn4.finalize(), g)
+      xs.append(a4)
+      if not need_bwd:
+        POOL.put(z4, g)
+    if fused_tail:
+      if tail_in is None:
+        call("as_agg_tail_fwd", ptr(xs[4]), g, None, None, None, None, ptr(w_out), ptr(b_out), LEAKY_SLOPE,
+             ptr(logits), ptr(pred), ptr(argmax), ptr(fcs), stream())
+    else:
+      call("as_conv3d_out_fwd", ptr(xs[4]), g, ptr(w_out), ptr(b_out), ptr(logits), stream())
+      call("as_softargmax_fwd", ptr(logits), B, D, H, W, ptr(pred), ptr(argmax), ptr(fcs), stream())
 
     if need_bwd:
       ctx.g = g

@@ -26,13 +26,13 @@ extern "C" int64_t as_pcl_numel(const as_pcl* g) {
 }
 
 // ---- measurement hook -------------------------------------------------------------------
-#define PROF_IDS 7
+#define PROF_IDS 10
 #define PROF_MAX 8192
 static int g_prof_on = 0;
 static hipEvent_t g_prof_ev[PROF_IDS][PROF_MAX][2];
-static int g_prof_created[PROF_IDS] = {0, 0, 0, 0, 0, 0, 0};
-static int g_prof_n[PROF_IDS] = {0, 0, 0, 0, 0, 0, 0};
-static double g_prof_flops[PROF_IDS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+static int g_prof_created[PROF_IDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static int g_prof_n[PROF_IDS] = {0};
+static double g_prof_flops[PROF_IDS] = {0.0};
 
 void as_prof_mark(int id, hipStream_t st, int begin, double flops) {
   if (!g_prof_on || id < 0 || id >= PROF_IDS) return;

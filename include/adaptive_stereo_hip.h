@@ -100,6 +100,55 @@ int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, cons
                   float* z, const as_pcl* gout, const as_conv_shape* s,
                   int epilogue, const float* ep_scale, const float* ep_shift, float slope,
                   const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
+/* ---- a3, second generation: one 3x3x3 stride-1 32->32 aggregation layer (stereo_net.py:21-30,155-161,185-186) or its data
+ * gradient, walking down the disparity axis with a rolling window of planes in LDS (csrc/agg3d.hip).
+ *   x, z, a_out      PCL tensors of geometry g (halo 1 in d, h, w; as_agg3d_ok(g) == 1)
+ *   in_scale/shift   non-null: x is the PREVIOUS layer's raw convolution output and lrelu(x*in_scale + in_shift) — that
+ *                    layer's BatchNorm + LeakyReLU(slope) — is applied on the fly; a_out (optional) receives the activated
+ *                    tensor (what nn.Sequential would have materialised: the backward pass needs it)
+ *   in_bn            alternative to in_scale/shift: the previous layer's BatchNorm is still in PARTIALS (what its own launch
+ *                    wrote through stat_*): every workgroup merges them (as_bn_finalize's arithmetic) while its first planes
+ *                    are in flight, workgroup 0 writes that layer's state and running statistics — no finalize launch
+ *   epilogue         0: z = conv + bias, and (count, mean, M2) BatchNorm partials if stat_* are given (as_agg3d_parts(g)
+ *                    partials); 1: z = lrelu((conv + bias)*ep_scale + ep_shift) (eval mode); 2: as 0 without moments */
+typedef struct as_bn_merge {
+  const float* stat_mean;   /* [nparts][32] */
+  const float* stat_m2;     /* [nparts][32] */
+  const float* stat_cnt;    /* [nparts] */
+  const float* gamma;
+  const float* beta;
+  float* running_mean;      /* may be NULL (with running_var) */
+  float* running_var;
+  float* save_mean;         /* outputs, [32] each */
+  float* save_invstd;
+  float* scale;
+  float* shift;
+  int32_t nparts;
+  float momentum;
+  float eps;
+} as_bn_merge;
+int as_agg3d_ok(const as_pcl* g);
+int as_agg3d_parts(const as_pcl* g);
+int as_agg3d_fwd(const float* x, const as_pcl* g, const float* packed_w, const float* bias,
+                 const float* in_scale, const float* in_shift, const as_bn_merge* in_bn, float* a_out,
+                 float* z, int epilogue, const float* ep_scale, const float* ep_shift, float slope,
+                 float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
+
+/* ---- a4 + a5 + a8 in one launch: conv3d_alone (stereo_net.py:162,187) -> logits -> soft-argmax (:190-192,124-134),
+ * arg-max index and feature-contrast score (utils/feature_contrast.py:12-23), csrc/agg_tail.hip.
+ *   x                PCL volume of geometry g (halo 1; as_agg_tail_ok(g) == 1): the last aggregation layer's ACTIVATED output,
+ *                    or — with in_scale/in_shift — its RAW convolution output, whose BatchNorm + LeakyReLU(slope) is then
+ *                    applied on the fly (a_out, optional, receives the activated tensor for the backward pass); in_bn: as for
+ *                    as_agg3d_fwd (the layer's BatchNorm still in partials, merged by every workgroup)
+ *   w, bias          conv3d_alone.weight [1,32,3,3,3] (PyTorch order) and bias [1] (may be NULL)
+ *   logits           dense [B,D,H,W];  pred, fcs: dense float [B,H,W];  argmax: int32 [B,H,W] (first maximum, as torch.argmax);
+ *                    argmax and fcs may be NULL */
+int as_agg_tail_ok(const as_pcl* g);
+int as_agg_tail_fwd(const float* x, const as_pcl* g, const float* in_scale, const float* in_shift,
+                    const as_bn_merge* in_bn, float* a_out,
+                    const float* w, const float* bias, float slope, float* logits, float* pred,
+                    int32_t* argmax, float* fcs, void* stream);
+
 /* Data gradient of nn.Conv2d(32,32,5,stride=2,padding=2) (FeatureExtractorNetwork.downsample[1..k-1],
  * stereo_net.py:61-69): four parity phases of a transposed convolution, each a gather over gz.
  * gz: PCL of the convolution's output extent (halo >= 1); gx: PCL of its input extent; w: PyTorch

@@ -30,11 +30,14 @@ DEV = "cuda:0"
 EPE_BAR = 1e-3
 # end-to-end gradient bounds (see test_adapt_step_matches_reference_golden); measured worst cases over the seven
 # fixtures are logged by every run (parity_note) and printed by tests/tools/parity_report.py
-GRAD_TENSOR_REL_L2 = 5e-2
-GRAD_WHOLE_REL_L2 = 2e-2
-GRAD_NORM_REL = 5e-3
-BN_ATOL, BN_RTOL = 1e-4, 1e-3
-STEP_TOL_LR = 0.5        # three Adam steps: elements whose gradient sign is decided agree to this many lr
+# (worst over the seven fixtures on MI355X, round 2: tensor 6.8e-3 / whole network 4.8e-3 / clip norm 1.8e-4 at gain 1;
+# 2.5e-2 / 1.6e-2 / 1.8e-3 at gain 20, where the soft-argmax multiplies every upstream rounding difference by the gain)
+def grad_bounds(gain):
+  """(per-tensor relative L2, whole-network relative L2, clip-norm relative error)"""
+  return (1.5e-2, 8e-3, 1e-3) if gain <= 1.0 else (4e-2, 2.5e-2, 4e-3)
+
+
+BN_ATOL, BN_RTOL = 6e-5, 3e-4      # measured worst: 4.6e-5 absolute on a running_var of the refinement at gain 20
 
 
 def build(meta):
@@ -125,7 +128,7 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
   # hand-written backward delivers end to end (tests/tools/parity_report.py prints the numbers per case).
   arena = adapter.arena
   names = ("stereo", "feature")
-  worst, eta = (0.0, ""), {}
+  worst, eta = (0.0, ""), {}            # eta: the GPU's gradient per tensor (laid out like the fixture's)
   whole = {n_: [0.0, 0.0] for n_ in names}
   for mi, name, p, off, n in arena.entries:
     key = "grad/%s.%s" % (names[mi], name)
@@ -136,7 +139,7 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
     exp, full = gold.expected(key)
     got = g.detach().cpu() if full else syn.subsample(g.detach().cpu(), 4096)
     diff = got.reshape(exp.shape).double() - exp.double()
-    eta[(names[mi], name)] = float(diff.abs().max())
+    eta[(names[mi], name)] = got.reshape(exp.shape)
     whole[names[mi]][0] += float(diff.pow(2).sum()); whole[names[mi]][1] += float(exp.double().pow(2).sum())
     if float(exp.abs().max()) < 1e-6 * scale:
       continue      # the reference's own gradient is rounding noise (e.g. a conv bias in front of a train-mode BatchNorm)
@@ -144,14 +147,14 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
       continue      # a single number = signed sum over every pixel: cancellation-dominated (conv3d_alone.bias: exactly 0)
     rel = float(diff.norm() / exp.double().norm())
     worst = max(worst, (rel, key))
-    assert rel <= GRAD_TENSOR_REL_L2, "%s: relative L2 error %.3e" % (key, rel)
+    assert rel <= grad_bounds(meta["gain"])[0], "%s: relative L2 error %.3e" % (key, rel)
   whole = {n_: (v[0] / v[1]) ** 0.5 for n_, v in whole.items()}
   norm = float(adapter.optimizer.grad_norm())
   ref_norm = gold.scalar("train/stereo_grad_norm")
   parity_note("grads[%s]" % case, worst_tensor_rel_l2=worst[0], worst_tensor=worst[1], whole_stereo_rel_l2=whole["stereo"],
               whole_feature_rel_l2=whole["feature"], clip_norm_rel_err=abs(norm - ref_norm) / ref_norm)
-  assert whole["stereo"] <= GRAD_WHOLE_REL_L2 and whole["feature"] <= GRAD_WHOLE_REL_L2, whole
-  assert abs(norm - ref_norm) <= GRAD_NORM_REL * ref_norm + 1e-6
+  assert max(whole.values()) <= grad_bounds(meta["gain"])[1], whole
+  assert abs(norm - ref_norm) <= grad_bounds(meta["gain"])[2] * ref_norm + 1e-6
 
   # the optimizer, tightly: clip coefficient and Adam applied (on the CPU, by the oracle) to the gradients the GPU
   # produced must give the weights the GPU holds now — every element, 2e-7 (an ulp of the weights)
@@ -169,14 +172,15 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
     orc.adam_step(w0, g * (coef_gpu if mi == 0 else 1.0), {}, lr)
     assert float((p.detach().cpu() - w0).abs().max()) <= 2e-7, "Adam step of %s.%s" % (names[mi], name)
 
-  # the state after the step against the reference's (fixture "after/..."): weights with the oracle test's per-element
-  # rule (test_oracle_golden.after_step_atol) — Adam's first step is lr*g/(|g|+1e-8), i.e. +-lr by the SIGN of g, so an
-  # element can only differ (by 2 lr) where the gradient error can change that sign: |g_ref| <= eta, eta = this
-  # tensor's largest gradient deviation seen above (bounded by the gradient assertions); everything else must agree to
-  # 2e-6.  The share of elements in the loose class is logged and bounded, and the parameters must have MOVED like the
-  # reference's (an optimizer that does nothing fails here).  BatchNorm buffers: see the tolerances at the comparison.
+  # the state after the step against the reference's (fixture "after/..."), every element: Adam's first step is
+  # lr*g/(|g|+1e-8), i.e. +-lr by the SIGN of g, so the GPU's weight can differ from the reference's (by 2 lr) exactly
+  # where the two gradients differ in sign — or where one of them is rounding noise (|g| < 1e-6 x gain: the class
+  # test_oracle_golden.after_step_atol already exempts, e.g. conv biases in front of a train-mode BatchNorm).
+  # Everything else must agree to 2e-6.  The sign disagreements are counted (logged, bounded: they are the
+  # element-level measure of the gradient's quality), and the parameters must have MOVED like the reference's — an
+  # optimizer that does nothing fails here.  BatchNorm buffers: tolerances at the comparison.
   coef = min(1.0, 1.0 / (ref_norm + 1e-6))
-  loose = checked = 0
+  flips = noise_elems = checked = 0
   moved = ref_moved = 0.0
   for net_name, net in (("stereo", snet), ("feature", fnet)):
     for name, t in net.state_dict().items():
@@ -184,18 +188,21 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
       if name.endswith("num_batches_tracked"):
         assert int(t) == int(gold.z[key]), key
       elif name.endswith(("running_mean", "running_var")):
-        # all BatchNorm layers run on the hand-written kernels (fp64 Chan merge of per-workgroup moments); the 3-D ones
-        # see inputs that differ from the reference's by ~1e-6, the refinement's see the train-mode disparity (EPE up
-        # to 3e-4 at gain 20) in channel 0 of their input
+        # all BatchNorm layers run on the hand-written kernels (fp64 merge of per-workgroup moments); the 3-D ones see
+        # inputs that differ from the reference's by ~1e-6, the refinement's see the train-mode disparity (EPE up to
+        # 3e-4 at gain 20) in channel 0 of their input
         gold.compare(key, t, atol=BN_ATOL, rtol=BN_RTOL)
       else:
         atol = after_step_atol(gold, net_name, name, lr, coef, scale)
         gkey = "grad/%s.%s" % (net_name, name)
         if gold.has(gkey):
-          gref = gold.expected(gkey)[0].abs().double() * (coef if net_name == "stereo" else 1.0)
-          flip = gref <= eta[(net_name, name)] * (coef if net_name == "stereo" else 1.0)
-          atol = torch.maximum(torch.as_tensor(atol, dtype=torch.float64).expand_as(gref), 2.1 * lr * flip.double())
-          loose += int((atol > 1e-5).sum()); checked += gref.numel()
+          gref, ggpu = gold.expected(gkey)[0].double(), eta[(net_name, name)].double()
+          # (either gradient below 1e-6 x gain: within a factor 100 of Adam's eps = 1e-8 the step is proportional to g,
+          # not +-lr — rounding-noise level for this network, where the reference's own run is not reproducible)
+          noise = torch.minimum(gref.abs(), ggpu.abs()) * (coef if net_name == "stereo" else 1.0) < 1e-6 * scale
+          flip = torch.sign(ggpu) != torch.sign(gref)
+          atol = 2e-6 + 2.1 * lr * (flip | noise).double()
+          flips += int((flip & ~noise).sum()); noise_elems += int(noise.sum()); checked += gref.numel()
           exp, full = gold.expected(key)
           got = t.detach().cpu() if full else syn.subsample(t.detach().cpu(), 4096)
           w0 = init[net_name][name]
@@ -204,10 +211,10 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
           ref_moved += float((exp.double() - w0).pow(2).sum())
         gold.compare(key, t, atol=atol, rtol=1e-5)
   moved, ref_moved = moved ** 0.5, ref_moved ** 0.5
-  parity_note("after_step[%s]" % case, loose_elements=loose, checked_elements=checked, moved_norm=moved,
-              ref_moved_norm=ref_moved)
+  parity_note("after_step[%s]" % case, gradient_sign_flips=flips, noise_level_elements=noise_elems, checked_elements=checked,
+              moved_norm=moved, ref_moved_norm=ref_moved)
   assert ref_moved > 100 * lr and abs(moved - ref_moved) <= 5e-4 * ref_moved, (moved, ref_moved)
-  assert loose <= 0.03 * checked, (loose, checked)
+  assert flips <= 0.01 * checked, (flips, checked)
 
 
 def test_gpu_matches_oracle_on_fresh_inputs():
@@ -475,80 +482,69 @@ def test_step_plan_equals_per_call_launches():
 
 
 def test_three_adaptation_steps_follow_the_oracle():
-  """State carried across steps — Adam moments and bias correction, BatchNorm running statistics, the parameters
-  themselves — must follow the oracle's: three steps on three different pairs; per step the loss, the FCS and every
-  gradient tensor, at the end every parameter and buffer.  (One step against the reference itself: the golden tests.)
-
-  Per-element rule for the parameters (as in the golden test): Adam moves a weight by about lr * sign-like(m/sqrt(v))
-  per step, so an element whose gradient the two implementations can disagree on in SIGN at some step
-  (|g_oracle| <= eta_step, eta_step = that tensor's largest gradient deviation at that step) may differ by up to
-  2 lr per such step; every other element must agree to STEP_TOL_LR * lr (relative gradient errors of ~1e-2 move
-  m/sqrt(v) by about as much).  The parameters must have moved as far as the oracle's did."""
+  """State carried across steps — Adam moments, bias correction and step count, BatchNorm running statistics, the
+  parameters themselves — over three steps on three different pairs.  (One step against the reference itself: the
+  golden tests above.)  Two fp32 implementations of a loss with |.|, clamp and a bilinear gather drift apart over steps
+  (a gradient element of opposite sign moves a weight by 2 lr and the next step's gradient with it), so every step is
+  compared from the SAME state, tightly, and the carried state is checked through a shadow optimizer:
+    * before each step the oracle is loaded with the GPU's current parameters and buffers; loss, FCS, every gradient
+      tensor and the BatchNorm buffers after the step are compared for that step alone;
+    * the oracle's clip + Adam (oracle/stereo_oracle.py, the arithmetic of torch.optim.Adam) is applied on the CPU to the
+      GPU's own gradients, with ITS moments and step count carried across the three steps: the GPU's parameters must
+      equal the shadow's to an ulp at every step — exp_avg, exp_avg_sq, the bias corrections and the device-side step
+      counter are all in that comparison."""
   B, H, W, k, maxdisp = 2, 64, 160, 3, 64
   meta = dict(k=k, s=0, maxdisp=maxdisp, gain=5.0)
   fnet, snet = build(meta)
-  fsd = {n: t.detach().cpu().clone() for n, t in fnet.state_dict().items()}
-  ssd = {n: t.detach().cpu().clone() for n, t in snet.state_dict().items()}
-  fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
-  state = {}
   lr = 5e-5
   adapter = OnlineAdapter(fnet, snet, H, W, lr=lr)
-  groups = {"stereo": sp, "feature": fp}
   names = ("stereo", "feature")
-  flips = {}                     # (net, name) -> number of steps at which an element's gradient sign is undecided
-  worst_rel = 0.0
+  nets = {"stereo": snet, "feature": fnet}
+  w0 = {(n, name): p.detach().cpu().clone() for n in names for name, p in nets[n].named_parameters()}
+  shadow = {key: t.clone() for key, t in w0.items()}
+  shadow_state = {}
+  worst_rel = worst_shadow = 0.0
   for step, seed in enumerate((41, 42, 43)):
     left, right = syn.stereo_pair(B, H, W, seed=seed, disparities=(4.0, 7.0))
-    ref = orc.adapt_step(fp, sp, state, left, right, k, 0, maxdisp, lr=lr)
+    fsd = {n: t.detach().cpu().clone() for n, t in fnet.state_dict().items()}
+    ssd = {n: t.detach().cpu().clone() for n, t in snet.state_dict().items()}
+    fp, sp = orc.make_params(fsd, True), orc.make_params(ssd, True)
+    ref = orc.adapt_step(fp, sp, {}, left, right, k, 0, maxdisp, lr=lr)
     got = adapter.step(left.to(DEV), right.to(DEV))
+    torch.cuda.synchronize()
     rl, gl = float(ref["loss"]), float(got["loss"])
-    assert abs(gl - rl) <= 2e-5 + 1e-4 * abs(rl), (step, gl, rl)
+    assert abs(gl - rl) <= 2e-5 + 1e-5 * abs(rl), (step, gl, rl)
     assert abs(float(got["fcs"]) - float(ref["fcs"])) <= 1e-4 * max(1.0, abs(float(ref["fcs"]))), step
     coef = float(adapter.optimizer.coef)
+    groups = {"stereo": sp, "feature": fp}
     for mi, name, p, off, n in adapter.arena.entries:
       g_ref = groups[names[mi]][name].grad               # the oracle clips stereo_net's gradients in place
-      if g_ref is None:
-        continue
       g = adapter.arena.grads[off:off + n].view(p.shape).detach().cpu() * (coef if mi == 0 else 1.0)
-      eta = float((g - g_ref).abs().max())
-      und = (g_ref.abs() <= eta).to(torch.int32)
-      flips[(names[mi], name)] = flips.get((names[mi], name), 0) + und
+      if g_ref is None:
+        assert float(g.abs().max()) == 0.0 and torch.equal(p.detach().cpu(), w0[(names[mi], name)]), name
+        continue
       if float(g_ref.abs().max()) >= 1e-6 * 5.0 and not name.endswith(("conv2d_out.bias", "conv3d_alone.bias")):
         rel = float((g - g_ref).double().norm() / g_ref.double().norm())
         worst_rel = max(worst_rel, rel)
-        assert rel <= GRAD_TENSOR_REL_L2, (step, name, rel)
-  torch.cuda.synchronize()
-  moved = ref_moved = 0.0
-  worst_tight = 0.0
-  loose = checked = 0
-  for name, net, ref_p, sd0 in (("feature", fnet, fp, fsd), ("stereo", snet, sp, ssd)):
-    sd = net.state_dict()
-    for key, ref_t in ref_p.items():
-      got_t = sd[key].detach().cpu()
-      if not got_t.is_floating_point():
-        assert int(got_t) == int(ref_t), (name, key)
-        continue
-      ref_t = ref_t.detach()
-      diff = (got_t - ref_t).abs()
-      if key.endswith(("running_mean", "running_var")):
-        assert bool((diff <= BN_ATOL + BN_RTOL * ref_t.abs()).all()), (name, key, float(diff.max()))
-        continue
-      und = flips.get((name, key))
-      if und is None:                                     # BasicBlock.conv2: never run, never moved
-        assert torch.equal(got_t, sd0[key]), (name, key)
-        continue
-      tol = 2e-6 + 1e-5 * ref_t.abs() + STEP_TOL_LR * lr + 2.1 * lr * und.to(torch.float32)
-      assert bool((diff <= tol).all()), (name, key, float(diff.max()), int((diff > tol).sum()))
-      worst_tight = max(worst_tight, float(diff[und == 0].max()) if bool((und == 0).any()) else 0.0)
-      loose += int((und > 0).sum()); checked += und.numel()
-      moved += float((got_t - sd0[key]).double().pow(2).sum()); ref_moved += float((ref_t - sd0[key]).double().pow(2).sum())
-    bad = [kk for kk in sd if kk not in ref_p]
-    assert not bad, bad
-  moved, ref_moved = moved ** 0.5, ref_moved ** 0.5
-  parity_note("three_steps", worst_grad_rel_l2=worst_rel, worst_decided_element_diff_over_lr=worst_tight / lr,
-              loose_elements=loose, checked_elements=checked, moved_norm=moved, ref_moved_norm=ref_moved)
-  assert ref_moved > 100 * lr and abs(moved - ref_moved) <= 2e-3 * ref_moved, (moved, ref_moved)
-  assert loose <= 0.05 * checked, (loose, checked)
+        assert rel <= grad_bounds(5.0)[0], (step, name, rel)
+      orc.adam_step(shadow[(names[mi], name)], g, shadow_state.setdefault((names[mi], name), {}), lr)
+      dev = float((p.detach().cpu() - shadow[(names[mi], name)]).abs().max())
+      worst_shadow = max(worst_shadow, dev)
+      assert dev <= 2e-7 * (step + 1), (step, name, dev)
+    assert adapter.optimizer.step_count == step + 1 and float(adapter.optimizer.step_dev) == step + 1.0
+    for n_, net, ref_p in (("feature", fnet, fp), ("stereo", snet, sp)):
+      sd = net.state_dict()
+      assert set(sd.keys()) == set(ref_p.keys())
+      for key, ref_t in ref_p.items():
+        if key.endswith("num_batches_tracked"):
+          assert int(sd[key]) == int(ref_t), (step, key)
+        elif key.endswith(("running_mean", "running_var")):
+          diff = (sd[key].detach().cpu() - ref_t).abs()
+          assert bool((diff <= BN_ATOL + BN_RTOL * ref_t.abs()).all()), (step, n_, key, float(diff.max()))
+  moved = sum(float((p.detach().cpu() - w0[(n, name)]).double().pow(2).sum()) for n in names
+              for name, p in nets[n].named_parameters()) ** 0.5
+  parity_note("three_steps", worst_grad_rel_l2=worst_rel, worst_shadow_optimizer_deviation=worst_shadow, moved_norm=moved)
+  assert moved > 100 * lr, moved
 
 
 def test_inference_plan_and_graph_equal_plain_forward():

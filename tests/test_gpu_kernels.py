@@ -690,3 +690,230 @@ def test_khamis_robust_loss_matches_reference_fixture(golden_loader):
   gt = (pred + 0.5).clone()
   gt[:, :, ::3, ::5] = 0.0
   assert abs(float(khamis_robust_loss(pred, gt)) - gold.scalar("train/khamis")) < 1e-6
+
+
+# ----------------------------------------------------------------------------- a3, second generation (csrc/agg3d.hip)
+AGG_CASES = [  # B, D, H, W
+  (1, 12, 24, 78),      # KITTI k=4, one pair: segments of one plane
+  (4, 12, 24, 78),      # the benchmark's launch: 240 units of three planes
+  (2, 12, 34, 60),      # SceneFlow k=4
+  (3, 5, 9, 40),        # ragged: D not a multiple of the segment length, last tile shifted back
+  (1, 1, 4, 33),        # a single plane, the smallest supported width (Wp = 35 >= 34)
+  (2, 7, 6, 85),        # the widest plane whose four runs fit in LDS
+  (6, 7, 24, 78),       # segments of four planes, the last one ragged (planes 4..6)
+]
+
+
+@pytest.mark.parametrize("B,D,H,W", AGG_CASES)
+def test_agg3d_layer_against_torch_and_first_generation(B, D, H, W):
+  """as_agg3d_fwd, every flavour: raw output + BatchNorm partials (training forward of layer 1), the previous layer's
+  BatchNorm merged from its partials by the consumer and applied with the LeakyReLU to the operand in LDS, the activated
+  tensor written back (layers 2-4), folded BatchNorm epilogue (eval) and raw data gradient — against torch's conv3d / batch_norm on the CPU and, bit for
+  bit, against the first-generation kernels (same fp32 accumulation order by construction)."""
+  g = Pcl(B, D, H, W, 1, 1, 1)
+  lib = nat.load()
+  assert lib.as_agg3d_ok(g) == 1
+  shape = ops.CONV3D_333
+  x = rnd(B, 32, D, H, W, seed=1)
+  w = rnd(32, 32, 3, 3, 3, seed=2, scale=1.0 / 864 ** 0.5)
+  b = rnd(32, seed=3, scale=0.1)
+  gamma, beta = rnd(32, seed=5) * 0.5 + 1.0, rnd(32, seed=6) * 0.2
+  rm, rv = rnd(32, seed=7) * 0.1, rnd(32, seed=8).abs() + 0.5
+  z_ref = F.conv3d(x, w, b, padding=1)
+  xb = ops.ncdhw_to_pcl(x.to(DEV), g)
+  wd, bd = w.to(DEV), b.to(DEV)
+  wp, wpt = ops.pack_weights(wd, shape, False), ops.pack_weights(wd, shape, True)
+  gd, bed = gamma.to(DEV), beta.to(DEV)
+  tag = "B%d D%d H%d W%d" % (B, D, H, W)
+
+  def halo_is_zero(buf, what):
+    full = ops.pcl_view(buf, g).clone(); ops.pcl_interior(full, g).zero_()
+    assert float(full.abs().max()) == 0.0, "%s: %s wrote into the halo" % (tag, what)
+
+  prev = ops.set_agg3d(False)
+  try:
+    old_stats = ops.conv32_stat_parts(g, g, shape, DEV)
+    z_old = ops.conv32(xb, g, wp, bd, g, shape, stats=old_stats)
+    rm_o, rv_o = rm.to(DEV).clone(), rv.to(DEV).clone()
+    st_old = ops.bn_train_stats(old_stats, gd, bed, rm_o, rv_o)
+  finally:
+    ops.set_agg3d(prev)
+
+  # -- training forward of a first layer: raw output + BatchNorm partials ------------------------------------------
+  nparts = lib.as_agg3d_parts(g)
+  z1 = ops.pcl_zeros(g, DEV)
+  rm_d, rv_d = rm.to(DEV).clone(), rv.to(DEV).clone()
+  pend = ops.PendingBn(ops.StatParts(nparts, DEV), gd, bed, rm_d, rv_d)
+  ops.agg3d(xb, g, wp, bd, z=z1, stats=pend.stats)
+  close(ops.pcl_to_ncdhw(z1, g), z_ref, 2e-5, 1e-5, tag + " fwd")
+  assert torch.equal(z1, z_old), tag + ": not bit-identical to conv3d_lds_kernel"
+  halo_is_zero(z1, "forward")
+  assert abs(float(pend.stats.cnt.sum()) - B * D * H * W) < 0.5, "the partials must count every voxel exactly once"
+
+  # -- layers 2-4: the operand is the previous layer's raw output; its BatchNorm is merged from the partials by every
+  #    workgroup (workgroup 0 publishes the state and the running statistics), applied in LDS; a_out is a by-product --
+  a_new, z2 = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  ops.agg3d(z1, g, wp, bd, z=z2, in_bn=pend, a_out=a_new, stats=ops.StatParts(nparts, DEV))
+  st = pend.state
+  mean_ref = z_ref.mean(dim=(0, 2, 3, 4)); var_ref = z_ref.var(dim=(0, 2, 3, 4), unbiased=False)
+  close(st.mean, mean_ref, 2e-6, 1e-5, tag + " bn mean")
+  close(st.invstd, 1.0 / torch.sqrt(var_ref + 1e-5), 0, 2e-5, tag + " bn invstd")
+  close(st.scale, gamma / torch.sqrt(var_ref + 1e-5), 0, 2e-5, tag + " bn scale")
+  close(st.shift, beta - mean_ref * gamma / torch.sqrt(var_ref + 1e-5), 3e-6, 3e-5, tag + " bn shift")
+  rm_ref, rv_ref = rm.clone(), rv.clone()
+  F.batch_norm(z_ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+  close(rm_d, rm_ref, 2e-6, 1e-5, tag + " running_mean"); close(rv_d, rv_ref, 2e-6, 2e-5, tag + " running_var")
+  close(st.mean, st_old.mean, 1e-6, 1e-6, tag + " mean vs first generation")
+  close(st.invstd, st_old.invstd, 0, 2e-6, tag + " invstd vs first generation")
+  # the stand-alone finalize launch on the same partials gives the same state (merge order differs: fp64, then rounded)
+  pend2 = ops.PendingBn(pend.stats, gd, bed, rm.to(DEV).clone(), rv.to(DEV).clone())
+  st2 = pend2.finalize()
+  close(st2.scale, st.scale, 0, 2e-7, tag + " scale vs as_bn_finalize"); close(st2.shift, st.shift, 1e-7, 2e-7, tag + " shift vs as_bn_finalize")
+  close(pend2.rm, rm_d, 1e-8, 2e-7, tag + " running_mean vs as_bn_finalize")
+  # first generation on the state the kernel published: element-wise pass, then the convolution
+  a_old = ops.bn_act(z1, st, g)
+  prev = ops.set_agg3d(False)
+  try:
+    z2_old = ops.conv32(a_old, g, wp, bd, g, shape)
+  finally:
+    ops.set_agg3d(prev)
+  assert torch.equal(a_new, a_old), tag + ": activated by-product differs from as_bn_act_fwd"
+  assert torch.equal(z2, z2_old), tag + ": fused-operand layer differs from the two-pass result"
+  halo_is_zero(a_new, "by-product"); halo_is_zero(z2, "fused layer")
+  a_ref = F.leaky_relu(z_ref * st.scale.cpu().view(1, -1, 1, 1, 1) + st.shift.cpu().view(1, -1, 1, 1, 1), 0.2)
+  close(ops.pcl_to_ncdhw(z2, g), F.conv3d(a_ref, w, b, padding=1), 5e-5, 1e-5, tag + " fused layer vs torch")
+  # the same layer with the affine handed over finalized, without by-product and moments; and a second merge of the same
+  # partials (fixed order: same bits)
+  z2n = ops.pcl_zeros(g, DEV)
+  ops.agg3d(z1, g, wp, bd, z=z2n, in_state=st)
+  assert torch.equal(z2n, z2)
+  pend3 = ops.PendingBn(pend.stats, gd, bed, rm.to(DEV).clone(), rv.to(DEV).clone())
+  z2m = ops.pcl_zeros(g, DEV)
+  ops.agg3d(z1, g, wp, bd, z=z2m, in_bn=pend3)
+  assert torch.equal(z2m, z2) and torch.equal(pend3.state.scale, st.scale) and torch.equal(pend3.rm, rm_d)
+
+  # -- eval forward (BatchNorm folded into the epilogue) and the data gradient --------------------------------------
+  prev = ops.set_agg3d(False)
+  try:
+    y_old = ops.conv32(xb, g, wp, bd, g, shape, epilogue=1, scale=st.scale, shift=st.shift)
+    gx_old = ops.conv32(xb, g, wpt, None, g, shape)
+  finally:
+    ops.set_agg3d(prev)
+  y_new = ops.agg3d(xb, g, wp, bd, z=ops.pcl_zeros(g, DEV), epilogue=1, ep_state=st)
+  assert torch.equal(y_new, y_old), tag + ": eval epilogue"
+  halo_is_zero(y_new, "eval epilogue")
+  gx_new = ops.agg3d(xb, g, wpt, None, z=ops.pcl_zeros(g, DEV), epilogue=2)
+  assert torch.equal(gx_new, gx_old), tag + ": data gradient"
+  halo_is_zero(gx_new, "data gradient")
+
+
+def test_agg3d_refuses_unsupported_geometry():
+  lib = nat.load()
+  assert lib.as_agg3d_ok(Pcl(1, 12, 24, 31, 1, 1, 1)) == 0      # Wp = 33 < 34
+  assert lib.as_agg3d_ok(Pcl(1, 12, 24, 90, 1, 1, 1)) == 0      # four runs of 130 + 2*92 voxels do not fit in LDS
+  assert lib.as_agg3d_ok(Pcl(1, 24, 47, 156, 1, 1, 1)) == 0     # KITTI k=3: stays on the first-generation kernels
+  assert lib.as_agg3d_ok(Pcl(1, 12, 24, 78, 1, 2, 2)) == 0      # halo must be exactly 1
+  g = Pcl(1, 12, 24, 90, 1, 1, 1)
+  x = ops.pcl_zeros(g, DEV)
+  with pytest.raises(RuntimeError, match="not supported"):
+    ops.agg3d(x, g, torch.zeros(27 * 1024, device=DEV), None, z=ops.pcl_zeros(g, DEV), epilogue=2)
+
+
+# ----------------------------------------------------------------------------- a4 + a5 + a8 fused (csrc/agg_tail.hip)
+def _tail(x_pcl, g, w, b, in_state=None, a_out=None, in_bn=None):
+  B, D, H, W = g.B, g.D, g.H, g.W
+  logits = torch.full((B, D, H, W), float("nan"), device=DEV)
+  pred = torch.full((B, H, W), float("nan"), device=DEV)
+  am = torch.full((B, H, W), -1, dtype=torch.int32, device=DEV)
+  fcs = torch.full((B, H, W), float("nan"), device=DEV)
+  nat.call("as_agg_tail_fwd", nat.ptr(x_pcl), g, nat.ptr(in_state.scale) if in_state is not None else None,
+           nat.ptr(in_state.shift) if in_state is not None else None, in_bn.block if in_bn is not None else None,
+           nat.ptr(a_out), nat.ptr(w), nat.ptr(b), 0.2,
+           nat.ptr(logits), nat.ptr(pred), nat.ptr(am), nat.ptr(fcs), nat.stream())
+  return logits, pred, am, fcs
+
+
+@pytest.mark.parametrize("B,D,H,W,gain", [(1, 8, 5, 9, 1.0), (2, 12, 6, 19, 50.0), (1, 24, 4, 33, 300.0), (4, 12, 24, 78, 20.0),
+                                          (1, 24, 47, 156, 20.0), (2, 1, 3, 40, 1.0), (1, 2, 2, 31, 5.0), (1, 32, 3, 17, 100.0)])
+def test_agg_tail_logits_softargmax_argmax_fcs(B, D, H, W, gain):
+  """conv3d_alone -> logits -> soft-argmax / arg-max / FCS in one launch (as_agg_tail_fwd) against torch on the CPU and
+  against the two-launch path (as_conv3d_out_fwd + as_softargmax_fwd); with the last layer's BatchNorm + LeakyReLU applied
+  on the way in (training forward) against as_bn_act_fwd followed by the plain flavour, bit for bit.  Arg-max indices:
+  equal to torch.argmax of the kernel's OWN logits everywhere (the index logic is exact) and equal to the reference's
+  wherever its top-2 gap exceeds twice the logit deviation (all pixels, in practice)."""
+  g = Pcl(B, D, H, W, 1, 1, 1)
+  assert nat.load().as_agg_tail_ok(g) == 1
+  a = rnd(B, 32, D, H, W, seed=1)
+  w = rnd(1, 32, 3, 3, 3, seed=2, scale=0.03) * gain
+  b = rnd(1, seed=3, scale=0.1) * gain
+  logits_ref = F.conv3d(a, w, b, padding=1).squeeze(1)
+  ab = ops.ncdhw_to_pcl(a.to(DEV), g)
+  wd, bd = w.to(DEV).contiguous(), b.to(DEV)
+  logits, pred, am, fcs = _tail(ab, g, wd, bd)
+  assert not bool(torch.isnan(logits).any() | torch.isnan(pred).any() | torch.isnan(fcs).any()) and int(am.min()) >= 0, \
+      "every interior pixel must be written"
+  close(logits, logits_ref, 3e-6 * max(1.0, gain), 1e-5, "logits")
+  own = logits.cpu()
+  assert torch.equal(am.cpu().long(), torch.argmax(own, dim=1)), "arg-max of the kernel's own logits"
+  srt = torch.sort(logits_ref, dim=1, descending=True)[0]
+  dev_l = float((own - logits_ref).abs().max())
+  decided = (srt[:, 0] - srt[:, 1]) > 2 * dev_l if D > 1 else torch.ones(B, H, W, dtype=torch.bool)
+  assert bool((am.cpu().long()[decided] == torch.argmax(logits_ref, dim=1)[decided]).all())
+  close(pred, orc.soft_argmax(own), 2e-5, 1e-5, "soft-argmax of the kernel's own logits")
+  close(pred, orc.soft_argmax(logits_ref), 2e-5 + 40.0 * dev_l, 1e-5, "soft-argmax")
+  if D > 2:
+    close(fcs, orc.feature_contrast_mean(own), 1e-5 * max(1.0, gain), 1e-5, "fcs")
+  else:
+    assert float(fcs.abs().max()) == 0.0
+  # the two-launch path on the same input
+  l2 = torch.empty(B, D, H, W, device=DEV)
+  nat.call("as_conv3d_out_fwd", nat.ptr(ab), g, nat.ptr(wd), nat.ptr(bd), nat.ptr(l2), nat.stream())
+  close(logits, l2, 3e-6 * max(1.0, gain), 1e-5, "logits vs conv32to1_fwd_kernel")
+  # training forward: raw input + BatchNorm affine + LeakyReLU on the way in, activated tensor as a by-product
+  st = ops.BnState(DEV)
+  st.scale.copy_((rnd(32, seed=11) * 0.5 + 1.0).to(DEV)); st.shift.copy_((rnd(32, seed=12) * 0.3).to(DEV))
+  act = ops.bn_act(ab, st, g)
+  l_two, p_two, am_two, f_two = _tail(act, g, wd, bd)
+  a_out = ops.pcl_zeros(g, DEV)
+  l_one, p_one, am_one, f_one = _tail(ab, g, wd, bd, in_state=st, a_out=a_out)
+  assert torch.equal(a_out, act), "activated by-product differs from as_bn_act_fwd"
+  assert torch.equal(l_one, l_two) and torch.equal(p_one, p_two) and torch.equal(am_one, am_two) and torch.equal(f_one, f_two)
+  l_nobp = _tail(ab, g, wd, bd, in_state=st)[0]
+  assert torch.equal(l_nobp, l_one)
+  # ... and with the BatchNorm still in partials (merged by every workgroup): against as_bn_finalize + the affine flavour
+  parts = ops.StatParts(37, DEV)
+  parts.mean.copy_((rnd(37 * 32, seed=21) * 0.3).to(DEV)); parts.m2.copy_((rnd(37 * 32, seed=22).abs() * 50 + 5).to(DEV))
+  parts.cnt.copy_((rnd(37, seed=23).abs() * 90 + 10).floor().to(DEV)); parts.cnt[5] = 0.0; parts.m2[5 * 32:6 * 32] = 0.0
+  gam, bet = (rnd(32, seed=24) * 0.5 + 1.0).to(DEV), (rnd(32, seed=25) * 0.2).to(DEV)
+  pa = ops.PendingBn(parts, gam, bet, torch.zeros(32, device=DEV), torch.ones(32, device=DEV))
+  pb = ops.PendingBn(parts, gam, bet, torch.zeros(32, device=DEV), torch.ones(32, device=DEV))
+  a_m = ops.pcl_zeros(g, DEV)
+  l_m, p_m, am_m, f_m = _tail(ab, g, wd, bd, in_bn=pa, a_out=a_m)
+  st_f = pb.finalize()
+  close(pa.state.scale, st_f.scale, 0, 2e-7, "merged scale"); close(pa.state.shift, st_f.shift, 1e-7, 2e-7, "merged shift")
+  close(pa.rm, pb.rm, 1e-8, 2e-7, "merged running_mean"); close(pa.rv, pb.rv, 1e-8, 2e-7, "merged running_var")
+  l_a, p_a, am_a, f_a = _tail(ab, g, wd, bd, in_state=pa.state)
+  assert torch.equal(l_m, l_a) and torch.equal(p_m, p_a) and torch.equal(am_m, am_a) and torch.equal(f_m, f_a)
+  assert torch.equal(a_m, ops.bn_act(ab, pa.state, g))
+
+
+def test_agg_tail_ties_and_extremes():
+  """First maximum wins (torch.argmax semantics), duplicates of the maximum count twice in the FCS (as in a sort), large
+  logits do not overflow: designed logits are driven through the convolution exactly (centre tap, one channel)."""
+  D, H, W = 6, 2, 40
+  l = torch.zeros(1, D, H, W)
+  l[0, :, 0, 1] = torch.tensor([1.0, 5.0, 5.0, 0.0, 5.0, -1.0])      # three-way tie -> index 1
+  l[0, :, 0, 2] = torch.tensor([-300.0, 200.0, -50.0, 199.0, 0.0, 10.0])
+  l[0, :, 0, 3] = torch.tensor([3e4, -3e4, 0.0, 0.0, 0.0, 0.0])
+  l[0, :, 1, 39] = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.0, 7.0])     # last pixel of the plane, maximum at the last index
+  l[0, :, 1, 0] = torch.tensor([2.0, 2.0, 2.0, 2.0, 2.0, 2.0])       # all equal -> index 0
+  a = torch.zeros(1, 32, D, H, W); a[0, 0] = l[0]
+  w = torch.zeros(1, 32, 3, 3, 3); w[0, 0, 1, 1, 1] = 1.0
+  g = Pcl(1, D, H, W, 1, 1, 1)
+  logits, pred, am, fcs = _tail(ops.ncdhw_to_pcl(a.to(DEV), g), g, w.to(DEV), None)
+  assert torch.equal(logits.cpu(), l)
+  assert torch.equal(am.cpu().long(), torch.argmax(l, dim=1))
+  assert int(am[0, 0, 1]) == 1 and int(am[0, 1, 39]) == 5 and int(am[0, 1, 0]) == 0
+  assert bool(torch.isfinite(pred).all())
+  close(pred, orc.soft_argmax(l), 2e-5, 1e-5, "soft-argmax")
+  close(fcs, orc.feature_contrast_mean(l), 1e-5, 1e-5, "fcs")
