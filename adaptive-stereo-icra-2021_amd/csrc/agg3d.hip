@@ -145,11 +145,11 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
     in_sc = *reinterpret_cast<const f32x4*>(p.in_scale + 4 * cg);
     in_sh = *reinterpret_cast<const f32x4*>(p.in_shift + 4 * cg);
   }
-  if (IN == 2) {            // scratch = the dump slots of the element-wise pass (not in use yet, not a DMA target)
-    const float* tab = bn_merge_partials(p.in_bn, ring + 4 * p.slot_bytes, blockIdx.x == 0);
+  if (IN == 2) {            // while the first three planes are in flight
+    const float* tab = bn_merge_partials<32>(p.in_bn, ring + ((d0 + 3) & 3) * p.slot_bytes, blockIdx.x == 0);   // plane d0+3's slot: no DMA target yet
     in_sc = *reinterpret_cast<const f32x4*>(tab + 4 * cg);
     in_sh = *reinterpret_cast<const f32x4*>(tab + 32 + 4 * cg);
-    __syncthreads();        // every thread has its affine before the dump slots are used as such
+    __syncthreads();        // every thread has its affine before plane d0+3 is requested into the scratch's slot
   }
   if (IN != 0) {
 #pragma unroll

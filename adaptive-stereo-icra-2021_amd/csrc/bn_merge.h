@@ -2,8 +2,8 @@
 // merges the producer's per-workgroup (count, mean, M2) partials itself while its first operand planes are still in flight
 // (plain cached loads after a kernel boundary: no hand-off protocol, no finalize launch, no ticket), all of them in the same
 // fixed order, so every workgroup holds the same bits; workgroup 0 also writes the layer's state (mean, invstd, scale,
-// shift: the backward pass reads them) and updates the running statistics.  Arithmetic = bn_finalize_kernel's exact
-// two-pass merge in fp64:  mean = sum n_i*mean_i / N;  M2 = sum [ M2_i + n_i*(mean_i - mean)^2 ].
+// shift: the backward pass reads them) and updates the running statistics.  Arithmetic: bn_finalize_kernel's merge
+// (mean = sum n_i*mean_i / N;  M2 = sum [ M2_i + n_i*(mean_i - mean)^2 ]) in its one-pass form, fp64.
 #pragma once
 #include "as_common.h"
 
@@ -23,45 +23,26 @@ struct BnMergeDev {
   float momentum, eps;
 };
 
-#define BN_MERGE_SCRATCH_BYTES (8 * 33 * 8 + 64 * 4)      // [8][33] doubles + scale[32] + shift[32]
+#define BN_MERGE_SCRATCH_BYTES (8 * 32 * 3 * 8 + 64 * 4)      // [8][32][3] doubles + scale[32] + shift[32]
 
-// All 256 threads of the workgroup call (it contains barriers).  On return tab[0..31] = scale, tab[32..63] = shift, where
-// tab = (float*)(scratch + 8*33*8).  `publish`: this workgroup writes the layer state and the running statistics.
+// All 256 threads of the workgroup call (it contains two barriers).  On return tab[0..31] = scale, tab[32..63] = shift,
+// where tab = (float*)(scratch + 6144).  `publish`: this workgroup writes the layer state and the running statistics.
+// ONE pass over the partials (a consumer waits for this: the two-pass form costs two dependent rounds of loads more):
+// with a pivot K (the first partial's mean) the sums  S0 = sum n_i,  S1 = sum n_i (mean_i - K),
+// S2 = sum [ M2_i + n_i (mean_i - K)^2 ]  give  mean = K + S1/S0  and  M2 = S2 - S1^2/S0  — algebraically the two-pass
+// result, and in fp64 (the terms are fp32 data, the pivot is within the data's range) equal to it to ~1e-15 relative.
+template <int BATCH>      // partials per thread whose loads are in flight together (3 x BATCH registers)
 __device__ inline float* bn_merge_partials(const BnMergeDev& m, char* scratch, bool publish) {
-  double* red = reinterpret_cast<double*>(scratch);
-  float* tab = reinterpret_cast<float*>(scratch + 8 * 33 * 8);
+  double* red = reinterpret_cast<double*>(scratch);            // [8][32][3]
+  float* tab = reinterpret_cast<float*>(scratch + 8 * 32 * 3 * 8);
   const int c = threadIdx.x & 31, slc = threadIdx.x >> 5;
   const int per_slice = (m.nparts + 7) >> 3;
-  double s = 0.0, cn = 0.0;
-  for (int j0 = 0; j0 < per_slice; j0 += 16) {
-    float pn[16], pm[16];
+  const double K = (double)m.stat_mean[c];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int j0 = 0; j0 < per_slice; j0 += BATCH) {
+    float pn[BATCH], pm[BATCH], pq[BATCH];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {                          // sixteen independent loads in flight per round
-      const int i = slc + 8 * (j0 + j);
-      const bool ok = i < m.nparts;
-      const int ii = ok ? i : 0;
-      pn[j] = ok ? m.stat_cnt[ii] : 0.f;
-      pm[j] = m.stat_mean[ii * 32 + c];
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { cn += (double)pn[j]; s += (double)pn[j] * (double)pm[j]; }
-  }
-  red[slc * 33 + c] = s;
-  __syncthreads();
-  double tot = 0.0;
-  for (int j = 0; j < 8; ++j) tot += red[j * 33 + c];
-  __syncthreads();
-  red[slc * 33 + c] = cn;
-  __syncthreads();
-  double count = 0.0;
-  for (int j = 0; j < 8; ++j) count += red[j * 33 + c];
-  __syncthreads();
-  const double mean = tot / count;
-  double qq = 0.0;
-  for (int j0 = 0; j0 < per_slice; j0 += 16) {
-    float pn[16], pm[16], pq[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < BATCH; ++j) {                       // every load of the round in flight together
       const int i = slc + 8 * (j0 + j);
       const bool ok = i < m.nparts;
       const int ii = ok ? i : 0;
@@ -70,13 +51,20 @@ __device__ inline float* bn_merge_partials(const BnMergeDev& m, char* scratch, b
       pq[j] = ok ? m.stat_m2[ii * 32 + c] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const double dm = (double)pm[j] - mean; qq += (double)pq[j] + (double)pn[j] * dm * dm; }
+    for (int j = 0; j < BATCH; ++j) {
+      const double n = (double)pn[j], dm = (double)pm[j] - K;
+      s0 += n; s1 += n * dm; s2 += (double)pq[j] + n * dm * dm;
+    }
   }
-  red[slc * 33 + c] = qq;
+  double* mine = red + (slc * 32 + c) * 3;
+  mine[0] = s0; mine[1] = s1; mine[2] = s2;
   __syncthreads();
   if (slc == 0) {
-    double m2 = 0.0;
-    for (int j = 0; j < 8; ++j) m2 += red[j * 33 + c];
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int j = 0; j < 8; ++j) { const double* r = red + (j * 32 + c) * 3; t0 += r[0]; t1 += r[1]; t2 += r[2]; }
+    const double count = t0;
+    const double mean = K + t1 / count;
+    const double m2 = fmax(t2 - t1 * t1 / count, 0.0);
     const double var_b = m2 / count;
     const float invstd = (float)(1.0 / sqrt(var_b + (double)m.eps));
     const float meanf = (float)mean;
