@@ -568,6 +568,8 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
       fused = conv32_dgrad_bnbwd(g_z, g, wp_t, shape, g_out if skip else None, next_bn[0], next_bn[1])
     if fused is not None:
       g_x, next_sums = fused
+    elif shape.kd == 3 and not skip and agg3d_ok(g):
+      g_x = agg3d(g_z, g, wp_t, None, epilogue=2)            # rolling-window kernel: the data gradient of a 3-D layer
     else:
       g_x = conv32(g_z, g, wp_t, None, g, shape, residual=g_out if skip else None)
   POOL.put(g_z, g)

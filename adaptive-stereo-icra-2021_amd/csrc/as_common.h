@@ -14,6 +14,15 @@
 void as_set_error(const char* fmt, ...);
 // measurement hook (optim.hip): event pair around a kernel launch; no-ops unless enabled
 void as_prof_mark(int kernel_id, hipStream_t st, int begin, double flops);
+// kernel ids of the measurement hook (bench.py reads them back with as_prof_read); the `flops` argument carries FLOPs for
+// the matrix-core kernels and ALGORITHMIC BYTES (every tensor read once + written once) for the HBM-bound rows
+enum {
+  AS_PROF_CONV32 = 0, AS_PROF_WGRAD32 = 1, AS_PROF_CONV32_LDS = 2, AS_PROF_WGRAD32_LDS = 3, AS_PROF_BN_ACT_FWD = 4,
+  AS_PROF_BN_BWD = 5, AS_PROF_CONV32_LDS_BNBWD = 6, AS_PROF_AGG3D = 7, AS_PROF_AGG_TAIL = 8, AS_PROF_WGRAD3D_LDS = 9,
+  AS_PROF_COSTVOL_FWD = 10, AS_PROF_COSTVOL_BWD = 11, AS_PROF_OUTCONV_BWD = 12, AS_PROF_SOFTARGMAX_BWD = 13,
+  AS_PROF_UPSAMPLE_FWD = 14, AS_PROF_UPSAMPLE_BWD = 15, AS_PROF_WARP_FWD = 16, AS_PROF_WARP_BWD = 17,
+  AS_PROF_LOSS_FWD = 18, AS_PROF_LOSS_BWD = 19, AS_PROF_OUTCONV_FWD = 20, AS_PROF_SOFTARGMAX_FWD = 21, AS_PROF_IDS = 24
+};
 
 #define AS_CHECK_ARG(cond, ...)            \
   do {                                     \

@@ -640,9 +640,9 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
     const int slabs = conv3d_wgrad_lds_slabs(gout);
     float* partial_db = workspace + (int64_t)slabs * T * 1024;
     hipStream_t st = (hipStream_t)stream;
-    as_prof_mark(1, st, 1, 0.0);
+    as_prof_mark(AS_PROF_WGRAD3D_LDS, st, 1, 0.0);
     if (int e = conv3d_wgrad_lds_launch(x, gin, gz, gout, workspace, partial_db, stream)) return e;
-    as_prof_mark(1, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
+    as_prof_mark(AS_PROF_WGRAD3D_LDS, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
                        workspace, partial_db, slabs, T, dW, db, accumulate);
     AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");

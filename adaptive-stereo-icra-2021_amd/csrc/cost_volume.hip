@@ -102,7 +102,9 @@ extern "C" int as_cost_volume_fwd(const float* L, const float* R, float* vol, co
   if (int e = check_cv(g, "as_cost_volume_fwd")) return e;
   AS_CHECK_ARG(L && R && vol, "as_cost_volume_fwd: null pointer");
   dim3 grid(as_div_up(g->W, CV_TX), g->H, g->B);
+  as_prof_mark(AS_PROF_COSTVOL_FWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(cost_volume_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, R, vol, as_make_dev(g));
+  as_prof_mark(AS_PROF_COSTVOL_FWD, (hipStream_t)stream, 0, 2.0 * 128.0 * (double)g->B * g->H * g->W + 128.0 * (double)g->B * g->D * g->H * g->W);
   AS_CHECK_LAUNCH("as_cost_volume_fwd");
   return AS_OK;
 }
@@ -111,7 +113,9 @@ extern "C" int as_cost_volume_bwd(const float* gvol, float* gL, float* gR, const
   if (int e = check_cv(g, "as_cost_volume_bwd")) return e;
   AS_CHECK_ARG(gvol && gL && gR, "as_cost_volume_bwd: null pointer");
   dim3 grid(as_div_up(g->W, CV_TX), g->H, g->B);
+  as_prof_mark(AS_PROF_COSTVOL_BWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(cost_volume_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gvol, gL, gR, as_make_dev(g));
+  as_prof_mark(AS_PROF_COSTVOL_BWD, (hipStream_t)stream, 0, 2.0 * 128.0 * (double)g->B * g->H * g->W + 128.0 * (double)g->B * g->D * g->H * g->W);
   AS_CHECK_LAUNCH("as_cost_volume_bwd");
   return AS_OK;
 }

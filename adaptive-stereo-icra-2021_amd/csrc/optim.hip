@@ -26,11 +26,11 @@ extern "C" int64_t as_pcl_numel(const as_pcl* g) {
 }
 
 // ---- measurement hook -------------------------------------------------------------------
-#define PROF_IDS 10
+#define PROF_IDS AS_PROF_IDS
 #define PROF_MAX 8192
 static int g_prof_on = 0;
 static hipEvent_t g_prof_ev[PROF_IDS][PROF_MAX][2];
-static int g_prof_created[PROF_IDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static int g_prof_created[PROF_IDS] = {0};
 static int g_prof_n[PROF_IDS] = {0};
 static double g_prof_flops[PROF_IDS] = {0.0};
 

@@ -317,9 +317,11 @@ extern "C" int as_monodepth_loss_fwd(const float* pred, const float* img, const 
   hipStream_t st = (hipStream_t)stream;
   PhWs w = carve(workspace, B);
   const long plane = (long)H * W;
+  as_prof_mark(AS_PROF_LOSS_FWD, st, 1, 0.0);
   if (int e = image_mean(pred, B, plane, w, st)) return e;
   hipLaunchKernelGGL(monodepth_fwd_kernel, dim3(as_div_up(plane, 256), B), dim3(256), 0, st, pred, img, warped,
                      w.mean, B, H, W, smoothness_weight, total, l1, ssim, smooth);
+  as_prof_mark(AS_PROF_LOSS_FWD, st, 0, 4.0 * (double)B * plane * (1 + 3 + 3 + 4));     // pred, img, warped read; four maps written
   AS_CHECK_LAUNCH("as_monodepth_loss_fwd");
   return AS_OK;
 }
@@ -334,6 +336,7 @@ extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, co
   hipStream_t st = (hipStream_t)stream;
   PhWs w = carve(workspace, B);
   const long plane = (long)H * W;
+  as_prof_mark(AS_PROF_LOSS_BWD, st, 1, 0.0);
   if (int e = image_mean(pred, B, plane, w, st)) return e;
   hipLaunchKernelGGL(monodepth_bwd_a_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, g_total, g_ssim, g_smooth,
                      pred, img, warped, w.mean, B, H, W, smoothness_weight, w.coef, w.partial);
@@ -343,6 +346,9 @@ extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, co
   AS_CHECK_LAUNCH("as_monodepth_loss_bwd(sum)");
   hipLaunchKernelGGL(monodepth_bwd_b_kernel, dim3(as_div_up(plane, 256), B), dim3(256), 0, st, g_total, g_l1,
                      pred, img, warped, w.mean, w.coef, w.sum, B, H, W, g_pred, g_warped);
+  // four incoming gradient maps, pred, img, warped read; g_pred and g_warped written (the 10-plane coefficient
+  // workspace between the two passes is the implementation's, not the algorithm's)
+  as_prof_mark(AS_PROF_LOSS_BWD, st, 0, 4.0 * (double)B * plane * (4 + 1 + 3 + 3 + 1 + 3));
   AS_CHECK_LAUNCH("as_monodepth_loss_bwd(B)");
   return AS_OK;
 }

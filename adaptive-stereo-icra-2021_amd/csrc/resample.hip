@@ -150,8 +150,10 @@ extern "C" int as_upsample_bilinear_fwd(const float* src, int B, int h, int w, f
                                         float gain, void* stream) {
   AS_CHECK_ARG(src && dst && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "as_upsample_bilinear_fwd: bad argument");
   const long n = (long)B * H * W;
+  as_prof_mark(AS_PROF_UPSAMPLE_FWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(upsample_fwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, src, B, h, w,
                      dst, H, W, gain);
+  as_prof_mark(AS_PROF_UPSAMPLE_FWD, (hipStream_t)stream, 0, 4.0 * ((double)B * h * w + (double)B * H * W));
   AS_CHECK_LAUNCH("as_upsample_bilinear_fwd");
   return AS_OK;
 }
@@ -160,8 +162,10 @@ extern "C" int as_upsample_bilinear_bwd(const float* g_dst, int B, int H, int W,
                                         float gain, void* stream) {
   AS_CHECK_ARG(g_dst && g_src && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "as_upsample_bilinear_bwd: bad argument");
   const long n = (long)B * h * w;
+  as_prof_mark(AS_PROF_UPSAMPLE_BWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(as_div_up(n, 4)), dim3(256), 0, (hipStream_t)stream, g_dst, B, H, W,
                      g_src, h, w, gain);
+  as_prof_mark(AS_PROF_UPSAMPLE_BWD, (hipStream_t)stream, 0, 4.0 * ((double)B * h * w + (double)B * H * W));
   AS_CHECK_LAUNCH("as_upsample_bilinear_bwd");
   return AS_OK;
 }
@@ -170,8 +174,10 @@ extern "C" int as_warp_fwd(const float* img, const float* disp, int B, int C, in
                            float* warped, uint8_t* mask, void* stream) {
   AS_CHECK_ARG(img && disp && warped && B > 0 && C > 0 && H > 0 && W > 0, "as_warp_fwd: bad argument");
   const long n = (long)B * H * W;
+  as_prof_mark(AS_PROF_WARP_FWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(warp_fwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, img, disp, B, C, H,
                      W, right_to_left, warped, mask);
+  as_prof_mark(AS_PROF_WARP_FWD, (hipStream_t)stream, 0, (double)B * H * W * (4.0 * (2 * C + 1) + 1.0));
   AS_CHECK_LAUNCH("as_warp_fwd");
   return AS_OK;
 }
@@ -180,8 +186,10 @@ extern "C" int as_warp_bwd(const float* g_warped, const float* img, const float*
                            int right_to_left, float* g_disp, void* stream) {
   AS_CHECK_ARG(g_warped && img && disp && g_disp && B > 0 && C > 0 && H > 0 && W > 0, "as_warp_bwd: bad argument");
   const long n = (long)B * H * W;
+  as_prof_mark(AS_PROF_WARP_BWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, g_warped, img, disp,
                      B, C, H, W, right_to_left, g_disp);
+  as_prof_mark(AS_PROF_WARP_BWD, (hipStream_t)stream, 0, (double)B * H * W * 4.0 * (2 * C + 2));
   AS_CHECK_LAUNCH("as_warp_bwd");
   return AS_OK;
 }

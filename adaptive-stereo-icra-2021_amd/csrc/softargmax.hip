@@ -537,7 +537,10 @@ static const as_conv_shape k333 = {3, 3, 3, 1, 1, 1, 1, 1};
 
 extern "C" int as_conv3d_out_fwd(const float* a, const as_pcl* g, const float* w, const float* bias,
                                  float* logits, void* stream) {
-  return as_conv32to1_fwd(a, g, &k333, w, bias, nullptr, 0, logits, stream);
+  as_prof_mark(AS_PROF_OUTCONV_FWD, (hipStream_t)stream, 1, 0.0);
+  const int e = as_conv32to1_fwd(a, g, &k333, w, bias, nullptr, 0, logits, stream);
+  if (e == AS_OK && g) as_prof_mark(AS_PROF_OUTCONV_FWD, (hipStream_t)stream, 0, (128.0 + 4.0) * (double)g->B * g->D * g->H * g->W);
+  return e;
 }
 
 extern "C" int64_t as_conv3d_out_bwd_workspace(const as_pcl* g) { return as_conv32to1_bwd_workspace(g, &k333); }
@@ -545,7 +548,11 @@ extern "C" int64_t as_conv3d_out_bwd_workspace(const as_pcl* g) { return as_conv
 extern "C" int as_conv3d_out_bwd(const float* g_logits, const float* a, const as_pcl* g, const float* w,
                                  float* g_a, float* g_w, float* g_bias, int accumulate, float* workspace, void* stream) {
   AS_CHECK_ARG(g_a && g_w, "as_conv3d_out_bwd: null pointer");
-  return as_conv32to1_bwd(g_logits, a, g, &k333, w, g_a, g_w, g_bias, accumulate, workspace, stream);
+  as_prof_mark(AS_PROF_OUTCONV_BWD, (hipStream_t)stream, 1, 0.0);
+  const int e = as_conv32to1_bwd(g_logits, a, g, &k333, w, g_a, g_w, g_bias, accumulate, workspace, stream);
+  // data gradient: logits gradient read, g_a written; weight gradient: a and the logits gradient read
+  if (e == AS_OK && g) as_prof_mark(AS_PROF_OUTCONV_BWD, (hipStream_t)stream, 0, (2 * 128.0 + 2 * 4.0) * (double)g->B * g->D * g->H * g->W);
+  return e;
 }
 
 extern "C" int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,
@@ -553,8 +560,10 @@ extern "C" int as_softargmax_fwd(const float* logits, int B, int D, int H, int W
   AS_CHECK_ARG(logits && pred, "as_softargmax_fwd: null pointer");
   AS_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "as_softargmax_fwd: bad shape");
   const long n = (long)B * H * W;
+  as_prof_mark(AS_PROF_SOFTARGMAX_FWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(softargmax_fwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      logits, B, D, (long)H * W, pred, argmax, fcs);
+  as_prof_mark(AS_PROF_SOFTARGMAX_FWD, (hipStream_t)stream, 0, 4.0 * (double)n * (D + 3));
   AS_CHECK_LAUNCH("as_softargmax_fwd");
   return AS_OK;
 }
@@ -564,8 +573,10 @@ extern "C" int as_softargmax_bwd(const float* logits, const float* g_pred, const
   AS_CHECK_ARG(logits && g_logits, "as_softargmax_bwd: null pointer");
   AS_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "as_softargmax_bwd: bad shape");
   const long n = (long)B * H * W;
+  as_prof_mark(AS_PROF_SOFTARGMAX_BWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(softargmax_bwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      logits, g_pred, g_logits_in, B, D, (long)H * W, g_logits);
+  as_prof_mark(AS_PROF_SOFTARGMAX_BWD, (hipStream_t)stream, 0, 4.0 * (double)n * (2 * D + 1 + (g_logits_in ? D : 0)));
   AS_CHECK_LAUNCH("as_softargmax_bwd");
   return AS_OK;
 }

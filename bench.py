@@ -232,7 +232,7 @@ def main():
   if not use_graph:
     t_adapt = min(t_adapt, t_adapt_eager)
   prof = []
-  for kid in (0, 1, 2, 3, 4, 5, 6):
+  for kid in range(24):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     nat.call("as_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
     prof.append((n.value, ms.value, fl.value))
@@ -287,15 +287,27 @@ def main():
     # sums (<3,true>: + read residual, + read the next layer's pre-activation): `traffic` is the mean over that
     # mix, like `achieved`.
     traffic, traffic_detail = None, None
-    pmc = os.path.join(REPO, "profiles", "pmc_conv32_lds.json")
-    if os.path.exists(pmc):
-      rec = json.load(open(pmc))
+    rec = None
+    by_pairs = os.path.join(REPO, "profiles", "r02_pmc_by_pairs.json")     # PMC passes at 1, 2 and 4 pairs per launch
+    if os.path.exists(by_pairs):
+      rec = json.load(open(by_pairs)).get(str(B))
+    if rec is None:
+      pmc = os.path.join(REPO, "profiles", "pmc_conv32_lds.json")
+      if os.path.exists(pmc):
+        rec = json.load(open(pmc))
+        rec = rec if rec.get("pairs_per_launch") == B else None
+    if rec is not None:
       ks = rec.get("kernels", {})
-      if rec.get("pairs_per_launch") == B and "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
+      if "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
         a, b = ks["conv32_lds_kernel<0, false>"], ks["conv32_lds_kernel<3, true>"]
         traffic = int((a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"]) / 2)
-        traffic_detail = {"forward": {"hbm_bytes": a["hbm_bytes_per_launch"], "algorithmic_bytes": a["algorithmic_bytes_per_launch"]},
-                          "dgrad_with_skip_and_bn_sums": {"hbm_bytes": b["hbm_bytes_per_launch"], "algorithmic_bytes": b["algorithmic_bytes_per_launch"]}}
+        traffic_detail = {"pairs_per_launch": rec.get("pairs_per_launch"),
+                          "forward": {"hbm_bytes": a["hbm_bytes_per_launch"], "algorithmic_bytes": a["algorithmic_bytes_per_launch"]},
+                          "dgrad_with_skip_and_bn_sums": {"hbm_bytes": b["hbm_bytes_per_launch"], "algorithmic_bytes": b["algorithmic_bytes_per_launch"]},
+                          "cost_aggregation_3d": {k: {"hbm_bytes": v["hbm_bytes_per_launch"], "algorithmic_bytes": v["algorithmic_bytes_per_launch"],
+                                                      "traffic_over_algorithmic": v["traffic_over_algorithmic"],
+                                                      "mfma_busy": v["mfma_busy_fraction_of_simd_cycles"]}
+                                                  for k, v in ks.items() if k.startswith(("agg3d", "agg_tail", "conv3d"))}}
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
@@ -304,7 +316,9 @@ def main():
                                          entry(6, "conv32_lds_kernel<3,true> (data gradient + skip + stage 1 of the next BatchNorm backward)"))
                              if e is not None],
                 "other_mfma_kernels": [e for e in (entry(3, "conv32_wgrad_lds_kernel"),
-                                                   entry(0, "conv32_fwd_kernel<taps> (3-D, strided, small 2-D)"),
+                                                   entry(7, "agg3d_kernel (a3: rolling-window 3-D aggregation layers and their data gradients)"),
+                                                   entry(9, "conv3d_wgrad_lds_kernel (a3 weight gradient)"),
+                                                   entry(0, "conv32_fwd_kernel<taps> (strided, small 2-D)"),
                                                    entry(1, "conv32_wgrad_kernel<taps>")) if e is not None]}
     # the HBM-bound passes of the step, against the 8 TB/s HBM3E peak (algorithmic bytes / HIP-event time)
     def hbm_entry(i, name):
@@ -318,6 +332,16 @@ def main():
                                                                "them: the 1/16-resolution and cost-volume layers, "
                                                                "launch-latency bound; the full-resolution passes ride "
                                                                "on the matrix-core kernels)")) if e is not None]
+    # the HBM-bound star rows of SURVEY 8 (a2, a4, a5+a8, a6, a9, a10), forward and backward: algorithmic bytes (every
+    # tensor read once + written once) / HIP-event time of the launches of this very run, against 8 TB/s
+    star = [(10, "a2 cost volume fwd"), (11, "a2 cost volume bwd"),
+            (8, "a4+a5+a8 conv3d_alone + soft-argmax + arg-max + FCS fwd (one launch, with layer 4's BatchNorm + LeakyReLU)"),
+            (20, "a4 conv3d_alone fwd (separate launch)"), (21, "a5+a8 soft-argmax + FCS fwd (separate launch)"),
+            (12, "a4 conv3d_alone bwd (data + weight gradient)"), (13, "a5 soft-argmax bwd"),
+            (14, "a6/a7 bilinear up-sampling fwd"), (15, "a6/a7 bilinear up-sampling bwd"),
+            (16, "a9 LinearWarping fwd"), (17, "a9 LinearWarping bwd"),
+            (18, "a10 monodepth loss fwd (image mean + SSIM/L1/smoothness)"), (19, "a10 monodepth loss bwd (two passes)")]
+    roofline["hbm_rows"] = [dict(e, row=nm.split(" ")[0]) for e, nm in ((hbm_entry(i, nm_), nm_) for i, nm_ in star) if e is not None]
 
   out = {
     "metric": "stereo pairs/sec (fwd+adapt-step), KITTI 1242x375 D=192",

@@ -38,18 +38,29 @@ for _ in range(5):
     nat.call("as_conv32_wgrad_bnapply", nat.ptr(x), g, nat.ptr(gx), nat.ptr(zb), g, shape, nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gzo), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
   nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(z), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
-# a3: one 3-D cost-aggregation layer (forward + weight gradient), 4 pairs
+# a3: one 3-D cost-aggregation layer: rolling-window forward (plain, with moments, with the previous BatchNorm merged and
+# applied in LDS + by-product), the fused tail (a4 + a5 + a8) and the LDS weight gradient
 g3 = Pcl(B, 12, 24, 78, 1, 1, 1)
 x3 = torch.randn(g3.numel(), device=dev) * 0.5
 x3v = ops.pcl_view(x3, g3).clone(); ops.pcl_interior(x3v, g3).zero_(); x3 = x3 - x3v.view(-1)
 w3 = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.03
 wp3 = ops.pack_weights(w3, ops.CONV3D_333, False)
-z3 = torch.zeros(g3.numel(), device=dev)
-st3 = ops.conv32_stat_parts(g3, g3, ops.CONV3D_333, dev)
+z3, z3b, a3 = torch.zeros(g3.numel(), device=dev), torch.zeros(g3.numel(), device=dev), torch.zeros(g3.numel(), device=dev)
+nparts = lib.as_agg3d_parts(g3)
 ws3 = torch.empty(nat.load().as_conv32_wgrad_workspace(g3, g3, ops.CONV3D_333), device=dev)
 dW3 = torch.empty_like(w3)
+w1 = torch.randn(1, 32, 3, 3, 3, device=dev) * 0.03
+logits = torch.empty(B, 12, 24, 78, device=dev); pred = torch.empty(B, 24, 78, device=dev)
+am = torch.empty(B, 24, 78, dtype=torch.int32, device=dev); fcs = torch.empty(B, 24, 78, device=dev)
 for _ in range(5):
-  ops.conv32(x3, g3, wp3, b, g3, ops.CONV3D_333, out=z3, stats=st3)
+  ops.agg3d(x3, g3, wp3, None, z=z3, epilogue=2)                                   # agg3d_kernel<0, 2>: data gradient flavour
+  pend = ops.PendingBn(ops.StatParts(nparts, dev), gam, torch.zeros(32, device=dev), torch.zeros(32, device=dev), torch.ones(32, device=dev))
+  ops.agg3d(x3, g3, wp3, b, z=z3, stats=pend.stats)                                # agg3d_kernel<0, 0>: layer 1
+  st2 = ops.StatParts(nparts, dev)
+  ops.agg3d(z3, g3, wp3, b, z=z3b, in_bn=pend, a_out=a3, stats=st2)                # agg3d_kernel<2, 0>: layers 2-4
+  pend2 = ops.PendingBn(st2, gam, torch.zeros(32, device=dev), torch.zeros(32, device=dev), torch.ones(32, device=dev))
+  nat.call("as_agg_tail_fwd", nat.ptr(z3b), g3, None, None, pend2.block, nat.ptr(a3), nat.ptr(w1), None, 0.2,
+           nat.ptr(logits), nat.ptr(pred), nat.ptr(am), nat.ptr(fcs), nat.stream())  # agg_tail_kernel<2, 8, true>
   nat.call("as_conv32_wgrad", nat.ptr(x3), g3, nat.ptr(z3), g3, ops.CONV3D_333, nat.ptr(dW3), nat.ptr(db), 0, nat.ptr(ws3), nat.stream())
 torch.cuda.synchronize()
 print("done")

@@ -1,0 +1,11 @@
+"""Merges gpurun_out/pmc_<tag>_p{1,2,4}.json (tests/tools/pmc_run.sh <tag>_p<N> <N>) into one file keyed by pairs per launch.
+usage: python tests/tools/pmc_merge.py <tag> <out.json>"""
+import json, os, sys
+tag, out = sys.argv[1], sys.argv[2]
+merged = {}
+for n in (1, 2, 4):
+  path = "gpurun_out/pmc_%s_p%d.json" % (tag, n)
+  if os.path.exists(path):
+    merged[str(n)] = json.load(open(path))
+json.dump(merged, open(out, "w"), indent=1)
+print({k: sorted(v["kernels"].keys()) for k, v in merged.items()})

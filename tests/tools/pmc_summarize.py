@@ -1,5 +1,5 @@
 """Summarises the three rocprofv3 --pmc passes of tests/tools/pmc_conv.py into profiles/pmc_conv32_lds.json.
-usage: python tests/tools/pmc_summarize.py <sq.csv> <fetch.csv> <write.csv> <out.json>
+usage: python tests/tools/pmc_summarize.py <sq.csv> <fetch.csv> <write.csv> <out.json> [pairs per launch, default 4]
 HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3): on gfx950 FETCH_SIZE tallies 64 B per 128-B request
 of a wide coalesced stream -> read bytes = 2 x FETCH_SIZE(KB) x 1024; WRITE_SIZE(KB) x 1024 is exact.
 MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles): MFMA_BUSY is the chip-wide sum
@@ -14,7 +14,8 @@ def load(path):
   return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 sq, fe, wr = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
-B, H, W = 4, 375, 1242
+B = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+H, W = 375, 1242
 vox = B * H * W
 flops = 2.0 * vox * 1024 * 9
 vox3 = B * 12 * 24 * 78
@@ -23,8 +24,11 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv32_wgrad_lds_kernel": 2 * vox * 128, "conv32_wgrad_lds2_kernel<false>": 2 * vox * 128,
        "conv32_wgrad_lds2_kernel<true>": 4 * vox * 128,        # x, g_a, z read; g_z written (fused BN-backward apply)
        "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128,
-       "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128}
-out = {"shape": "2-D 3x3 stride 1, 32->32, 4 pairs x 375x1242 (one full-resolution refinement layer)",
+       "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128,
+       "agg3d_kernel<0, 2>": 2 * vox3 * 128 + 27 * 4096, "agg3d_kernel<0, 0>": 2 * vox3 * 128 + 27 * 4096,
+       "agg3d_kernel<2, 0>": 3 * vox3 * 128 + 27 * 4096,      # raw operand read, activated by-product and output written
+       "agg_tail_kernel<2, 8, true>": 2 * vox3 * 128 + vox3 * 4}
+out = {"shape": "2-D 3x3 stride 1, 32->32, %d pair(s) x 375x1242 (one full-resolution refinement layer); 3-D rows: 12x24x78 per pair" % B,
        "pairs_per_launch": B, "algorithmic_flops_per_launch": flops,
        "command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 tests/tools/pmc_conv.py   (separate passes: SQ_* ; FETCH_SIZE ; WRITE_SIZE GRBM_GUI_ACTIVE)",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams -> read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM); WRITE_SIZE x 1024 exact.",
