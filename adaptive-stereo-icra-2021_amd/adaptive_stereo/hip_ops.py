@@ -542,7 +542,28 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
   data gradient and returned as next_sums (None when not available)."""
   sw, sb, sg, sbeta = sinks if sinks is not None else (None, None, None, None)
   lib = nat.load()
-  if sw is not None and sb is not None and sg is not None and sbeta is not None and \
+  all_sunk = sw is not None and sb is not None and sg is not None and sbeta is not None
+  if _BWD_FUSED and all_sunk and skip and need_dx and train and next_bn is not None and _BN_SYNC is None and \
+      lib.as_conv32_bwd_fused_ok(g, g, shape) == 1:
+    # the whole backward of the layer in ONE launch (csrc/conv32_bwd.hip): stages 1-2 of its BatchNorm backward first
+    # (stage 1 usually already in `sums`), then stage 3 + data gradient + skip + weight/bias gradient + stage 1 of the
+    # next BatchNorm backward; g_z never leaves the chip
+    dev = z.device
+    ws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
+    bn_bwd_coefs(g_out, z, st, gamma, g, train, sg, sbeta, True, ws, sums)
+    coef = ws[lib.as_bn_bwd_coef_offset():]
+    wp_t = pack_weights(w, shape, True)
+    g_x = POOL.get(g, dev)
+    nws = _empty(lib.as_bn_bwd_workspace(g), dev)
+    wws = _empty(lib.as_conv32_bwd_fused_workspace(), dev)
+    next_z, next_st = next_bn
+    _rmw_wait(sw)
+    call("as_conv32_bwd_fused", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(wp_t), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+         ptr(coef), LEAKY_SLOPE, ptr(next_z), ptr(next_st.scale), ptr(next_st.shift), ptr(next_st.mean), ptr(g_x), ptr(sw),
+         ptr(sb), 1, ptr(nws), ptr(wws), stream())
+    _rmw_done(sw)
+    return g_x, None, None, None, None, BnBwdSums(nws, lib.as_conv32_bwd_fused_parts())
+  if all_sunk and \
       lib.as_conv32_wgrad_bnapply_ok(g, g, shape) == 1:
     # stages 1-2 of the BatchNorm backward only (stage 1 may already be in `sums`); stage 3 rides on the weight gradient,
     # which stages g_out and z rows, applies it in LDS, accumulates dW / db and writes g_z for the data gradient
@@ -582,6 +603,10 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
 # ----------------------------------------------------------------------------------------
 _AGG3D = True            # False: the first-generation path (conv3d_lds + finalize + element-wise pass per layer)
 _AGG_TAIL = True         # False: conv3d_alone and the soft-argmax as two launches (conv32to1_fwd + softargmax_fwd)
+_BWD_FUSED = True        # False: a full-resolution layer's backward as two launches (wgrad + BN stage 3 | dgrad + BN stage 1)
+import os as _os
+if _os.environ.get("AS_BWD_FUSED") == "0":      # A/B measurements only
+  _BWD_FUSED = False
 
 
 def set_agg3d(flag: bool):
@@ -589,6 +614,12 @@ def set_agg3d(flag: bool):
   (A/B measurements and parity tests); returns the previous setting."""
   global _AGG3D
   prev, _AGG3D = _AGG3D, bool(flag)
+  return prev
+
+
+def set_bwd_fused(flag: bool):
+  global _BWD_FUSED
+  prev, _BWD_FUSED = _BWD_FUSED, bool(flag)
   return prev
 
 

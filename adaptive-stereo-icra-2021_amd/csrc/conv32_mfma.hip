@@ -28,6 +28,7 @@
 #include "conv_epilogue.h"
 #include "conv32_lds.h"
 #include "conv3d_lds.h"
+#include "conv32_bwd.h"
 
 static bool wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 
@@ -494,6 +495,43 @@ extern "C" int as_conv32_wgrad_bnapply(const float* x, const as_pcl* gin, const 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
                      workspace, partial_db, slabs, T, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv32_wgrad_bnapply(reduce)");
+  return AS_OK;
+}
+
+// Whole backward of a full-resolution layer in one launch (conv32_bwd.hip): stage 3 of its BatchNorm backward, data gradient
+// + skip connection, weight / bias gradient, stage 1 of the next BatchNorm backward.
+extern "C" int as_conv32_bwd_fused_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
+  return conv32_bwd_fused_applicable(gin, gout, s) ? 1 : 0;
+}
+extern "C" int as_conv32_bwd_fused_parts(void) { return conv32_bwd_fused_slabs(); }
+extern "C" int64_t as_conv32_bwd_fused_workspace(void) { return (int64_t)conv32_bwd_fused_slabs() * (9 * 1024 + 32); }
+
+extern "C" int as_conv32_bwd_fused(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                                   const as_conv_shape* s, const float* packed_wt, const float* scale, const float* shift,
+                                   const float* mean, const float* coef, float slope, const float* next_z,
+                                   const float* next_scale, const float* next_shift, const float* next_mean, float* g_x,
+                                   float* dW, float* db, int accumulate, float* next_bn_workspace, float* workspace,
+                                   void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_bwd_fused")) return e;
+  AS_CHECK_ARG(x && g_a && z && packed_wt && scale && shift && mean && coef && next_z && next_scale && next_shift && next_mean &&
+               g_x && dW && next_bn_workspace && workspace, "as_conv32_bwd_fused: null pointer");
+  AS_CHECK_ARG(conv32_bwd_fused_applicable(gin, gout, s), "as_conv32_bwd_fused: configuration not supported (as_conv32_bwd_fused_ok() == 0)");
+  AS_CHECK_ARG(((uintptr_t)next_bn_workspace & 7) == 0, "as_conv32_bwd_fused: the BatchNorm workspace must be 8-byte aligned");
+  AS_CHECK_ARG(g_x != g_a && g_x != x && g_x != z, "as_conv32_bwd_fused: g_x must not alias an input");
+  const int T = 9;
+  const int slabs = conv32_bwd_fused_slabs();
+  float* partial_db = workspace + (int64_t)slabs * T * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(AS_PROF_BWD_FUSED, st, 1, 0.0);
+  if (int e = conv32_bwd_fused_launch(x, g_a, z, gout, s, packed_wt, scale, shift, mean, coef, slope, next_z, next_scale,
+                                      next_shift, next_mean, g_x, workspace, partial_db,
+                                      reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
+  as_prof_mark(AS_PROF_BWD_FUSED, st, 0, 2.0 * 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);   // dgrad + wgrad
+  AS_CHECK_LAUNCH("as_conv32_bwd_fused");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
+                     workspace, partial_db, slabs, T, dW, db, accumulate);
+  AS_CHECK_LAUNCH("as_conv32_bwd_fused(reduce)");
   return AS_OK;
 }
 

@@ -100,6 +100,25 @@ int as_conv32_fwd(const float* x, const as_pcl* gin, const float* packed_w, cons
                   float* z, const as_pcl* gout, const as_conv_shape* s,
                   int epilogue, const float* ep_scale, const float* ep_shift, float slope,
                   const float* residual, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream);
+/* ---- whole backward of a full-resolution refinement layer in ONE launch (csrc/conv32_bwd.hip): nn.Conv2d(32,32,3,dilation) +
+ * BatchNorm2d + LeakyReLU + skip connection of a BasicBlock (stereo_net.py:10-18,33-51,97).  Replaces
+ * as_conv32_wgrad_bnapply followed by as_conv32_fwd_bnbwd; g_z never leaves the chip.
+ *   x, g_a, z, next_z, g_x   PCL tensors of ONE padded geometry (gin == gout; as_conv32_bwd_fused_ok() == 1)
+ *   packed_wt                as_conv32_pack_weights(..., transpose_flip = 1)
+ *   scale, shift, mean, coef the layer's BatchNorm state and the stage-3 coefficients [96] (as_bn_act_bwd(_given) with
+ *                            g_z = NULL leaves them at workspace + as_bn_bwd_coef_offset())
+ *   next_*                   the BatchNorm whose output gradient g_x is: its stage-1 sums go to next_bn_workspace
+ *                            (as_bn_bwd_workspace floats; as_conv32_bwd_fused_parts() partials, for as_bn_act_bwd_given)
+ *   dW [32,32,3,3], db [32]  set or accumulated; workspace: as_conv32_bwd_fused_workspace() floats */
+int as_conv32_bwd_fused_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+int as_conv32_bwd_fused_parts(void);
+int64_t as_conv32_bwd_fused_workspace(void);
+int as_conv32_bwd_fused(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                        const as_conv_shape* s, const float* packed_wt, const float* scale, const float* shift,
+                        const float* mean, const float* coef, float slope, const float* next_z,
+                        const float* next_scale, const float* next_shift, const float* next_mean, float* g_x,
+                        float* dW, float* db, int accumulate, float* next_bn_workspace, float* workspace, void* stream);
+
 /* ---- a3, second generation: one 3x3x3 stride-1 32->32 aggregation layer (stereo_net.py:21-30,155-161,185-186) or its data
  * gradient, walking down the disparity axis with a rolling window of planes in LDS (csrc/agg3d.hip).
  *   x, z, a_out      PCL tensors of geometry g (halo 1 in d, h, w; as_agg3d_ok(g) == 1)

@@ -917,3 +917,74 @@ def test_agg_tail_ties_and_extremes():
   assert bool(torch.isfinite(pred).all())
   close(pred, orc.soft_argmax(l), 2e-5, 1e-5, "soft-argmax")
   close(fcs, orc.feature_contrast_mean(l), 1e-5, 1e-5, "fcs")
+
+
+# ----------------------------------------------------------------------------- a7 backward in one launch (csrc/conv32_bwd.hip)
+@pytest.mark.parametrize("B,H,W,dil", [(2, 160, 1242, 1), (2, 161, 1242, 2), (1, 375, 1030, 4), (2, 163, 1237, 8)])
+def test_conv32_backward_fused_in_one_launch(B, H, W, dil):
+  """as_conv32_bwd_fused — stage 3 of the layer's BatchNorm backward, data gradient + skip connection, weight / bias
+  gradient and stage 1 of the next BatchNorm backward from ONE staged copy — against the two-launch path
+  (as_conv32_wgrad_bnapply, then as_conv32_fwd_bnbwd): g_x bit for bit where the arithmetic is the same chain, the weight
+  gradient and the per-channel sums to summation order.  Ragged last segment, every dilation, comb residues that do not
+  divide H."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_bwd_fused_ok(g, g, shape) == 1
+  x = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=1).to(DEV), g)
+  g_a = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=2).to(DEV), g)
+  z = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=3).to(DEV), g)
+  zn = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=4).to(DEV), g)
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  wp_t = ops.pack_weights(w, shape, True)
+
+  def state(seed):
+    st = ops.BnState(DEV)
+    st.mean.copy_(rnd(32, seed=seed).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=seed + 1).abs().to(DEV) + 0.5)
+    gamma = (rnd(32, seed=seed + 2).abs() + 0.5).to(DEV)
+    st.scale.copy_(st.invstd * gamma); st.shift.copy_(rnd(32, seed=seed + 3).to(DEV) * 0.1 - st.mean * st.scale)
+    return st, gamma
+  st, gamma = state(5)
+  stn, gamman = state(15)
+  # stages 1-2 of this layer's BatchNorm backward: coefficients for stage 3
+  ws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  gg, gb = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+  nat.call("as_bn_act_bwd", nat.ptr(g_a), nat.ptr(z), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(st.mean),
+           nat.ptr(st.invstd), nat.ptr(gamma), 0.2, 1, None, nat.ptr(gg), nat.ptr(gb), 0, nat.ptr(ws), g, nat.stream())
+  coef = ws[lib.as_bn_bwd_coef_offset():]
+  # two launches
+  gz = ops.pcl_zeros(g, DEV)
+  dW_ref = torch.zeros(32, 32, 3, 3, device=DEV); db_ref = torch.zeros(32, device=DEV)
+  wws = torch.empty(lib.as_conv32_wgrad_workspace(g, g, shape), device=DEV)
+  nat.call("as_conv32_wgrad_bnapply", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(z), g, shape, nat.ptr(st.scale), nat.ptr(st.shift),
+           nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gz), nat.ptr(dW_ref), nat.ptr(db_ref), 0, nat.ptr(wws), nat.stream())
+  gx_ref, sums_ref = ops.conv32_dgrad_bnbwd(gz, g, wp_t, shape, g_a, zn, stn)
+  _, ggn_ref, gbn_ref = ops.bn_act_bwd(gx_ref, zn, stn, gamman, g, True, sums=sums_ref)
+  # one launch
+  gx = ops.pcl_zeros(g, DEV)
+  dW = torch.zeros(32, 32, 3, 3, device=DEV); db = torch.zeros(32, device=DEV)
+  nws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  fws = torch.empty(lib.as_conv32_bwd_fused_workspace(), device=DEV)
+  nat.call("as_conv32_bwd_fused", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(z), g, shape, nat.ptr(wp_t), nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(stn.scale), nat.ptr(stn.shift),
+           nat.ptr(stn.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(nws), nat.ptr(fws), nat.stream())
+  tag = "B%d H%d W%d d%d" % (B, H, W, dil)
+  full = ops.pcl_view(gx, g).clone(); ops.pcl_interior(full, g).zero_()
+  assert float(full.abs().max()) == 0.0, tag + ": wrote into the halo"
+  gi, gi_ref = ops.pcl_interior(ops.pcl_view(gx, g), g), ops.pcl_interior(ops.pcl_view(gx_ref, g), g)
+  close(gi, gi_ref, 2e-6, 1e-6, tag + " g_x")
+  exact = bool(torch.equal(gi, gi_ref))
+  n = B * H * W
+  for name, got, exp in ((" dW", dW, dW_ref), (" db", db, db_ref)):
+    rel = float((got.double() - exp.double()).norm() / exp.double().norm())
+    assert rel < 2e-5, "%s%s: relative L2 error %.2e" % (tag, name, rel)
+  _, ggn, gbn = ops.bn_act_bwd(gx, zn, stn, gamman, g, True, sums=ops.BnBwdSums(nws, lib.as_conv32_bwd_fused_parts()))
+  close(ggn, ggn_ref, 2e-6 * n ** 0.5 * float(ggn_ref.abs().max()) + 1e-5, 1e-5, tag + " next g_gamma")
+  close(gbn, gbn_ref, 2e-6 * n ** 0.5 * float(gbn_ref.abs().max()) + 1e-5, 1e-5, tag + " next g_beta")
+  # accumulate flavour: a second launch adds the same gradient again
+  nat.call("as_conv32_bwd_fused", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(z), g, shape, nat.ptr(wp_t), nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(stn.scale), nat.ptr(stn.shift),
+           nat.ptr(stn.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 1, nat.ptr(nws), nat.ptr(fws), nat.stream())
+  close(dW, 2 * dW_ref, 1e-4 * float(dW_ref.abs().max()), 1e-4, tag + " accumulated dW")
+  from conftest import parity_note
+  parity_note("bwd_fused[%s]" % tag, g_x_bit_identical=exact)
