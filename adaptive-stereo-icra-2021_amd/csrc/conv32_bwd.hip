@@ -54,7 +54,7 @@ struct BwdArgs {
   float* partial_db;       // [BW_GRID][32]
   double* n_partial;       // [BW_GRID][64]: sum g_y, sum g_y*(z-mean) of the next BatchNorm
   PclDev g;
-  int dil, nseg, chunk_rows, nchunks, units;
+  int dil, nseg;
   float slope;
 #ifdef BW_TIMING_BUILD
   long long* timing;       // diagnostic build only: [workgroup][wave][8] cycle counts per phase
@@ -154,17 +154,23 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
   long long tlast = clock64();
   const long long wall0 = wall_clock64();
 #endif
-  for (int unit = blockIdx.x; unit < p.units; unit += gridDim.x) {
+  // Work split: the launch's tiles in one line — (pair, segment) blocks of H rows, inside a block the combs r = 0..d-1 one
+  // after the other — cut into gridDim.x equal ranges; a workgroup walks the one to three comb pieces of its range (each
+  // piece pays a run-in of three row conversions).  Round-robin units of equal row count, the first plan, left 6-22 % of
+  // the workgroup slots idle (4 pairs: 480 units of 63 rows on 512 slots).
+  const long t_total = (long)p.g.B * p.nseg * H;
+  long t_next = t_total * blockIdx.x / gridDim.x;
+  const long t_end = t_total * (blockIdx.x + 1) / gridDim.x;
+  while (t_next < t_end) {
     BW_T(0);
-    // unit -> (pair b, segment, residue r, chunk c of the comb)
-    int t = unit;
-    const int c = t % p.nchunks; t /= p.nchunks;
-    const int r0 = t % d; t /= d;
-    const int seg = t % p.nseg;
-    const int b = t / p.nseg;
-    const int nrow = (H - r0 + d - 1) / d;                // rows of this comb
-    const int j0 = c * p.chunk_rows, j1 = min(j0 + p.chunk_rows, nrow);
-    if (j0 >= j1) continue;                                // (workgroup-uniform)
+    const int blk = (int)(t_next / H);
+    int j0 = (int)(t_next - (long)blk * H);
+    int r0 = 0, nrow = (H + d - 1) / d;                   // rows of comb r0
+    while (j0 >= nrow) { j0 -= nrow; ++r0; nrow = (H - r0 + d - 1) / d; }
+    const int j1 = (int)min((long)nrow, j0 + (t_end - t_next));
+    t_next += j1 - j0;
+    const int seg = blk % p.nseg;
+    const int b = blk / p.nseg;
     const int x_new = 64 * seg;
     const int x0 = min(x_new, W - 64);
     const long img = (long)b * p.g.Hp;                     // padded row index base of pair b
@@ -266,6 +272,7 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
             const int tp = (cc + 3) >> 2;
             a[(cc + 3) & 3] = bw_chunk(rows[tp / 3], vbase + (tp % 3 - 1) * d, h, (cc + 3) & 3);
           }
+#ifndef BW_EXP_NOEPI
           if (cc == 4) {
 #define BW_LD(r) bw_load_imm<BW_ROW_IMM(r)>(res[r], res_base, io_off);
             BW_FOR_ROWS(BW_LD)
@@ -276,6 +283,7 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
             BW_FOR_ROWS(BW_LD)
 #undef BW_LD
           }
+#endif
           __builtin_amdgcn_sched_barrier(0);
           const f32x4 av = a[cc & 3];
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, R[cc >> 2][4 * (cc & 3) + 0], acc, 0, 0, 0);
@@ -285,8 +293,15 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
           __builtin_amdgcn_sched_barrier(0);
         }
         BW_T(2);
+#ifndef BW_EXP_NOB1
         __syncthreads();                                   // B1
+#endif
         BW_T(3);
+#ifdef BW_EXP_NOEPI
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bn_dy += acc[r];
+#else
         // the x row of the next tile, the skip-connection row and the next layer's pre-activation row are home
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]),
@@ -305,8 +320,11 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
                    bn_dy += gy; bn_dx = fmaf(gy, zt[r] - bn_mu, bn_dx); }
         BW_FOR_ROWS(BW_ST)
 #undef BW_ST
+#endif
       } else {
+#ifndef BW_EXP_NOCONV
         fetch_row(j + 2);                                  // in flight during the matrix phase
+#endif
         // ---- weight gradient: acc[kh*3+kw][ci][co] += sum_u x[y][u][ci] * g_z[y-(kh-1)d][u-(kw-1)d][co] ----
         const int u0 = 8 + 32 * half + h;                                   // voxel of step 0 in the staged g_z rows
         const char* xaddr = smem + BW_X_OFF + (j & 1) * BW_XROW_BYTES + (u0 - 8) * 128 + li * 4;
@@ -338,9 +356,13 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
           __builtin_amdgcn_sched_barrier(0);
         }
         BW_T(2);
+#ifndef BW_EXP_NOB1
         __syncthreads();                                   // B1: nobody reads row j-1's slot any more
+#endif
         BW_T(3);
+#ifndef BW_EXP_NOCONV
         convert_row(j + 2);
+#endif
       }
       BW_T(4);
       __syncthreads();                                     // B2: g_z row j+2 and x row j+1 are in place
@@ -416,40 +438,6 @@ bool conv32_bwd_fused_applicable(const as_pcl* gin, const as_pcl* gout, const as
   return (long)gout->B * gout->H * ((gout->W + 63) / 64) >= (long)BW_GRID * 12;
 }
 
-// Units are dealt round-robin (unit u -> workgroup u % BW_GRID), so what a launch costs is the LARGEST number of rows any
-// workgroup walks (its tiles + three run-in conversions per unit).  The first plan ("about three units per workgroup":
-// 1600 units of 19 rows at 4 pairs -> some workgroups walk four units, the average is 3.1) left 22 % of the chip idle at
-// the end; this one tries every chunk count and keeps the cheapest deal.
-static void bwd_plan(const as_pcl* g, int dil, int* nseg, int* chunk_rows, int* nchunks) {
-  *nseg = (g->W + 63) / 64;
-  const int combs_per_res = g->B * *nseg;
-  const int nrow_max = (g->H + dil - 1) / dil;
-  long best_cost = -1;
-  int best_rows = nrow_max, best_nc = 1;
-  static thread_local long load[BW_GRID];
-  for (int nc = 1; nc <= nrow_max; ++nc) {
-    const int rows = (nrow_max + nc - 1) / nc;
-    if (rows < 6 && nc > 1) break;                        // run-in would exceed a third of the staging
-    const int nch = (nrow_max + rows - 1) / rows;
-    if (nch != nc) continue;                              // same split as a smaller chunk count
-    for (int i = 0; i < BW_GRID; ++i) load[i] = 0;
-    long unit = 0;                                        // same order as the kernel decodes: chunk fastest, then residue, segment, pair
-    for (int bs = 0; bs < combs_per_res; ++bs)
-      for (int r = 0; r < dil; ++r) {
-        const int nrow = (g->H - r + dil - 1) / dil;
-        for (int c = 0; c < nch; ++c, ++unit) {
-          const int j0 = c * rows, j1 = (j0 + rows < nrow) ? j0 + rows : nrow;
-          if (j1 > j0) load[unit % BW_GRID] += (j1 - j0) + 3;
-        }
-      }
-    long mx = 0;
-    for (int i = 0; i < BW_GRID; ++i) mx = load[i] > mx ? load[i] : mx;
-    if (best_cost < 0 || mx < best_cost) { best_cost = mx; best_rows = rows; best_nc = nch; }
-  }
-  *chunk_rows = best_rows;
-  *nchunks = best_nc;
-}
-
 int conv32_bwd_fused_slabs(void) { return BW_GRID; }
 
 int conv32_bwd_fused_launch(const float* x, const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s,
@@ -470,8 +458,7 @@ int conv32_bwd_fused_launch(const float* x, const float* g_a, const float* z, co
   a.gx = g_x; a.partial = partial; a.partial_db = partial_db; a.n_partial = next_partial;
   a.g = as_make_dev(g);
   a.dil = s->dil; a.slope = slope;
-  bwd_plan(g, s->dil, &a.nseg, &a.chunk_rows, &a.nchunks);
-  a.units = g->B * a.nseg * s->dil * a.nchunks;
+  a.nseg = (g->W + 63) / 64;
 #ifdef BW_TIMING_BUILD
   static long long* timing_buf = nullptr;
   const size_t timing_bytes = (size_t)BW_GRID * 4 * 8 * 8;

@@ -278,14 +278,17 @@ def main():
       return None
     return {"kernel": "conv32_lds_kernel", "achieved": round(fl_f / (ms_f * 1e-3) / 1e12, 3), "launches": n_f,
             "avg_launch_us": round(1e3 * ms_f / n_f, 2), "flops_per_launch": fl_f / n_f}
-  dom = entry_family()
+  fam_entry = entry_family()
+  fused_entry = entry(22, "conv32_bwd_fused_kernel")
+  # the dominant kernel is the one a step spends most time in: since the full-resolution backward is one launch
+  # (conv32_bwd_fused_kernel, id 22: data gradient + weight gradient = 2 x the forward's FLOPs per launch) that is it
+  fused_is_dom = fused_entry is not None and (fam_entry is None or prof[22][1] > ms_f)
+  dom = fused_entry if fused_is_dom else fam_entry
   roofline = None
   if dom is not None:
-    # HBM bytes per launch from the committed PMC passes (profiles/pmc_conv32_lds.json; FETCH_SIZE / WRITE_SIZE
-    # corrected as MI355X_MICROARCH.md prescribes).  A step launches the kernel as 6 training forwards
-    # (<0,false>: read x, write z) and 6 data gradients with the skip connection and the fused BatchNorm-backward
-    # sums (<3,true>: + read residual, + read the next layer's pre-activation): `traffic` is the mean over that
-    # mix, like `achieved`.
+    # HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_by_pairs.json, keyed by pairs per launch;
+    # FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes).  `traffic` is the dominant kernel's; the
+    # forward / data-gradient flavours of conv32_lds_kernel and the 3-D kernels are in traffic_detail.
     traffic, traffic_detail = None, None
     rec = None
     by_pairs = os.path.join(REPO, "profiles", "r02_pmc_by_pairs.json")     # PMC passes at 1, 2 and 4 pairs per launch
@@ -298,21 +301,26 @@ def main():
         rec = rec if rec.get("pairs_per_launch") == B else None
     if rec is not None:
       ks = rec.get("kernels", {})
-      if "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
-        a, b = ks["conv32_lds_kernel<0, false>"], ks["conv32_lds_kernel<3, true>"]
-        traffic = int((a["hbm_bytes_per_launch"] + b["hbm_bytes_per_launch"]) / 2)
-        traffic_detail = {"pairs_per_launch": rec.get("pairs_per_launch"),
-                          "forward": {"hbm_bytes": a["hbm_bytes_per_launch"], "algorithmic_bytes": a["algorithmic_bytes_per_launch"]},
-                          "dgrad_with_skip_and_bn_sums": {"hbm_bytes": b["hbm_bytes_per_launch"], "algorithmic_bytes": b["algorithmic_bytes_per_launch"]},
-                          "cost_aggregation_3d": {k: {"hbm_bytes": v["hbm_bytes_per_launch"], "algorithmic_bytes": v["algorithmic_bytes_per_launch"],
-                                                      "traffic_over_algorithmic": v["traffic_over_algorithmic"],
-                                                      "mfma_busy": v["mfma_busy_fraction_of_simd_cycles"]}
-                                                  for k, v in ks.items() if k.startswith(("agg3d", "agg_tail", "conv3d"))}}
+      def pmc_row(k):
+        v = ks.get(k)
+        return None if v is None else {"hbm_bytes": v["hbm_bytes_per_launch"], "algorithmic_bytes": v["algorithmic_bytes_per_launch"],
+                                       "traffic_over_algorithmic": v["traffic_over_algorithmic"],
+                                       "mfma_busy": v["mfma_busy_fraction_of_simd_cycles"]}
+      if fused_is_dom and "conv32_bwd_fused_kernel" in ks:
+        traffic = int(ks["conv32_bwd_fused_kernel"]["hbm_bytes_per_launch"])
+      elif not fused_is_dom and "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
+        traffic = int((ks["conv32_lds_kernel<0, false>"]["hbm_bytes_per_launch"] + ks["conv32_lds_kernel<3, true>"]["hbm_bytes_per_launch"]) / 2)
+      traffic_detail = {"pairs_per_launch": rec.get("pairs_per_launch"),
+                        "backward_fused": pmc_row("conv32_bwd_fused_kernel"),
+                        "forward": pmc_row("conv32_lds_kernel<0, false>"),
+                        "dgrad_with_skip_and_bn_sums": pmc_row("conv32_lds_kernel<3, true>"),
+                        "cost_aggregation_3d": {k: pmc_row(k) for k in ks if k.startswith(("agg3d", "agg_tail", "conv3d"))}}
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
                 "flops_per_launch": dom["flops_per_launch"], "traffic_detail": traffic_detail,
-                "flavours": [e for e in (entry(2, "conv32_lds_kernel<0,false> (training forward: raw output + BatchNorm moments)"),
+                "flavours": [e for e in (entry(22, "conv32_bwd_fused_kernel (full-resolution layer backward in one launch: BatchNorm-backward apply, data gradient + skip, weight gradient, next BatchNorm's sums)"),
+                                         entry(2, "conv32_lds_kernel<0,false> (training forward: raw output + BatchNorm moments)"),
                                          entry(6, "conv32_lds_kernel<3,true> (data gradient + skip + stage 1 of the next BatchNorm backward)"))
                              if e is not None],
                 "other_mfma_kernels": [e for e in (entry(3, "conv32_wgrad_lds_kernel"),

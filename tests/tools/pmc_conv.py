@@ -26,6 +26,8 @@ gam = torch.ones(32, device=dev)
 bws = torch.empty(lib.as_bn_bwd_workspace(g), device=dev)
 coef = bws[lib.as_bn_bwd_coef_offset():]; coef.zero_(); coef[64:96] = 1.0
 gzo = torch.zeros(g.numel(), device=dev)
+bws2 = torch.empty(lib.as_bn_bwd_workspace(g), device=dev)
+fws = torch.empty(lib.as_conv32_bwd_fused_workspace(), device=dev)
 zb = x.clone()            # a distinct buffer for the next layer's pre-activation (a shared one would be read from HBM once)
 for _ in range(5):
   ops.conv32(x, g, wp, b, g, shape, out=z, stats=stats)              # conv32_lds_kernel<0,false>: training forward
@@ -38,6 +40,12 @@ for _ in range(5):
     nat.call("as_conv32_wgrad_bnapply", nat.ptr(x), g, nat.ptr(gx), nat.ptr(zb), g, shape, nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gzo), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
   nat.call("as_conv32_wgrad", nat.ptr(x), g, nat.ptr(z), g, shape, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
+  # conv32_bwd_fused_kernel: the whole backward of a full-resolution layer in one launch (what a step launches when
+  # as_conv32_bwd_fused_ok): x, g_a (= gzo here), z, z_next read, g_x written
+  if lib.as_conv32_bwd_fused_ok(g, g, shape) == 1:
+    nat.call("as_conv32_bwd_fused", nat.ptr(x), g, nat.ptr(gzo), nat.ptr(z), g, shape, nat.ptr(wpt), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zb), nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(st.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(bws2), nat.ptr(fws), nat.stream())
 # a3: one 3-D cost-aggregation layer: rolling-window forward (plain, with moments, with the previous BatchNorm merged and
 # applied in LDS + by-product), the fused tail (a4 + a5 + a8) and the LDS weight gradient
 g3 = Pcl(B, 12, 24, 78, 1, 1, 1)
