@@ -4,6 +4,7 @@ Each Function is a hand-written forward AND backward: autograd only stitches the
 together.  Nothing here computes on the CPU; every call goes through
 ``_native.call`` on the current HIP stream with raw device pointers.
 """
+import os
 import torch
 
 from . import _native as nat
@@ -102,6 +103,9 @@ class PclPool(object):
   def put(self, buf, g: Pcl, channels=32):
     if buf is None:
       return
+    if buf.data_ptr() in _WgradSide.held:                # still being read by a weight gradient on the side stream
+      _WgradSide.deferred.append((buf, g, channels))
+      return
     self.free.setdefault(self._key(buf.device, g, channels), []).append(buf)
 
   def clear(self):
@@ -127,9 +131,66 @@ class _RmwOrder(object):
 
 def rmw_order_reset(enabled):
   """Opens (True) or closes (False) a multi-stream region; forgets events of the previous region (an event recorded
-  outside a graph capture must not be waited on inside it)."""
+  outside a graph capture must not be waited on inside it).  Closing joins the weight-gradient side stream."""
+  if not enabled:
+    _wgrad_side_join()
   _RmwOrder.enabled = bool(enabled)
   _RmwOrder.last = {}
+  if enabled and _WGRAD_SIDE and torch.cuda.is_available():
+    _WgradSide.origin = torch.cuda.current_stream().cuda_stream
+
+
+class _WgradSide(object):
+  """Weight gradients are leaves of the backward pass: nothing before the optimizer reads them, while the data gradient
+  they sit next to is the critical path.  Inside a multi-stream region the accumulate-into-sink weight gradients of the
+  small layers (1/16-resolution feature tower, the 3-D aggregation layers: 10-60 us kernels on a few dozen workgroups)
+  are issued on a side stream that waits for their operand and is joined when the region closes; in a captured graph
+  they become a parallel branch.  Only work issued on the stream that opened the region forks (a fork from an already
+  forked stream inside a capture crashed hipStreamEndCapture on ROCm 7.2); the accumulation order into a
+  sink is kept by the read-modify-write events, so results are bit-identical to the one-stream order.
+  OFF by default (AS_WGRAD_SIDE=1 / set_wgrad_side(True) turn it on): measured on MI355X the 20 forks of a step make it
+  SLOWER — 10.44 against 10.02 ms at 4 pairs, 4.04 against 3.73 ms at one pair (tests/tools/ab_wgrad_side.sh).  The big
+  kernels are persistent grids sized for an empty chip (a side kernel holding CUs when one starts serialises its
+  workgroups), and every cross-branch edge of the captured graph costs a few microseconds of its own."""
+  origin = None      # stream handle that opened the region
+  stream = None      # the side stream (created once)
+  used = False
+  held = set()       # data_ptr of PCL-pool buffers a side-stream kernel still reads
+  deferred = []      # (buffer, geometry, channels) returned to the pool while held: handed back at the join
+
+
+_WGRAD_SIDE = os.environ.get("AS_WGRAD_SIDE", "0") == "1"
+
+
+def set_wgrad_side(enabled):
+  global _WGRAD_SIDE
+  prev, _WGRAD_SIDE = _WGRAD_SIDE, bool(enabled)
+  return prev
+
+
+def _wgrad_side_stream():
+  """The side stream if the current stream may fork to it, else None."""
+  if not _WGRAD_SIDE or not _RmwOrder.enabled or _WgradSide.origin is None:
+    return None
+  if torch.cuda.current_stream().cuda_stream != _WgradSide.origin:
+    return None
+  if _WgradSide.stream is None:
+    _WgradSide.stream = torch.cuda.Stream()
+  return _WgradSide.stream
+
+
+def _wgrad_side_join():
+  if _WgradSide.used:
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream != _WgradSide.origin:
+      raise RuntimeError("adaptive_stereo: the multi-stream region is closed on a different stream than it was opened on")
+    cur.wait_stream(_WgradSide.stream)
+    _WgradSide.used = False
+  _WgradSide.held = set()
+  deferred, _WgradSide.deferred = _WgradSide.deferred, []
+  for buf, g, channels in deferred:
+    POOL.put(buf, g, channels)
+  _WgradSide.origin = None
 
 
 def _rmw_wait(t):
@@ -330,13 +391,27 @@ def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, s
   """Returns (dW, db); an entry is None when it was accumulated into its sink instead."""
   lib = nat.load()
   dev = x.device
-  ws = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
   taps = shape.taps()
   if sink_w is not None and (sink_b is not None or not want_bias):
+    side = _wgrad_side_stream()
+    if side is not None:
+      side.wait_stream(torch.cuda.current_stream())      # the operands are ready where the caller stands
+      with torch.cuda.stream(side):
+        ws_side = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
+        _rmw_wait(sink_w)
+        call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(sink_w), ptr(sink_b), 1, ptr(ws_side), stream())
+        _rmw_done(sink_w)
+      for t in (x, gz):                                  # neither the caching allocator nor the PCL pool may hand the
+        t.record_stream(side)                            # operands to other work before the side stream is joined
+        _WgradSide.held.add(t.data_ptr())
+      _WgradSide.used = True
+      return None, None
+    ws = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
     _rmw_wait(sink_w)
     call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(sink_w), ptr(sink_b), 1, ptr(ws), stream())
     _rmw_done(sink_w)
     return None, None
+  ws = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
   if shape.kd > 1:
     dW = _empty(32 * 32 * taps, dev).view(32, 32, shape.kd, shape.kh, shape.kw)
   else:

@@ -418,6 +418,54 @@ def test_two_stream_feature_extraction_equals_one_stream():
       assert torch.equal(a, b)
 
 
+def test_weight_gradients_on_a_side_stream_equal_the_one_stream_order():
+  """Inside a step's multi-stream region the accumulate-into-sink weight gradients of the small layers run on a side
+  stream next to the data-gradient chain (hip_ops._WgradSide); operands are kept alive / out of the buffer pool until
+  the join and the sinks are ordered by events, so eager stepping and graph replay must give the bits of the inline
+  order — losses, weights, gradients, BatchNorm buffers — and the side stream must really have been used."""
+  from adaptive_stereo import hip_ops
+  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
+  H, W, B = 96, 256, 2
+  batches = [syn.stereo_pair(B, H, W, seed=s) for s in (71, 72, 73, 74)]
+  batches = [(l.to(DEV), r.to(DEV)) for l, r in batches]
+  results = []
+  prev = hip_ops.set_wgrad_side(False)
+  try:
+    for side, use_graph in ((False, False), (True, False), (True, True)):
+      hip_ops.set_wgrad_side(side)
+      fnet, snet = build(meta)
+      adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+      forks = []
+      orig = hip_ops._wgrad_side_stream
+      def counting():
+        st = orig()
+        forks.append(st is not None)
+        return st
+      hip_ops._wgrad_side_stream = counting
+      try:
+        adapter.step(*batches[0])
+        if use_graph:
+          adapter.capture(*batches[0], warmup=1)
+        else:
+          adapter.step(*batches[0])
+      finally:
+        hip_ops._wgrad_side_stream = orig
+      assert any(forks) == side, (side, sum(forks), len(forks))
+      losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
+      torch.cuda.synchronize()
+      bufs = torch.cat([b.detach().double().reshape(-1) for net in (fnet, snet) for _, b in sorted(net.named_buffers())])
+      results.append((losses, adapter.arena.params.clone(), adapter.arena.grads.clone(), bufs, sum(forks)))
+  finally:
+    hip_ops.set_wgrad_side(prev)
+  ref = results[0]
+  for got in results[1:]:
+    assert got[0] == ref[0], (got[0], ref[0])
+    for a, b in zip(got[1:4], ref[1:4]):
+      assert torch.equal(a, b)
+  from conftest import parity_note
+  parity_note("wgrad_side_stream", forked_weight_gradients_per_step=results[1][4] // 2, bit_identical=True)
+
+
 def test_direct_gradient_accumulation_equals_autograd_accumulation():
   """Backward kernels that add parameter gradients straight into the flat arena (hip_ops.grad_sinks) must leave
   the same bits there as autograd's own AccumulateGrad route (feature_net is used twice per step, so the
