@@ -81,6 +81,10 @@ _SIGNATURES = {
   "as_conv32_wgrad_bnapply_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_wgrad_bnapply": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_float,
                                       c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+  "as_conv32_act_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
+  "as_conv32_act_parts": (c_int, []),
+  "as_conv32_act_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_float, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp,
+                                c_vp, c_vp]),
   "as_conv32_bwd_fused_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_bwd_fused_parts": (c_int, []),
   "as_conv32_bwd_fused_workspace": (c_i64, []),

@@ -160,6 +160,13 @@ class _WgradSide(object):
 
 
 _WGRAD_SIDE = os.environ.get("AS_WGRAD_SIDE", "0") == "1"
+_FWD_ACT = os.environ.get("AS_FWD_ACT", "1") != "0"     # full-resolution training forward: previous BN + LReLU on the way in
+
+
+def set_fwd_act(enabled):
+  global _FWD_ACT
+  prev, _FWD_ACT = _FWD_ACT, bool(enabled)
+  return prev
 
 
 def set_wgrad_side(enabled):
@@ -605,6 +612,21 @@ def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train,
   if not keep_z and z is not None:
     POOL.put(z, g); z = None
   return z, a, st
+
+
+def block_forward_act(z_prev, a_prevprev, st_prev: BnState, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv):
+  """Train-mode forward of a full-resolution layer whose operand a_prev = lrelu(BN(z_prev)) (+ a_prevprev) is formed on
+  the way in (csrc/conv32_act.hip): returns (a_prev, z, BnState of this layer).  The standalone bn_act pass of the
+  previous layer (read z_prev, read a_prevprev, write a_prev) disappears."""
+  dev = z_prev.device
+  lib = nat.load()
+  wp = pack_weights(w, shape, False)
+  stats = StatParts(lib.as_conv32_act_parts(), dev)
+  a_prev, z = POOL.get(g, dev), POOL.get(g, dev)
+  call("as_conv32_act_fwd", ptr(z_prev), ptr(a_prevprev), ptr(st_prev.scale), ptr(st_prev.shift), ptr(a_prev), g, ptr(wp), ptr(b),
+       LEAKY_SLOPE, ptr(z), g, shape, ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stream())
+  st = bn_train_stats(stats, gamma, beta, rm, rv)
+  return a_prev, z, st
 
 
 def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, skip, need_dx, sinks=None,
@@ -1083,8 +1105,10 @@ class EdgeRefineFn(torch.autograd.Function):
       call("as_conv4_fwd", ptr(in4), g4, ptr(wp4), ptr(b0), ptr(z0), g, s33, 0, None, None, LEAKY_SLOPE,
            ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stream())
       st0 = bn_train_stats(stats, gamma0, beta0, rm0, rv0)
-      a0 = bn_act(z0, st0, g)
+      fused_act = _FWD_ACT and need_bwd and all(lib.as_conv32_act_ok(g, g, conv_shape_2d(d)) == 1 for d in REFINE_DILATIONS)
+      a0 = None if fused_act else bn_act(z0, st0, g)
     else:
+      fused_act = False
       st0 = bn_eval_stats(gamma0, beta0, rm0, rv0)
       if need_bwd:
         z0 = POOL.get(g, dev)
@@ -1100,13 +1124,27 @@ class EdgeRefineFn(torch.autograd.Function):
       POOL.put(z0, g); z0 = None
 
     xs, zs, sts = [a0], [], []
-    for l, dil in enumerate(REFINE_DILATIONS):
-      wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
-      rm, rv = bn_buffers[1 + l]
-      z, a, st = block_forward(xs[-1], g, conv_shape_2d(dil), wl, bl, gamma, beta, rm, rv, train, True, need_bwd)
-      zs.append(z); sts.append(st); xs.append(a)
-      if not need_bwd:
-        POOL.put(xs[-2], g)
+    if fused_act:
+      # every layer forms its own operand: layer l reads z_{l-1} (+ a_{l-2}), leaves a_{l-1} behind as a by-product and
+      # writes z_l; only the last layer's output needs a BatchNorm + LeakyReLU pass of its own
+      xs = []
+      z_prev, st_prev = z0, st0
+      for l, dil in enumerate(REFINE_DILATIONS):
+        wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
+        rm, rv = bn_buffers[1 + l]
+        a_prev, z, st = block_forward_act(z_prev, xs[-1] if xs else None, st_prev, g, conv_shape_2d(dil), wl, bl, gamma, beta,
+                                          rm, rv)
+        xs.append(a_prev); zs.append(z); sts.append(st)
+        z_prev, st_prev = z, st
+      xs.append(bn_act(z_prev, st_prev, g, residual=xs[-1]))
+    else:
+      for l, dil in enumerate(REFINE_DILATIONS):
+        wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
+        rm, rv = bn_buffers[1 + l]
+        z, a, st = block_forward(xs[-1], g, conv_shape_2d(dil), wl, bl, gamma, beta, rm, rv, train, True, need_bwd)
+        zs.append(z); sts.append(st); xs.append(a)
+        if not need_bwd:
+          POOL.put(xs[-2], g)
 
     w_out, b_out = params[28], params[29]
     out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)

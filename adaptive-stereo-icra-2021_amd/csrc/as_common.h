@@ -21,7 +21,7 @@ enum {
   AS_PROF_BN_BWD = 5, AS_PROF_CONV32_LDS_BNBWD = 6, AS_PROF_AGG3D = 7, AS_PROF_AGG_TAIL = 8, AS_PROF_WGRAD3D_LDS = 9,
   AS_PROF_COSTVOL_FWD = 10, AS_PROF_COSTVOL_BWD = 11, AS_PROF_OUTCONV_BWD = 12, AS_PROF_SOFTARGMAX_BWD = 13,
   AS_PROF_UPSAMPLE_FWD = 14, AS_PROF_UPSAMPLE_BWD = 15, AS_PROF_WARP_FWD = 16, AS_PROF_WARP_BWD = 17,
-  AS_PROF_LOSS_FWD = 18, AS_PROF_LOSS_BWD = 19, AS_PROF_OUTCONV_FWD = 20, AS_PROF_SOFTARGMAX_FWD = 21, AS_PROF_BWD_FUSED = 22,
+  AS_PROF_LOSS_FWD = 18, AS_PROF_LOSS_BWD = 19, AS_PROF_OUTCONV_FWD = 20, AS_PROF_SOFTARGMAX_FWD = 21, AS_PROF_BWD_FUSED = 22, AS_PROF_CONV_ACT = 23,
   AS_PROF_IDS = 24
 };
 

@@ -29,6 +29,7 @@
 #include "conv32_lds.h"
 #include "conv3d_lds.h"
 #include "conv32_bwd.h"
+#include "conv32_act.h"
 
 static bool wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 
@@ -532,6 +533,34 @@ extern "C" int as_conv32_bwd_fused(const float* x, const as_pcl* gin, const floa
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
                      workspace, partial_db, slabs, T, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv32_bwd_fused(reduce)");
+  return AS_OK;
+}
+
+// Training forward of a full-resolution layer whose operand is the PREVIOUS layer's output, formed on the way in from that
+// layer's pre-activation, BatchNorm affine and skip input (csrc/conv32_act.hip).
+extern "C" int as_conv32_act_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
+  return conv32_act_applicable(gin, gout, s) ? 1 : 0;
+}
+extern "C" int as_conv32_act_parts(void) { return conv32_act_parts(); }
+
+extern "C" int as_conv32_act_fwd(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift,
+                                 float* a_out, const as_pcl* gin, const float* packed_w, const float* bias, float slope,
+                                 float* z, const as_pcl* gout, const as_conv_shape* s, float* stat_mean, float* stat_m2,
+                                 float* stat_cnt, void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_act_fwd")) return e;
+  AS_CHECK_ARG(z_prev && in_scale && in_shift && a_out && packed_w && z, "as_conv32_act_fwd: null pointer");
+  AS_CHECK_ARG((stat_mean != nullptr) == (stat_m2 != nullptr) && (stat_mean != nullptr) == (stat_cnt != nullptr),
+               "as_conv32_act_fwd: pass all three moment arrays or none");
+  AS_CHECK_ARG(conv32_act_applicable(gin, gout, s), "as_conv32_act_fwd: configuration not supported (as_conv32_act_ok() == 0)");
+  AS_CHECK_ARG(a_out != z_prev && a_out != a_prevprev && z != z_prev && z != a_out && z != a_prevprev,
+               "as_conv32_act_fwd: outputs must not alias inputs or each other");
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(AS_PROF_CONV_ACT, st, 1, 0.0);
+  if (int e = conv32_act_launch(z_prev, a_prevprev, in_scale, in_shift, a_out, gout, s, packed_w, bias, slope, z, stat_mean,
+                                stat_m2, stat_cnt, stream)) return e;
+  as_prof_mark(AS_PROF_CONV_ACT, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
+  AS_CHECK_LAUNCH("as_conv32_act_fwd");
   return AS_OK;
 }
 

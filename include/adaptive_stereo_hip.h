@@ -119,6 +119,22 @@ int as_conv32_bwd_fused(const float* x, const as_pcl* gin, const float* g_a, con
                         const float* next_scale, const float* next_shift, const float* next_mean, float* g_x,
                         float* dW, float* db, int accumulate, float* next_bn_workspace, float* workspace, void* stream);
 
+/* ---- training forward of a full-resolution refinement layer that forms its operand on the way in (csrc/conv32_act.hip):
+ * the PREVIOUS BasicBlock's BatchNorm2d + LeakyReLU + skip connection (stereo_net.py:10-18,33-51,97) are applied to that
+ * block's pre-activation while it is staged, the activated tensor is written back once as a by-product (the backward pass
+ * and the next skip connection need it), and the layer's own convolution + BatchNorm moments follow.  Replaces
+ * as_bn_act_fwd (previous layer) followed by as_conv32_fwd (this layer).
+ *   z_prev, a_prevprev, a_out, z   PCL tensors of ONE padded geometry (gin == gout; as_conv32_act_ok() == 1)
+ *   a_out = lrelu(z_prev*in_scale + in_shift) (+ a_prevprev if not NULL);  z = conv(a_out) + bias
+ *   packed_w   as_conv32_pack_weights(..., transpose_flip = 0);  stat_*: (count, mean, M2) partials, as_conv32_act_parts()
+ *   of them, all three or none */
+int as_conv32_act_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+int as_conv32_act_parts(void);
+int as_conv32_act_fwd(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift,
+                      float* a_out, const as_pcl* gin, const float* packed_w, const float* bias, float slope,
+                      float* z, const as_pcl* gout, const as_conv_shape* s, float* stat_mean, float* stat_m2,
+                      float* stat_cnt, void* stream);
+
 /* ---- a3, second generation: one 3x3x3 stride-1 32->32 aggregation layer (stereo_net.py:21-30,155-161,185-186) or its data
  * gradient, walking down the disparity axis with a rolling window of planes in LDS (csrc/agg3d.hip).
  *   x, z, a_out      PCL tensors of geometry g (halo 1 in d, h, w; as_agg3d_ok(g) == 1)

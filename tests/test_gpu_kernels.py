@@ -988,3 +988,51 @@ def test_conv32_backward_fused_in_one_launch(B, H, W, dil):
   close(dW, 2 * dW_ref, 1e-4 * float(dW_ref.abs().max()), 1e-4, tag + " accumulated dW")
   from conftest import parity_note
   parity_note("bwd_fused[%s]" % tag, g_x_bit_identical=exact)
+
+# ----------------------------------------------------------------------------- a7 forward with the previous BN + LReLU on the way in
+@pytest.mark.parametrize("B,H,W,dil,skip", [(2, 160, 1242, 1, True), (2, 161, 1242, 2, True), (1, 375, 1030, 4, True),
+                                            (2, 163, 1237, 8, True), (4, 97, 700, 1, False)])
+def test_conv32_forward_with_previous_activation_on_the_way_in(B, H, W, dil, skip):
+  """as_conv32_act_fwd — a_prev = lrelu(z_prev*scale + shift) (+ a_prevprev) formed while the operand is staged, written
+  back once, then the layer's convolution and BatchNorm moments — against as_bn_act_fwd followed by as_conv32_fwd: the
+  by-product and the convolution output bit for bit (same arithmetic chain, same K order), the moments after the merge to
+  rounding.  Ragged last segment, every dilation, comb residues that do not divide H, with and without skip."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_act_ok(g, g, shape) == 1
+  z_prev = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=1).to(DEV), g)
+  a_pp = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=2).to(DEV), g) if skip else None
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  b = (rnd(32, seed=10) * 0.1).to(DEV)
+  wp = ops.pack_weights(w, shape, False)
+  st = ops.BnState(DEV)
+  st.scale.copy_(rnd(32, seed=5).abs().to(DEV) + 0.5); st.shift.copy_(rnd(32, seed=6).to(DEV) * 0.3)
+  # two launches
+  a_ref = ops.bn_act(z_prev, st, g, residual=a_pp, out=ops.pcl_zeros(g, DEV))
+  stats_ref = ops.conv32_stat_parts(g, g, shape, DEV)
+  z_ref = ops.conv32(a_ref, g, wp, b, g, shape, out=ops.pcl_zeros(g, DEV), stats=stats_ref)
+  # one launch
+  a_out, z = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  stats = ops.StatParts(lib.as_conv32_act_parts(), DEV)
+  nat.call("as_conv32_act_fwd", nat.ptr(z_prev), nat.ptr(a_pp), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a_out), g,
+           nat.ptr(wp), nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats.mean), nat.ptr(stats.m2), nat.ptr(stats.cnt),
+           nat.stream())
+  tag = "B%d H%d W%d d%d %s" % (B, H, W, dil, "skip" if skip else "plain")
+  for name, got in (("a_out", a_out), ("z", z)):
+    full = ops.pcl_view(got, g).clone(); ops.pcl_interior(full, g).zero_()
+    assert float(full.abs().max()) == 0.0, tag + ": %s written into the halo" % name
+  ai, ai_ref = ops.pcl_interior(ops.pcl_view(a_out, g), g), ops.pcl_interior(ops.pcl_view(a_ref, g), g)
+  zi, zi_ref = ops.pcl_interior(ops.pcl_view(z, g), g), ops.pcl_interior(ops.pcl_view(z_ref, g), g)
+  close(ai, ai_ref, 1e-6, 1e-6, tag + " by-product")
+  close(zi, zi_ref, 2e-6, 1e-6, tag + " z")
+  a_exact, z_exact = bool(torch.equal(ai, ai_ref)), bool(torch.equal(zi, zi_ref))
+  assert a_exact, tag + ": by-product differs from as_bn_act_fwd"
+  # moments: finalize both sets of partials
+  gam, bet = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+  fin = [ops.bn_train_stats(sp, gam, bet, torch.zeros(32, device=DEV), torch.ones(32, device=DEV)) for sp in (stats, stats_ref)]
+  close(fin[0].mean, fin[1].mean, 2e-6, 1e-5, tag + " batch mean")
+  close(fin[0].invstd, fin[1].invstd, 0, 2e-6, tag + " batch invstd")
+  assert float(stats.cnt.sum()) == float(B * H * W)
+  from conftest import parity_note
+  parity_note("conv32_act[%s]" % tag, by_product_bit_identical=a_exact, z_bit_identical=z_exact)
