@@ -150,8 +150,9 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         f32x4 yv = pz[k] * sc + sh;
-        yv.x = yv.x > 0.f ? yv.x : yv.x * p.slope; yv.y = yv.y > 0.f ? yv.y : yv.y * p.slope;
-        yv.z = yv.z > 0.f ? yv.z : yv.z * p.slope; yv.w = yv.w > 0.f ? yv.w : yv.w * p.slope;
+        const f32x4 ys = yv * p.slope;                      // 0 < slope < 1: lrelu(y) = max(y, slope*y), the same bits as
+        yv.x = fmaxf(yv.x, ys.x); yv.y = fmaxf(yv.y, ys.y);   // the compare-and-select of as_bn_act_fwd (host checks slope)
+        yv.z = fmaxf(yv.z, ys.z); yv.w = fmaxf(yv.w, ys.w);
         if (SKIP) yv += pa[k];
         if (k == 0 || k == 4) {                            // only the halo voxels (v < 8, v >= 136) can lie outside the image
           const int xx = x0 - 8 + (t >> 3) + 32 * k;
@@ -175,7 +176,9 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
       const char* rows[3] = {smem + ((j + 0) % 3) * CA_ROW_BYTES, smem + ((j + 1) % 3) * CA_ROW_BYTES,
                              smem + ((j + 2) % 3) * CA_ROW_BYTES};
       const int xw = x0 + 32 * wave;
+#ifndef CA_EXP_NOCONV
       fetch_row(j + 2);                                    // in flight during the matrix phase
+#endif
       const int vbase = 8 + 32 * wave + li;
       f32x16 acc;
 #pragma unroll
@@ -210,11 +213,14 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
       }
       __syncthreads();                                     // B1: nobody reads row j-1's slot any more
       // ---- output: 16 stores per wave, then the tile's contribution to the moments ----
+#ifndef CA_EXP_NOCONV
       wait_row();                                          // the prefetch is home (requested ~9,000 cycles ago); older
+#endif
       float* z_base = p.ep.z + ((img + y + p.g.ph) * Wp + xw + p.g.pw) * 32;   // than every store below
 #define CA_ST(r) ca_store_imm<CA_ROW_IMM(r)>(z_base, io_off, acc[r]);
       CA_FOR_ROWS(CA_ST)
 #undef CA_ST
+#ifndef CA_EXP_NOMOM
       if (p.ep.stat_mean != nullptr) {
         const int dup = x_new - xw;      // wave-uniform: rows below `dup` also belong to the neighbouring segment
         if (dup <= 0) {
@@ -232,8 +238,11 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
           }
         }
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
+#ifndef CA_EXP_NOCONV
       convert_row(j + 2);
+#endif
       __syncthreads();                                     // B2: activated row j+2 is in place
     }
   }

@@ -553,6 +553,7 @@ extern "C" int as_conv32_act_fwd(const float* z_prev, const float* a_prevprev, c
   AS_CHECK_ARG((stat_mean != nullptr) == (stat_m2 != nullptr) && (stat_mean != nullptr) == (stat_cnt != nullptr),
                "as_conv32_act_fwd: pass all three moment arrays or none");
   AS_CHECK_ARG(conv32_act_applicable(gin, gout, s), "as_conv32_act_fwd: configuration not supported (as_conv32_act_ok() == 0)");
+  AS_CHECK_ARG(slope > 0.f && slope < 1.f, "as_conv32_act_fwd: slope must lie in (0, 1)");
   AS_CHECK_ARG(a_out != z_prev && a_out != a_prevprev && z != z_prev && z != a_out && z != a_prevprev,
                "as_conv32_act_fwd: outputs must not alias inputs or each other");
   hipStream_t st = (hipStream_t)stream;

@@ -320,6 +320,7 @@ def main():
                 "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
                 "flops_per_launch": dom["flops_per_launch"], "traffic_detail": traffic_detail,
                 "flavours": [e for e in (entry(22, "conv32_bwd_fused_kernel (full-resolution layer backward in one launch: BatchNorm-backward apply, data gradient + skip, weight gradient, next BatchNorm's sums)"),
+                                         entry(23, "conv32_act_kernel (full-resolution training forward: previous BatchNorm + LeakyReLU + skip applied on the way in, by-product written back, raw output + moments)"),
                                          entry(2, "conv32_lds_kernel<0,false> (training forward: raw output + BatchNorm moments)"),
                                          entry(6, "conv32_lds_kernel<3,true> (data gradient + skip + stage 1 of the next BatchNorm backward)"))
                              if e is not None],
