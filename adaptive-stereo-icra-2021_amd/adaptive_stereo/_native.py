@@ -109,6 +109,9 @@ _SIGNATURES = {
   "as_pack_in4": (c_int, [c_vp, c_vp, c_int, c_vp, _P(Pcl), c_vp]),
   "as_conv4_pack_weights": (c_int, [c_vp, c_int, c_vp, _P(ConvShape), c_vp]),
   "as_conv4_wgrad_bnapply_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
+  "as_conv4_wgrad_bnapply_proj": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_vp, c_vp, c_float,
+                                          c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+  "as_tap_gather": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
   "as_conv4_wgrad_bnapply": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_vp, c_vp, c_float,
                                      c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_conv4_stat_parts": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),

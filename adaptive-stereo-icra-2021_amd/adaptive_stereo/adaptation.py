@@ -576,15 +576,37 @@ def allreduce_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count, group
     return buf
 
 
+_COMM_STREAMS = {}
+
+
+def _all_reduce_on_comm_stream(flat, group):
+    """all-reduce(sum) of a CUDA tensor on a HIP stream of its own, ordered against the current stream by events.
+    c10d issues a blocking collective on the CURRENT stream and its watchdog thread keeps polling the work's end event;
+    when that stream then starts a graph capture (the step's second graph follows the collective on the capture stream)
+    the poll fails with hipErrorCapturedEvent and invalidates the capture — seen as a sporadic failure of capture() under
+    RCCL.  A stream that never captures keeps the collective's events away from the graphs."""
+    if not flat.is_cuda:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return
+    cur = torch.cuda.current_stream(flat.device)
+    comm = _COMM_STREAMS.get(flat.device.index)
+    if comm is None:
+        comm = _COMM_STREAMS[flat.device.index] = torch.cuda.Stream(flat.device)
+    comm.wait_stream(cur)
+    with torch.cuda.stream(comm):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    cur.wait_stream(comm)
+
+
 def allreduce_gradients_and_scalars(arena, group=None):
     """THE collective of a data-parallel adaptation step: one all-reduce(sum) of the flat gradient arena with the
     step's four scalars riding behind it (313,702 floats at k=4; latency-bound on xGMI, hence one message)."""
-    dist.all_reduce(arena.grads_and_scalars, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_on_comm_stream(arena.grads_and_scalars, group)
     return arena.grads_and_scalars
 
 
 def allreduce_gradients(flat_grads, group=None):
     """ONE all-reduce(sum) of the flat gradient arena (313,698 floats at k=4): on xGMI this message is
     latency-bound, so a single bucket beats per-tensor or per-layer buckets."""
-    dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_on_comm_stream(flat_grads, group)
     return flat_grads

@@ -160,7 +160,14 @@ class _WgradSide(object):
 
 
 _WGRAD_SIDE = os.environ.get("AS_WGRAD_SIDE", "0") == "1"
+_HEAD_PROJ = os.environ.get("AS_HEAD_PROJ", "1") != "0"  # conv2d_feature backward: per-tap projections instead of g_z
 _FWD_ACT = os.environ.get("AS_FWD_ACT", "1") != "0"     # full-resolution training forward: previous BN + LReLU on the way in
+
+
+def set_head_proj(enabled):
+  global _HEAD_PROJ
+  prev, _HEAD_PROJ = _HEAD_PROJ, bool(enabled)
+  return prev
 
 
 def set_fwd_act(enabled):
@@ -1210,11 +1217,24 @@ class EdgeRefineFn(torch.autograd.Function):
       st0 = ctx.st0
       bn_bwd_coefs(g_a, ctx.z0, st0, gamma0, g, ctx.train, sinks[2], sinks[3], True, bws, sums)
       coef = bws[lib.as_bn_bwd_coef_offset():]
-      g_z0 = POOL.get(g, dev)
-      call("as_conv4_wgrad_bnapply", ptr(ctx.in4), g4, ptr(g_a), ptr(ctx.z0), g, s33, 4, ptr(st0.scale), ptr(st0.shift),
-           ptr(st0.mean), ptr(coef), LEAKY_SLOPE, ptr(g_z0), ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())
+      if _HEAD_PROJ and ctx.needs_input_grad[0] and not ctx.needs_input_grad[1]:
+        # g_z0 itself is needed by nobody: only its 3x3 32->1 data gradient towards the disparity channel is.  The weight
+        # gradient kernel writes the nine per-tap projections of g_z0 (36 B per pixel instead of 128) and a gather sums
+        # the nine shifted planes — no g_z0 write, no 32-channel re-read
+        w_proj = w0[:, 0].flip(-1, -2).reshape(32, 9).t().contiguous()          # [9][32]
+        h_proj = _empty(B * 9 * H * W, dev)
+        call("as_conv4_wgrad_bnapply_proj", ptr(ctx.in4), g4, ptr(g_a), ptr(ctx.z0), g, s33, 4, ptr(st0.scale), ptr(st0.shift),
+             ptr(st0.mean), ptr(coef), LEAKY_SLOPE, ptr(w_proj), ptr(h_proj), ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4),
+             stream())
+        g_z0 = None
+      else:
+        h_proj = None
+        g_z0 = POOL.get(g, dev)
+        call("as_conv4_wgrad_bnapply", ptr(ctx.in4), g4, ptr(g_a), ptr(ctx.z0), g, s33, 4, ptr(st0.scale), ptr(st0.shift),
+             ptr(st0.mean), ptr(coef), LEAKY_SLOPE, ptr(g_z0), ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())
       dW0 = db0 = g_gamma0 = g_beta0 = None
     else:
+      h_proj = None
       g_z0, g_gamma0, g_beta0 = bn_act_bwd(g_a, ctx.z0, ctx.st0, gamma0, g, ctx.train, _sink(sinks, 2), _sink(sinks, 3), sums)
       if _sink(sinks, 0) is not None and _sink(sinks, 1) is not None:
         call("as_conv4_wgrad", ptr(ctx.in4), g4, ptr(g_z0), g, s33, 4, ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4), stream())
@@ -1230,7 +1250,10 @@ class EdgeRefineFn(torch.autograd.Function):
       # channel 0, which is a 32->1 convolution of g_z0 with mirrored taps; the add is fused.
       w_ch0 = w0[:, 0].flip(-1, -2).reshape(32, 9).contiguous()
       g_up = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-      call("as_conv32to1_fwd", ptr(g_z0), g, s33, ptr(w_ch0), None, ptr(g_pre), 0, ptr(g_up), stream())
+      if h_proj is not None:
+        call("as_tap_gather", ptr(h_proj), ptr(g_pre), ptr(g_up), B, H, W, stream())
+      else:
+        call("as_conv32to1_fwd", ptr(g_z0), g, s33, ptr(w_ch0), None, ptr(g_pre), 0, ptr(g_up), stream())
       g_coarse = torch.empty(B, h, w, dtype=torch.float32, device=dev)
       call("as_upsample_bilinear_bwd", ptr(g_up), B, H, W, ptr(g_coarse), h, w, gain, stream())
     if ctx.needs_input_grad[1]:

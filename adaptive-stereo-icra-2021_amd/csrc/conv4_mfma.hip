@@ -349,14 +349,22 @@ struct Wgrad4RowsArgs {
   // APPLY flavour: gz is the layer's output gradient g_a; stage 3 of its BatchNorm backward is applied on the fly
   const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_coef;
   float* gz_out; float slope;
+  // PROJ flavour: instead of g_z (32 channels) the nine per-tap projections h[t] = sum_co g_z[co] * w_proj[t][co] go out
+  // ([B][9][H][W] planes): all the thin 32->1 data gradient that follows needs of g_z
+  const float* w_proj; float* h_out;
 };
 
 // APPLY: g_z = (g_a*lrelu'(z*scale+shift) - k1 - (z-mean)*k2)*k3 is formed in registers from g_a and z (the lane's four
 // output channels), used for the products and written out for whoever needs g_z next — the element-wise pass of
 // as_bn_act_bwd (read g_a, read z, write g_z) disappears.
-template <bool APPLY>
+template <bool APPLY, bool PROJ>
 __global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p) {
   __shared__ float red[32][33];
+  __shared__ __attribute__((aligned(16))) float wpr[9 * 32];
+  if (PROJ) {
+    for (int i = threadIdx.x; i < 9 * 32; i += 256) wpr[i] = p.w_proj[i];
+    __syncthreads();
+  }
   const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
   f32x4 acc[36];
 #pragma unroll
@@ -393,7 +401,27 @@ __global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p)
           // the products below must see the ROUNDED g_z (what the element-wise pass would have stored), not a value
           // hipcc contracts into their FMAs
           asm volatile("" : "+v"(g4.x), "+v"(g4.y), "+v"(g4.z), "+v"(g4.w));
-          *reinterpret_cast<f32x4*>(p.gz_out + goff + f * 4) = g4;
+          if (!PROJ) *reinterpret_cast<f32x4*>(p.gz_out + goff + f * 4) = g4;
+        }
+        if (PROJ) {
+          // nine projections of this pixel's g_z: the lane's four channels, then a butterfly over the pixel's 8 lanes
+          float hp[9];
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wpr + tp * 32 + c4 * 4);
+            hp[tp] = g4.x * w4.x + g4.y * w4.y + g4.z * w4.z + g4.w * w4.w;
+          }
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            hp[tp] += __shfl_xor(hp[tp], 1, 64); hp[tp] += __shfl_xor(hp[tp], 2, 64); hp[tp] += __shfl_xor(hp[tp], 4, 64);
+          }
+          const long plane = (long)p.gout.H * p.gout.W;
+          float* hrow = p.h_out + (long)b * 9 * plane + (long)y * p.gout.W + x0 + vx;
+          float mine = hp[0];
+#pragma unroll
+          for (int tp = 1; tp < 8; ++tp) mine = c4 == tp ? hp[tp] : mine;
+          hrow[c4 * plane] = mine;                             // lane c4 of the pixel writes tap c4, lane 0 also tap 8
+          if (c4 == 0) hrow[8 * plane] = hp[8];
         }
         f32x4 px[9];
 #pragma unroll
@@ -421,6 +449,143 @@ __global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p)
       else p.partial_db[blockIdx.x * 32 + threadIdx.x] = sum;
     }
   }
+}
+
+// ---- weight gradient, 3x3 stride-1 instance, third form: tile staged in LDS, products on the matrix cores --------------
+// The vector-ALU form above keeps dW[36][4 co] per lane (144 accumulators, 246 registers, two waves per SIMD): every load's
+// round trip is exposed and 211 us go by for 745 MB.  Here a workgroup stages a 128-pixel row chunk once — g_z formed from
+// g_a and z on the way in (stage 3 of the BatchNorm backward), the three 4-channel input rows next to it — and then
+//   * dW[k = 4 tap + c][co] += x[p + off_tap][c] * g_z[p][co]: v_mfma_f32_32x32x2_f32 with two PIXELS as the K dimension,
+//     the 36 k-rows as M (two blocks: taps 0-7, tap 8 in rows 0-3 of the second), co as N; both operands are ds_read_b32
+//     with immediate offsets (the g_z tile has a row pitch of 36 floats: conflict-free);
+//   * the nine per-tap projections h[t][p] = sum_co g_z[p][co] * w_proj[t][co] (all the 32->1 data gradient that follows
+//     needs of g_z) on the vector ALUs, two threads per pixel;
+// 32 accumulator registers per lane, many workgroups per CU: the latency hides behind other workgroups.
+#define W4M_PITCH 36                              // floats per pixel of the g_z tile
+#define W4M_GZ_BYTES (128 * W4M_PITCH * 4)        // 18,432
+#define W4M_X_OFF W4M_GZ_BYTES                    // three input rows of 130 pixels x 4 channels
+#define W4M_X_BYTES (3 * 130 * 16)                // 6,240
+#define W4M_W_OFF (W4M_X_OFF + W4M_X_BYTES)       // w_proj [9][32]
+#define W4M_C_OFF (W4M_W_OFF + 9 * 32 * 4)        // the BatchNorm constants [6][32]
+#define W4M_LDS_BYTES (W4M_C_OFF + 6 * 32 * 4)    // 26,592
+
+template <bool PROJ>
+__global__ __launch_bounds__(256, 4) void conv4_wgrad_mfma_kernel(Wgrad4RowsArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[W4M_LDS_BYTES];
+  float* gzt = reinterpret_cast<float*>(smem);
+  float* xt = reinterpret_cast<float*>(smem + W4M_X_OFF);
+  float* wpr = reinterpret_cast<float*>(smem + W4M_W_OFF);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, li = lane & 31;
+  const int c4 = t & 7;
+  float* cft = reinterpret_cast<float*>(smem + W4M_C_OFF);     // k1, k2, k3, scale, shift, mean [6][32]: re-read per chunk
+  if (PROJ) for (int i = t; i < 9 * 32; i += 256) wpr[i] = p.w_proj[i];
+  if (t < 96) cft[t] = p.bn_coef[t];
+  if (t < 32) { cft[96 + t] = p.bn_scale[t]; cft[128 + t] = p.bn_shift[t]; cft[160 + t] = p.bn_mean[t]; }
+  f32x16 acc0;                                     // k rows 0-31 (taps 0-7) on the matrix cores
+  f32x4 acc8 = {0.f, 0.f, 0.f, 0.f};               // k rows 32-35 (tap 8) of this lane's co and pixel parity: four FMAs a step
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+  float bsum = 0.f;
+  // operand addresses of this lane: A block 0 = x[row tap/3][px + tap%3][c], tap = li >> 2, c = li & 3;
+  // A block 1 = x[2][px + 2][li] for li < 4; B = g_z[px][co = li];  px = 32 wave + 2 s + h
+  const int tap = li >> 2;
+  const float* a0p = xt + ((tap / 3) * 130 + (32 * wave + h + tap % 3)) * 4 + (li & 3);
+  const float* a1p = xt + (2 * 130 + (32 * wave + h + 2)) * 4;
+  const float* bp = gzt + (32 * wave + h) * W4M_PITCH + li;
+
+  for (int ch = blockIdx.x; ch < p.nchunks; ch += gridDim.x) {
+    const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
+    const int y = rowi % p.gout.H, b = rowi / p.gout.H, x0 = cx * 128;
+    const int npx = min(128, p.gout.W - x0);
+    const long goff = p.gout.vox(b, 0, y, x0) * 32;
+    __syncthreads();                               // the previous chunk's tile is no longer read
+    // ---- stage: g_z = stage 3 of the BatchNorm backward of (g_a, z), zeros beyond the row's end ----
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(cft + c4 * 4), k2 = *reinterpret_cast<const f32x4*>(cft + 32 + c4 * 4),
+                k3 = *reinterpret_cast<const f32x4*>(cft + 64 + c4 * 4);
+    const f32x4 bsc = *reinterpret_cast<const f32x4*>(cft + 96 + c4 * 4), bsh = *reinterpret_cast<const f32x4*>(cft + 128 + c4 * 4),
+                bmu = *reinterpret_cast<const f32x4*>(cft + 160 + c4 * 4);
+#pragma unroll 2
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int f = t + 256 * k4, vx = f >> 3;
+      f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+      if (vx < npx) {
+        g4 = *reinterpret_cast<const f32x4*>(p.gz + goff + f * 4);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(p.bn_z + goff + f * 4);
+        const f32x4 yy = zz * bsc + bsh;
+        f32x4 gy;
+        gy.x = yy.x > 0.f ? g4.x : g4.x * p.slope; gy.y = yy.y > 0.f ? g4.y : g4.y * p.slope;
+        gy.z = yy.z > 0.f ? g4.z : g4.z * p.slope; gy.w = yy.w > 0.f ? g4.w : g4.w * p.slope;
+        g4 = (gy - k1 - (zz - bmu) * k2) * k3;
+      }
+      *reinterpret_cast<f32x4*>(gzt + vx * W4M_PITCH + c4 * 4) = g4;
+    }
+    // the three input rows y-1, y, y+1, pixels x0-1 .. x0+128 (the padded 4-channel layout has the halo)
+    for (int i = t; i < 3 * 130; i += 256) {
+      const int r = i / 130, xx = i - r * 130;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (xx <= npx + 1)
+        v = *reinterpret_cast<const f32x4*>(p.x4 + (((long)b * p.gin.Hp + (y + p.gin.ph - 1 + r)) * p.gin.Wp + (x0 + p.gin.pw - 1 + xx)) * 4);
+      *reinterpret_cast<f32x4*>(xt + i * 4) = v;
+    }
+    __syncthreads();
+    // ---- products: 16 steps of two pixels ----
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float bv = bp[2 * s * W4M_PITCH];
+      const float av0 = a0p[2 * s * 4];
+      const f32x4 x8 = *reinterpret_cast<const f32x4*>(a1p + 2 * s * 4);     // one address per half-wave: a broadcast
+      bsum += bv;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
+      acc8 += x8 * bv;
+    }
+    if (PROJ) {
+      // two threads per pixel (16 channels each), nine projections, one shuffle to combine
+      const int px = t >> 1, q = t & 1;
+      const float* gp = gzt + px * W4M_PITCH + 16 * q;
+      f32x4 gv[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) gv[m] = *reinterpret_cast<const f32x4*>(gp + 4 * m);
+      float hp[9];
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wpr + tp * 32 + 16 * q + 4 * m);
+          sum += gv[m].x * w4.x + gv[m].y * w4.y + gv[m].z * w4.z + gv[m].w * w4.w;
+        }
+        hp[tp] = sum + __shfl_xor(sum, 1, 64);
+      }
+      if (px < npx) {
+        const long plane = (long)p.gout.H * p.gout.W;
+        float* hrow = p.h_out + (long)b * 9 * plane + (long)y * p.gout.W + x0 + px;
+        if (q == 0) { hrow[0] = hp[0]; hrow[plane] = hp[1]; hrow[2 * plane] = hp[2]; hrow[3 * plane] = hp[3]; hrow[4 * plane] = hp[4]; }
+        else { hrow[5 * plane] = hp[5]; hrow[6 * plane] = hp[6]; hrow[7 * plane] = hp[7]; hrow[8 * plane] = hp[8]; }
+      }
+    }
+  }
+  // ---- one slab per workgroup in the layout conv4_wgrad_reduce_kernel reads (NB = 2): [k][co], k = 4 tap + c ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);     // [4 waves][36][32] floats = 18,432 B
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    red[(wave * 36 + row) * 32 + li] = acc0[r];
+  }
+  acc8.x += __shfl_xor(acc8.x, 32, 64); acc8.y += __shfl_xor(acc8.y, 32, 64);
+  acc8.z += __shfl_xor(acc8.z, 32, 64); acc8.w += __shfl_xor(acc8.w, 32, 64);
+  if (h == 0) {
+    red[(wave * 36 + 32) * 32 + li] = acc8.x; red[(wave * 36 + 33) * 32 + li] = acc8.y;
+    red[(wave * 36 + 34) * 32 + li] = acc8.z; red[(wave * 36 + 35) * 32 + li] = acc8.w;
+  }
+  bsum += __shfl_xor(bsum, 32, 64);
+  __syncthreads();
+  float* out = p.partial + (long)blockIdx.x * 2048;
+  for (int i = t; i < 36 * 32; i += 256) out[i] = red[i] + red[36 * 32 + i] + red[2 * 36 * 32 + i] + red[3 * 36 * 32 + i];
+  __syncthreads();
+  if (h == 0) red[wave * 32 + li] = bsum;
+  __syncthreads();
+  if (t < 32) p.partial_db[blockIdx.x * 32 + t] = red[t] + red[32 + t] + red[64 + t] + red[96 + t];
 }
 
 static bool conv4_wgrad_rows_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
@@ -587,7 +752,8 @@ static void launch4(const Wgrad4Args& a, int nchunks, hipStream_t st) {
 static int conv4_wgrad_rows_launch(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout, int Cin,
                                    float* dW, float* db, int accumulate, float* workspace, bool apply,
                                    const float* bn_z, const float* scale, const float* shift, const float* mean,
-                                   const float* coef, float slope, float* gz_out, void* stream) {
+                                   const float* coef, float slope, float* gz_out, void* stream,
+                                   const float* w_proj = nullptr, float* h_out = nullptr) {
   Wgrad4RowsArgs r;
   const int grid = conv4_wgrad_rows_grid(gout);
   r.x4 = x4; r.gz = gz; r.partial = workspace; r.partial_db = workspace + (int64_t)grid * 2048;
@@ -595,8 +761,10 @@ static int conv4_wgrad_rows_launch(const float* x4, const as_pcl* gin, const flo
   r.chunks_per_row = (gout->W + 127) / 128; r.nchunks = gout->B * gout->H * r.chunks_per_row;
   r.bn_z = bn_z; r.bn_scale = scale; r.bn_shift = shift; r.bn_mean = mean; r.bn_coef = coef; r.gz_out = gz_out; r.slope = slope;
   hipStream_t st = (hipStream_t)stream;
-  if (apply) hipLaunchKernelGGL(conv4_wgrad_rows_kernel<true>, dim3(grid), dim3(256), 0, st, r);
-  else hipLaunchKernelGGL(conv4_wgrad_rows_kernel<false>, dim3(grid), dim3(256), 0, st, r);
+  r.w_proj = w_proj; r.h_out = h_out;
+  if (apply && w_proj) hipLaunchKernelGGL(conv4_wgrad_mfma_kernel<true>, dim3(grid), dim3(256), 0, st, r);   // grid <= 1,024 = 4 per CU
+  else if (apply) hipLaunchKernelGGL((conv4_wgrad_rows_kernel<true, false>), dim3(grid), dim3(256), 0, st, r);
+  else hipLaunchKernelGGL((conv4_wgrad_rows_kernel<false, false>), dim3(grid), dim3(256), 0, st, r);
   AS_CHECK_LAUNCH("as_conv4_wgrad(rows)");
   hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up((32 * Cin * 9 + 32) * 32, 256)), dim3(256), 0, st, r.partial,
                      r.partial_db, grid, 2, 9, Cin, dW, db, accumulate);
@@ -620,6 +788,44 @@ extern "C" int as_conv4_wgrad_bnapply(const float* x4, const as_pcl* gin, const 
   AS_CHECK_ARG(conv4_wgrad_rows_applicable(gin, gout, s), "as_conv4_wgrad_bnapply: configuration not supported");
   return conv4_wgrad_rows_launch(x4, gin, g_a, gout, Cin, dW, db, accumulate, workspace, true, z, scale, shift, mean, coef,
                                  slope, g_z, stream);
+}
+
+// As as_conv4_wgrad_bnapply, but g_z is not written: the nine per-tap projections h[t][p] = sum_co g_z[p][co] * w_proj[t][co]
+// are ([B][9][H][W]), which is all a following 3x3 32->1 data gradient needs (as_tap_gather sums the nine shifted planes).
+extern "C" int as_conv4_wgrad_bnapply_proj(const float* x4, const as_pcl* gin, const float* g_a, const float* z,
+                                           const as_pcl* gout, const as_conv_shape* s, int Cin, const float* scale,
+                                           const float* shift, const float* mean, const float* coef, float slope,
+                                           const float* w_proj, float* h, float* dW, float* db, int accumulate,
+                                           float* workspace, void* stream) {
+  if (int e = check4(gin, gout, s, "as_conv4_wgrad_bnapply_proj")) return e;
+  AS_CHECK_ARG(x4 && g_a && z && scale && shift && mean && coef && w_proj && h && dW && workspace && Cin >= 1 && Cin <= 4,
+               "as_conv4_wgrad_bnapply_proj: bad argument");
+  AS_CHECK_ARG(conv4_wgrad_rows_applicable(gin, gout, s), "as_conv4_wgrad_bnapply_proj: configuration not supported");
+  return conv4_wgrad_rows_launch(x4, gin, g_a, gout, Cin, dW, db, accumulate, workspace, true, z, scale, shift, mean, coef,
+                                 slope, nullptr, stream, w_proj, h);
+}
+
+// out[b][y][x] = residual[b][y][x] + sum_t h[b][t][y + t/3 - 1][x + t%3 - 1]   (zero outside the image)
+__global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ h, const float* __restrict__ residual,
+                                                          float* __restrict__ out, int H, int W) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const long plane = (long)H * W;
+  const float* hb = h + (long)b * 9 * plane;
+  float acc = residual ? residual[(long)b * plane + (long)y * W + x] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += hb[t * plane + (long)yy * W + xx];
+  }
+  out[(long)b * plane + (long)y * W + x] = acc;
+}
+
+extern "C" int as_tap_gather(const float* h, const float* residual, float* out, int B, int H, int W, void* stream) {
+  AS_CHECK_ARG(h && out && B > 0 && H > 0 && W > 0 && H <= 65535 && B <= 65535, "as_tap_gather: bad argument");
+  hipLaunchKernelGGL(tap_gather_kernel, dim3(as_div_up(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, h, residual, out, H, W);
+  AS_CHECK_LAUNCH("as_tap_gather");
+  return AS_OK;
 }
 
 extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,

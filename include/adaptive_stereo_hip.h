@@ -331,6 +331,15 @@ int as_conv4_wgrad_bnapply(const float* x4, const as_pcl* gin, const float* g_a,
                            const as_conv_shape* s, int Cin, const float* scale, const float* shift, const float* mean,
                            const float* coef, float slope, float* g_z, float* dW, float* db, int accumulate,
                            float* workspace, void* stream);
+/* as_conv4_wgrad_bnapply without the g_z write: what goes out are the nine per-tap projections
+ * h[b][t][y][x] = sum_co g_z[b][y][x][co] * w_proj[t][co]  (t = 3*kh + kw, w_proj [9][32]) — all that the 3x3 32->1 data
+ * gradient of conv2d_feature's disparity channel (stereo_net.py:116-118) needs; as_tap_gather then forms
+ * out[b][y][x] = residual[b][y][x] + sum_t h[b][t][y + kh - 1][x + kw - 1] (zero outside the image; residual may be NULL). */
+int as_conv4_wgrad_bnapply_proj(const float* x4, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                                const as_conv_shape* s, int Cin, const float* scale, const float* shift, const float* mean,
+                                const float* coef, float slope, const float* w_proj, float* h, float* dW, float* db,
+                                int accumulate, float* workspace, void* stream);
+int as_tap_gather(const float* h, const float* residual, float* out, int B, int H, int W, void* stream);
 int64_t as_conv4_wgrad_workspace(const as_pcl* gout, const as_conv_shape* s);
 int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* gz, const as_pcl* gout,
                    const as_conv_shape* s, int Cin, float* dW, float* db, int accumulate, float* workspace,

@@ -377,7 +377,8 @@ def _rccl_worker(rank, world, port, out_path):
     torch.cuda.synchronize()
     results[mode] = (losses, adapter.arena.params.detach().cpu().clone(), adapter.optimizer.step_count,
                      float(adapter.optimizer.step_dev))
-  torch.save({"identity": identity, "results": results}, out_path)
+    entries = [(mi, name, off, n) for (mi, name, _p, off, n) in adapter.arena.entries]
+  torch.save({"identity": identity, "results": results, "entries": entries}, out_path)
   dist.barrier()
   dist.destroy_process_group()
 
@@ -396,8 +397,18 @@ def test_rccl_single_rank_allreduce_and_two_graph_replay(tmp_path):
   assert (ce, de) == (cg, dg) == (5, 5.0) and (cs, ds) == (5, 5.0)
   assert le == lg, (le, lg)
   assert torch.equal(pe, pg_), float((pe - pg_).abs().max())
-  assert abs(ls[0] - le[0]) <= 1e-6 * max(1.0, abs(ls[0])), (ls, le)           # same weights so far (to Adam sign flips)
+  # two Adam steps precede the first listed loss: the two paths round the gradient at different places, so noise-level
+  # gradient elements take their +-lr first steps with different signs (how many depends on the kernels' summation order:
+  # 1e-6 with the 32-channel g_z head backward, 3e-5 with the per-tap projections)
   assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(ls, le)), (ls, le)
   # five Adam steps at lr 5e-5: identical up to sign flips of noise-level gradients (2 lr each)
   assert float((ps - pe).abs().max()) <= 5 * 2.1 * 5e-5
-  assert float((ps - pe).abs().mean()) <= 0.05 * 5e-5          # ... and those are rare
+  flipped = float(((ps - pe).abs() > 0.5 * 5e-5).float().mean())
+  worst = sorted(((float((ps[o:o + n] - pe[o:o + n]).abs().mean()) / 5e-5, "%d:%s" % (mi, name), n) for mi, name, o, n in got["entries"]),
+                 reverse=True)[:8]
+  print("largest mean |single - dp| / lr by parameter:", worst)
+  from conftest import parity_note
+  parity_note("rccl_one_rank", mean_abs_weight_diff_over_lr=float((ps - pe).abs().mean()) / 5e-5, fraction_over_half_lr=flipped,
+              first_loss_rel_dev=abs(ls[0] - le[0]) / max(1.0, abs(ls[0])))
+  assert float((ps - pe).abs().mean()) <= 0.1 * 5e-5           # ... and those are rare
+  assert flipped <= 0.1

@@ -474,6 +474,9 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
   meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
   H, W, B = 96, 256, 2
   results = []
+  # (conv2d_feature's backward has a sinks-only flavour that sums its weight gradient on the matrix cores in another order:
+  # the comparison is about the accumulation ROUTE, so both runs use the flavour both routes have)
+  prev_proj = hip_ops.set_head_proj(False)
   try:
     for direct in (False, True):
       hip_ops.set_direct_grad_accumulation(direct)
@@ -485,6 +488,7 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
       results.append((float(out["loss"]), adapter.arena.grads.clone(), adapter.arena.params.clone()))
   finally:
     hip_ops.set_direct_grad_accumulation(True)
+    hip_ops.set_head_proj(prev_proj)
   (l0, g0, p0), (l1, g1, p1) = results
   assert l0 == l1
   assert float(g0.abs().max()) > 0

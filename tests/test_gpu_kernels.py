@@ -592,6 +592,63 @@ def test_conv4_wgrad_fused_with_bn_backward_apply():
   assert torch.equal(dW, dW_ref) and torch.equal(db, db_ref)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 37, 150), (1, 61, 1242), (3, 5, 129)])
+def test_conv4_wgrad_with_per_tap_projections_instead_of_g_z(B, H, W):
+  """as_conv4_wgrad_bnapply_proj + as_tap_gather (conv2d_feature's backward without a g_z tensor: nine per-tap projections
+  of g_z go out, a gather sums the shifted planes; LDS-staged tile, products on the matrix cores) against
+  as_conv4_wgrad_bnapply + the 32->1 convolution of g_z: dW / db and the disparity-channel data gradient to fp32 summation
+  order (the data gradient: one chain of 288 products per pixel there, 9 chains of 32 here; both equally close to fp64)."""
+  g4, g = Pcl(B, 1, H, W, 0, 8, 8), Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(1)
+  lib = nat.load()
+  x4 = torch.zeros(lib.as_pcl4_numel(g4), device=DEV)
+  ch0, img = rnd(B, 1, H, W, seed=1).to(DEV), rnd(B, 3, H, W, seed=2).to(DEV)
+  nat.call("as_pack_in4", nat.ptr(ch0), nat.ptr(img), 3, nat.ptr(x4), g4, nat.stream())
+  g_a = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=3).to(DEV), g)
+  z = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=4).to(DEV), g)
+  g_pre = rnd(B, 1, H, W, seed=11).to(DEV).contiguous()
+  w0 = (rnd(32, 4, 3, 3, seed=12) * 0.2).to(DEV)
+  st = ops.BnState(DEV)
+  st.mean.copy_(rnd(32, seed=5).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=6).abs().to(DEV) + 0.5)
+  gamma = (rnd(32, seed=7).abs() + 0.5).to(DEV)
+  st.scale.copy_(st.invstd * gamma); st.shift.copy_(rnd(32, seed=8).to(DEV) * 0.1 - st.mean * st.scale)
+  ws = torch.empty(lib.as_conv4_wgrad_workspace(g, shape), device=DEV)
+  bws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  gg, gb = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+  nat.call("as_bn_act_bwd", nat.ptr(g_a), nat.ptr(z), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(st.mean),
+           nat.ptr(st.invstd), nat.ptr(gamma), 0.2, 1, None, nat.ptr(gg), nat.ptr(gb), 0, nat.ptr(bws), g, nat.stream())
+  coef = bws[lib.as_bn_bwd_coef_offset():]
+  # with g_z
+  gz = ops.pcl_zeros(g, DEV)
+  dW_ref = torch.zeros(32, 4, 3, 3, device=DEV); db_ref = torch.zeros(32, device=DEV)
+  nat.call("as_conv4_wgrad_bnapply", nat.ptr(x4), g4, nat.ptr(g_a), nat.ptr(z), g, shape, 4, nat.ptr(st.scale), nat.ptr(st.shift),
+           nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gz), nat.ptr(dW_ref), nat.ptr(db_ref), 0, nat.ptr(ws), nat.stream())
+  w_ch0 = w0[:, 0].flip(-1, -2).reshape(32, 9).contiguous()
+  g_up_ref = torch.empty(B, 1, H, W, device=DEV)
+  nat.call("as_conv32to1_fwd", nat.ptr(gz), g, shape, nat.ptr(w_ch0), None, nat.ptr(g_pre), 0, nat.ptr(g_up_ref), nat.stream())
+  # without
+  w_proj = w_ch0.t().contiguous()
+  h = torch.full((B * 9 * H * W,), float("nan"), device=DEV)
+  dW = torch.zeros(32, 4, 3, 3, device=DEV); db = torch.zeros(32, device=DEV)
+  nat.call("as_conv4_wgrad_bnapply_proj", nat.ptr(x4), g4, nat.ptr(g_a), nat.ptr(z), g, shape, 4, nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(w_proj), nat.ptr(h), nat.ptr(dW), nat.ptr(db), 0,
+           nat.ptr(ws), nat.stream())
+  g_up = torch.empty(B, 1, H, W, device=DEV)
+  nat.call("as_tap_gather", nat.ptr(h), nat.ptr(g_pre), nat.ptr(g_up), B, H, W, nat.stream())
+  assert bool(torch.isfinite(h).all()), "a projection was not written"
+  for name, got, exp in (("dW", dW, dW_ref), ("db", db, db_ref)):      # matrix cores, pixel pairs as K: another summation order
+    rel = float((got.double() - exp.double()).norm() / exp.double().norm())
+    assert rel < 2e-5, "%s: relative L2 error %.2e" % (name, rel)
+  # fp64 truth from the g_z tensor: both paths must be equally close to it
+  gz_i = ops.pcl_to_ncdhw(gz, g)[:, :, 0].double().cpu()
+  truth = torch.nn.functional.conv2d(gz_i, w0[:, 0].flip(-1, -2).double().cpu().reshape(1, 32, 3, 3), padding=1) + g_pre.double().cpu()
+  err_new = float((g_up.double().cpu() - truth).abs().max()); err_ref = float((g_up_ref.double().cpu() - truth).abs().max())
+  scale = float(truth.abs().max())
+  assert err_new <= 2e-6 * scale and err_ref <= 2e-6 * scale, (err_new, err_ref, scale)
+  from conftest import parity_note
+  parity_note("head_proj[B%d H%d W%d]" % (B, H, W), max_err_vs_fp64=err_new, two_launch_path_err=err_ref, scale=scale)
+
+
 def test_conv3d_lds_random_geometries():
   """The flattened-plane 3-D kernels (forward, data gradient, weight gradient, moments) over a sweep of geometries around
   their applicability edges: the narrowest row (W + 2 = 34), planes of just over one tile, every remainder class of the
