@@ -46,6 +46,13 @@ for _ in range(5):
     nat.call("as_conv32_bwd_fused", nat.ptr(x), g, nat.ptr(gzo), nat.ptr(z), g, shape, nat.ptr(wpt), nat.ptr(st.scale),
              nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zb), nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(bws2), nat.ptr(fws), nat.stream())
+# conv32_act_kernel<true>: the training forward with the previous BatchNorm + LeakyReLU + skip applied on the way in
+if lib.as_conv32_act_ok(g, g, shape) == 1:
+  stats_a = ops.StatParts(lib.as_conv32_act_parts(), dev)
+  a_by = torch.zeros(g.numel(), device=dev)
+  for _ in range(5):
+    nat.call("as_conv32_act_fwd", nat.ptr(zb), nat.ptr(x), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a_by), g, nat.ptr(wp),
+             nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats_a.mean), nat.ptr(stats_a.m2), nat.ptr(stats_a.cnt), nat.stream())
 # a3: one 3-D cost-aggregation layer: rolling-window forward (plain, with moments, with the previous BatchNorm merged and
 # applied in LDS + by-product), the fused tail (a4 + a5 + a8) and the LDS weight gradient
 g3 = Pcl(B, 12, 24, 78, 1, 1, 1)

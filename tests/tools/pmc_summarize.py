@@ -23,6 +23,7 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv32_lds_kernel<3, true>": 4 * vox * 128,            # + the next layer's pre-activation (fused BN-backward sums)
        "conv32_wgrad_lds_kernel": 2 * vox * 128, "conv32_wgrad_lds2_kernel<false>": 2 * vox * 128,
        "conv32_wgrad_lds2_kernel<true>": 4 * vox * 128,        # x, g_a, z read; g_z written (fused BN-backward apply)
+       "conv32_act_kernel<true>": 4 * vox * 128,               # z_prev, a_prevprev read; a_prev (by-product), z written
        "conv32_bwd_fused_kernel": 5 * vox * 128,               # x, g_a, z, z_next read; g_x written (2 x the flops)
        "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128,
        "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128,
