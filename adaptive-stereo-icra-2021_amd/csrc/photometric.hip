@@ -9,6 +9,10 @@
 // moments, (B) a 3x3 gather of those onto each warped pixel.  All HBM/L2-bound.
 // fp contraction is disabled in this file so sigma = E[x^2] - mu^2 rounds the way the
 // reference's separate ATen multiply / subtract do (the subtraction cancels ~2 digits).
+// What bounds the three stencil kernels (62 / 86 / 51 us at 4 pairs for 60-190 MB) is arithmetic, not loads: ~25 IEEE
+// divisions (by 9, by 3, by the mean disparity, n/d) and two expf per pixel, ~600 vector instructions.  Staging 32x8 tiles
+// with a halo in LDS and taking the 54 / 81 window taps from there (same order, same bits; tried in round 2) changed
+// nothing: 73 / 87 / 55 us on a box that runs the step 4 % slower.  Not kept.
 #include "as_common.h"
 #pragma clang fp contract(off)
 
