@@ -43,6 +43,19 @@ __global__ __launch_bounds__(64) void image_sum_finalize_kernel(const double* __
   if (threadIdx.x == 0) out[b] = (float)(s * mul);
 }
 
+// ---- division by 9 and by 3 ---------------------------------------------------------------------
+// The kernels divide ~19 times per pixel by these two constants (the reference's avg_pool2d and means divide, so must we,
+// bit for bit) and an IEEE fp32 division is ~12 instructions.  q = x*c, r = fma(-q, y, x), q' = fma(r, c, q) with
+// c = RN(1/y) is the correctly rounded x / y for EVERY finite binary32 x for y = 9 and y = 3, -0 excepted (it comes out
+// as +0): checked exhaustively over all 2^32 bit patterns (tests/tools/div_const.c).  Three instructions.
+__device__ inline float div_const(float x, float y, float c) {
+  const float q = x * c;
+  const float r = __builtin_fmaf(-q, y, x);
+  return __builtin_fmaf(r, c, q);
+}
+__device__ inline float div9(float x) { return div_const(x, 9.f, 1.f / 9.f); }
+__device__ inline float div3(float x) { return div_const(x, 3.f, 1.f / 3.f); }
+
 // ---- shared per-pixel SSIM arithmetic --------------------------------------------------------
 struct SsimTerms { float mux, muy, A1, A2, B1, B2, n, d, raw; };
 
@@ -77,10 +90,10 @@ __device__ inline SsimTerms ssim_at(const float* __restrict__ X, const float* __
   }
   const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
   SsimTerms t;
-  t.mux = sx / 9.f; t.muy = sy / 9.f;
-  const float sigx = sxx / 9.f - t.mux * t.mux;
-  const float sigy = syy / 9.f - t.muy * t.muy;
-  const float sigxy = sxy / 9.f - t.mux * t.muy;
+  t.mux = div9(sx); t.muy = div9(sy);
+  const float sigx = div9(sxx) - t.mux * t.mux;
+  const float sigy = div9(syy) - t.muy * t.muy;
+  const float sigxy = div9(sxy) - t.mux * t.muy;
   t.A1 = 2.f * t.mux * t.muy + C1;
   t.A2 = 2.f * sigxy + C2;
   t.B1 = t.mux * t.mux + t.muy * t.muy + C1;
@@ -96,14 +109,14 @@ __device__ inline float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 
 // edge weights exp(-mean_c |I(p) - I(p+e)|)
 __device__ inline float edge_wx(const float* __restrict__ img, long plane, int y, int x, int W) {
   const long o = (long)y * W + x;
-  const float m = (fabsf(img[o] - img[o + 1]) + fabsf(img[plane + o] - img[plane + o + 1]) +
-                   fabsf(img[2 * plane + o] - img[2 * plane + o + 1])) / 3.f;
+  const float m = div3(fabsf(img[o] - img[o + 1]) + fabsf(img[plane + o] - img[plane + o + 1]) +
+                       fabsf(img[2 * plane + o] - img[2 * plane + o + 1]));
   return expf(-m);
 }
 __device__ inline float edge_wy(const float* __restrict__ img, long plane, int y, int x, int W) {
   const long o = (long)y * W + x;
-  const float m = (fabsf(img[o] - img[o + W]) + fabsf(img[plane + o] - img[plane + o + W]) +
-                   fabsf(img[2 * plane + o] - img[2 * plane + o + W])) / 3.f;
+  const float m = div3(fabsf(img[o] - img[o + W]) + fabsf(img[plane + o] - img[plane + o + W]) +
+                       fabsf(img[2 * plane + o] - img[2 * plane + o + W]));
   return expf(-m);
 }
 
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(256) void monodepth_fwd_kernel(const float* __restr
     s_acc += fminf(fmaxf(t.raw, 0.f), 1.f);
     l_acc += fabsf(I[c * plane + (long)y * W + x] - Wp[c * plane + (long)y * W + x]);
   }
-  const float ps = s_acc / 3.f, pl = l_acc / 3.f;
+  const float ps = div3(s_acc), pl = div3(l_acc);
   const float den = mean_disp[b] + 1e-7f;
   const float* P = pred + (long)b * plane;
   const float nd = P[(long)y * W + x] / den;
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
     for (int c = 0; c < 3; ++c) {
       const SsimTerms t = ssim_at(I + c * plane, Wp + c * plane, y, x, H, W);
       const float pass = (t.raw >= 0.f && t.raw <= 1.f) ? 1.f : 0.f;
-      const float Gq = (G_ssim / 3.f) * (-0.5f) * pass;
+      const float Gq = div3(G_ssim) * (-0.5f) * pass;
       const float d2 = t.d * t.d;
       cf[(3 * c + 0) * plane] = Gq * ((2.f * t.mux * (t.A2 - t.A1)) * t.d - t.n * (2.f * t.muy * (t.B2 - t.B1))) / d2;
       cf[(3 * c + 1) * plane] = Gq * (-(t.n * t.B1)) / d2;
@@ -250,8 +263,8 @@ __global__ __launch_bounds__(256) void monodepth_bwd_b_kernel(
           }
         }
       }
-      float g = (sa + 2.f * sb * yv + sc * xv) / 9.f;
-      g += (G_l1 / 3.f) * (-sgn(xv - yv));
+      float g = div9(sa + 2.f * sb * yv + sc * xv);
+      g += div3(G_l1) * (-sgn(xv - yv));
       g_warped[((long)b * 3 + c) * plane + o] = g;
     }
   }
