@@ -367,7 +367,7 @@ def _rccl_worker(rank, world, port, out_path):
   for mode in ("single", "dp_eager", "dp_graph"):
     adapter = fresh(force_data_parallel=(mode != "single"))
     assert adapter.dp == (mode != "single") and adapter.world == 1
-    adapter.step(*batches[0])
+    first_loss = float(adapter.step(*batches[0])["loss"])                         # identical weights in all three modes
     if mode == "dp_graph":
       adapter.capture(*batches[0], warmup=1)
       assert isinstance(adapter._graph, tuple) and len(adapter._graph) == 2      # two graphs, the all-reduce between
@@ -377,6 +377,7 @@ def _rccl_worker(rank, world, port, out_path):
     torch.cuda.synchronize()
     results[mode] = (losses, adapter.arena.params.detach().cpu().clone(), adapter.optimizer.step_count,
                      float(adapter.optimizer.step_dev))
+    results[mode + "_first_loss"] = first_loss
     entries = [(mi, name, off, n) for (mi, name, _p, off, n) in adapter.arena.entries]
   torch.save({"identity": identity, "results": results, "entries": entries}, out_path)
   dist.barrier()
@@ -397,10 +398,14 @@ def test_rccl_single_rank_allreduce_and_two_graph_replay(tmp_path):
   assert (ce, de) == (cg, dg) == (5, 5.0) and (cs, ds) == (5, 5.0)
   assert le == lg, (le, lg)
   assert torch.equal(pe, pg_), float((pe - pg_).abs().max())
+  # the very first step runs on identical weights: the data-parallel loss (local sum, all-reduce, divide) and the single-GPU
+  # masked mean are the same number up to the order of one division
+  f_s, f_e, f_g = (got["results"][m + "_first_loss"] for m in ("single", "dp_eager", "dp_graph"))
+  assert f_e == f_g and abs(f_s - f_e) <= 1e-6 * max(1.0, abs(f_s)), (f_s, f_e, f_g)
   # two Adam steps precede the first listed loss: the two paths round the gradient at different places, so noise-level
-  # gradient elements take their +-lr first steps with different signs (how many depends on the kernels' summation order:
-  # 1e-6 with the 32-channel g_z head backward, 3e-5 with the per-tap projections)
-  assert all(abs(a - b) <= 1e-4 * max(1.0, abs(a)) for a, b in zip(ls, le)), (ls, le)
+  # gradient elements take their +-lr first steps with different signs and the trajectories drift apart from there (how
+  # fast depends on every kernel's summation order: 5e-7 ... 6e-4 seen over the round's kernel generations)
+  assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(ls, le)), (ls, le)
   # five Adam steps at lr 5e-5: identical up to sign flips of noise-level gradients (2 lr each)
   assert float((ps - pe).abs().max()) <= 5 * 2.1 * 5e-5
   flipped = float(((ps - pe).abs() > 0.5 * 5e-5).float().mean())
