@@ -27,6 +27,7 @@
 #include "as_common.h"
 #include "conv_epilogue.h"
 #include "conv32_lds.h"
+#include <cstdlib>
 #include "conv3d_lds.h"
 #include "conv32_bwd.h"
 #include "conv32_act.h"
@@ -123,6 +124,66 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
   }
   TileStats ts;
   conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.M - (int)blockIdx.x * 128), red, bmean, &ts);
+  stats_write(p.ep, blockIdx.x, ts);
+}
+
+// Split-K flavour for small maps.  On a 24x78 map (1/16 resolution: 59 workgroups of 128 voxels at 4 pairs, 15 at one) the
+// kernel above lasts as long as ONE wave's chain of NT x 16 dependent MFMAs plus its loads (11 us for 9 taps), on a chip that
+// is mostly idle.  Here a workgroup owns ONE 32-voxel tile and its four waves split the taps (wave w takes taps w, w+4, ...):
+// a quarter of the chain, four times the workgroups; waves 1-3 hand their partial accumulators over through LDS and wave 0
+// adds them in fixed order and runs the ordinary epilogue (one BatchNorm partial per 32 voxels).  A different summation order
+// than the one-wave chain (four partial sums), deterministic.  AS_SPLITK=0 in the environment turns it off (A/B runs).
+#define CONV32_SPLITK_MAX_M 32768
+static inline bool conv32_splitk_applies(int ntaps, long M) {
+  static const bool enabled = [] { const char* e = getenv("AS_SPLITK"); return !(e && e[0] == '0'); }();
+  return enabled && ntaps == 9 && M <= CONV32_SPLITK_MAX_M;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv32_fwd_splitk_kernel(ConvArgs p) {
+  __shared__ float red[4][32];
+  __shared__ float bmean[32];
+  __shared__ float part[3][16][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int v = blockIdx.x * 32 + li;
+  const bool in_range = v < p.M;
+  int in_vox, out_vox;
+  conv_decode(in_range ? v : p.M - 1, p.gin, p.gout, p.map, in_vox, out_vox);
+  const float* xa = p.x + (long)in_vox * 32 + h * 16;
+  const float* wb = p.wp + lane * 4;
+  const float bias_v = wave == 0 ? p.ep.bias[li] : 0.f;
+  constexpr int PER = (NT + 3) / 4;                       // taps per wave (the last ones may have one less)
+  f32x4 a[2][4], b[2][4];
+  if (wave < NT) {
+    load16(a[0], xa + (long)p.tap_off[wave] * 32);
+    loadw(b[0], wb + wave * 1024);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = bias_v;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int tp = wave + 4 * k;                          // wave-uniform
+    if (k + 1 < PER && tp + 4 < NT) {
+      load16(a[(k + 1) & 1], xa + (long)p.tap_off[tp + 4] * 32);
+      loadw(b[(k + 1) & 1], wb + (tp + 4) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tp < NT) mfma16(acc, a[k & 1], b[k & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + part[0][r][lane]) + part[1][r][lane]) + part[2][r][lane];
+  }
+  TileStats ts;
+  conv_epilogue(acc, p.ep, out_vox, in_range && wave == 0, min(32, p.M - (int)blockIdx.x * 32), red, bmean, &ts);
   stats_write(p.ep, blockIdx.x, ts);
 }
 
@@ -365,6 +426,10 @@ static int launch_conv32(const ConvArgs& args, hipStream_t st, const char* who) 
     a.ep.bias = zeros;
   }
   const dim3 grid(as_div_up(a.M, 128)), block(256);
+  if (conv32_splitk_applies(a.ntaps, a.M)) {
+    hipLaunchKernelGGL(conv32_fwd_splitk_kernel<9>, dim3(as_div_up(a.M, 32)), block, 0, st, a);
+    return AS_OK;
+  }
   switch (a.ntaps) {
     case 27: hipLaunchKernelGGL(conv32_fwd_kernel<27>, grid, block, 0, st, a); break;
     case 25: hipLaunchKernelGGL(conv32_fwd_kernel<25>, grid, block, 0, st, a); break;
@@ -594,6 +659,8 @@ extern "C" int as_conv32_stat_parts(const as_pcl* gin, const as_pcl* gout, const
   if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
   if (conv32_lds_applicable(gin, gout, s)) return conv32_lds_grid(gout);
   if (conv3d_lds_applicable(gin, gout, s)) return conv3d_lds_grid(gout);
+  const int64_t M = (int64_t)gout->B * gout->D * gout->H * gout->W;
+  if (conv32_splitk_applies(s->kd * s->kh * s->kw, M)) return as_div_up(M, 32);     // one partial per 32-voxel tile
   return as_conv32_num_blocks(gout);
 }
 
