@@ -29,7 +29,9 @@
 #define CA_WLDS_OFF (CA_COEF_OFF + 256) // 55,552: B fragments of the taps that are not register-resident [2][4][64][4]
 #define CA_RES 5                        // taps resident in registers (80); with 7 and the 40-register prefetch hipcc spilled 48 registers
 #define CA_LDS_BYTES (CA_WLDS_OFF + (9 - CA_RES) * 4096)   // 71,936
-#define CA_GRID 512                     // two resident workgroups per CU
+#define CA_GRID 512                     // two resident workgroups per CU (AS_CA_GRID in the environment: experiments)
+#include <cstdlib>
+static int ca_grid(void) { static const int g = [] { const char* e = getenv("AS_CA_GRID"); const int v = e ? atoi(e) : CA_GRID; return v >= 64 && v <= CA_GRID ? v : CA_GRID; }(); return g; }
 
 struct ActArgs {
   const float* zin;        // previous layer's pre-activation
@@ -282,7 +284,7 @@ bool conv32_act_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_
   return tiles >= 4L * CA_GRID && tiles < (1L << 31);
 }
 
-int conv32_act_parts(void) { return CA_GRID; }
+int conv32_act_parts(void) { return ca_grid(); }
 
 int conv32_act_launch(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift, float* a_out,
                       const as_pcl* g, const as_conv_shape* s, const float* packed_w, const float* bias, float slope,
@@ -302,7 +304,7 @@ int conv32_act_launch(const float* z_prev, const float* a_prevprev, const float*
   a.g = as_make_dev(g);
   a.dil = s->dil; a.nseg = (g->W + 127) / 128; a.slope = slope;
   void* kargs[] = {&a};
-  hipError_t le = hipLaunchKernel(fn, dim3(CA_GRID), dim3(256), kargs, CA_LDS_BYTES, (hipStream_t)stream);
+  hipError_t le = hipLaunchKernel(fn, dim3(ca_grid()), dim3(256), kargs, CA_LDS_BYTES, (hipStream_t)stream);
   if (le != hipSuccess) { as_set_error("as_conv32_act_fwd: launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
   return AS_OK;
 }

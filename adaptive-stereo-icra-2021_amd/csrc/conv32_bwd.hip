@@ -34,7 +34,8 @@
 #define BW_XROW_BYTES (64 * 128)        //         pairing shifts g_z, not x: no halo)
 #define BW_COEF_OFF (BW_X_OFF + 2 * BW_XROW_BYTES)   // 77,824: k1, k2, k3, scale, shift, mean [6][32]
 #define BW_LDS_BYTES (BW_COEF_OFF + 6 * 128)          // 78,592
-#define BW_GRID 512                     // two resident workgroups per CU
+#define BW_GRID 512                     // two resident workgroups per CU (AS_BW_GRID in the environment: experiments)
+static int bw_grid(void) { static const int g = [] { const char* e = getenv("AS_BW_GRID"); const int v = e ? atoi(e) : BW_GRID; return v >= 64 && v <= BW_GRID ? v : BW_GRID; }(); return g; }
 
 struct BwdArgs {
   const float* x;          // layer input a_{l-1} (PCL)
@@ -438,7 +439,7 @@ bool conv32_bwd_fused_applicable(const as_pcl* gin, const as_pcl* gout, const as
   return (long)gout->B * gout->H * ((gout->W + 63) / 64) >= (long)BW_GRID * 12;
 }
 
-int conv32_bwd_fused_slabs(void) { return BW_GRID; }
+int conv32_bwd_fused_slabs(void) { return bw_grid(); }
 
 int conv32_bwd_fused_launch(const float* x, const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s,
                             const float* packed_wt, const float* scale, const float* shift, const float* mean,
@@ -466,7 +467,7 @@ int conv32_bwd_fused_launch(const float* x, const float* g_a, const float* z, co
   hipMemsetAsync(timing_buf, 0, timing_bytes, (hipStream_t)stream);
   a.timing = timing_buf;
 #endif
-  hipLaunchKernelGGL(conv32_bwd_fused_kernel, dim3(BW_GRID), dim3(256), BW_LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv32_bwd_fused_kernel, dim3(bw_grid()), dim3(256), BW_LDS_BYTES, (hipStream_t)stream, a);
 #ifdef BW_TIMING_BUILD
   if (getenv("AS_BW_TIMING")) {                            // dump THIS launch (synchronises: diagnostic build only)
     hipStreamSynchronize((hipStream_t)stream);
