@@ -538,6 +538,7 @@ class OnlineAdapter(object):
     mean of the reference (adapt.py:83) is (sum over ranks of these sums) / N_total, and backward is linear in the
     incoming gradient: the division by N_total waits until gradients and counts have been all-reduced together."""
     total.backward(m8.to(torch.float32))
+    hip_ops.flush_deferred_reductions()          # the gradients must be complete before the all-reduce reads them
 
   def _dp_results(self):
     """Phase 2 head (after the all-reduce): scales the summed gradients by 1/N_total; returns (loss, FCS)."""

@@ -134,10 +134,49 @@ def rmw_order_reset(enabled):
   outside a graph capture must not be waited on inside it).  Closing joins the weight-gradient side stream."""
   if not enabled:
     _wgrad_side_join()
+    flush_deferred_reductions()
   _RmwOrder.enabled = bool(enabled)
   _RmwOrder.last = {}
+  if enabled and _DEFER_REDUCE and torch.cuda.is_available():
+    _DeferredReduce.on = True
+    nat.load().as_wgrad_defer(1)
   if enabled and _WGRAD_SIDE and torch.cuda.is_available():
     _WgradSide.origin = torch.cuda.current_stream().cuda_stream
+
+
+class _DeferredReduce(object):
+  """Inside a step's multi-stream region the ~30 slab reductions behind the weight-gradient kernels (4.5 us each, nothing
+  reads their result before the optimizer) are recorded by the library and run in one launch when the region closes
+  (as_wgrad_defer / as_wgrad_defer_flush).  `keep` holds the workspaces until then."""
+  on = False
+  keep = []
+
+
+_DEFER_REDUCE = os.environ.get("AS_DEFER_REDUCE", "1") != "0"
+
+
+def set_defer_reduce(enabled):
+  global _DEFER_REDUCE
+  prev, _DEFER_REDUCE = _DEFER_REDUCE, bool(enabled)
+  return prev
+
+
+def _keep_for_deferred_reduce(ws):
+  if _DeferredReduce.on:
+    _DeferredReduce.keep.append(ws)
+
+
+def flush_deferred_reductions():
+  """Runs the recorded weight-gradient reductions (one launch) on the current stream and ends the deferral.  Called when the
+  multi-stream region closes and, under data parallelism, before the gradient all-reduce.  Everything that produced a slab
+  must already be ordered before the current stream (after backward() it is: autograd joins its streams)."""
+  if not _DeferredReduce.on:
+    return
+  lib = nat.load()
+  lib.as_wgrad_defer(0)
+  _DeferredReduce.on = False
+  call("as_wgrad_defer_flush", stream())
+  _DeferredReduce.keep = []
 
 
 class _WgradSide(object):
@@ -412,6 +451,7 @@ def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, s
       side.wait_stream(torch.cuda.current_stream())      # the operands are ready where the caller stands
       with torch.cuda.stream(side):
         ws_side = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
+        _keep_for_deferred_reduce(ws_side)
         _rmw_wait(sink_w)
         call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(sink_w), ptr(sink_b), 1, ptr(ws_side), stream())
         _rmw_done(sink_w)
@@ -421,6 +461,7 @@ def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, s
       _WgradSide.used = True
       return None, None
     ws = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
+    _keep_for_deferred_reduce(ws)
     _rmw_wait(sink_w)
     call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(sink_w), ptr(sink_b), 1, ptr(ws), stream())
     _rmw_done(sink_w)
@@ -431,7 +472,11 @@ def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, s
   else:
     dW = _empty(32 * 32 * taps, dev).view(32, 32, shape.kh, shape.kw)
   db = _empty(32, dev) if want_bias else None
-  call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(dW), ptr(db), 0, ptr(ws), stream())
+  prev = lib.as_wgrad_defer(0)          # autograd reads these tensors as soon as we return: reduce now
+  try:
+    call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(dW), ptr(db), 0, ptr(ws), stream())
+  finally:
+    lib.as_wgrad_defer(prev)
   return dW, db
 
 
@@ -660,6 +705,7 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
     g_x = POOL.get(g, dev)
     nws = _empty(lib.as_bn_bwd_workspace(g), dev)
     wws = _empty(lib.as_conv32_bwd_fused_workspace(), dev)
+    _keep_for_deferred_reduce(wws)
     next_z, next_st = next_bn
     _rmw_wait(sw)
     call("as_conv32_bwd_fused", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(wp_t), ptr(st.scale), ptr(st.shift), ptr(st.mean),
@@ -677,6 +723,7 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
     coef = ws[lib.as_bn_bwd_coef_offset():]
     g_z = POOL.get(g, dev)
     wws = _empty(lib.as_conv32_wgrad_workspace(g, g, shape), dev)
+    _keep_for_deferred_reduce(wws)
     _rmw_wait(sw)
     call("as_conv32_wgrad_bnapply", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(st.scale), ptr(st.shift), ptr(st.mean),
          ptr(coef), LEAKY_SLOPE, ptr(g_z), ptr(sw), ptr(sb), 1, ptr(wws), stream())

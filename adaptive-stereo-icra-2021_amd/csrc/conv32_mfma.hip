@@ -373,6 +373,123 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// ---- deferred reductions ---------------------------------------------------------------------------------------------
+// A step has ~30 of these reductions, 4.5 us each (launch-bound: a few hundred KB of slabs), one behind every weight-gradient
+// kernel.  Nothing before the optimizer reads dW / db, so a caller may open a deferral region (as_wgrad_defer(1)): the weight-
+// gradient entry points then only RECORD their reduction, and as_wgrad_defer_flush() runs all of them in one launch — grouped by
+// destination, the jobs of one destination (a layer used twice: left and right feature tower) applied in recording order with
+// the arithmetic of the separate launches (bit-identical).  The caller keeps the workspaces alive until the flush.
+// The record is process-global behind a mutex: autograd runs backward nodes on its own thread.
+struct ReduceJob { const float* partial; const float* partial_db; int nchunks, accumulate; };
+#define RB_MAX_DEST 32
+#define RB_MAX_JOBS 2
+struct ReduceDest { float* dW; float* db; int T, njobs; ReduceJob job[RB_MAX_JOBS]; };
+struct ReduceBatch { int ndest; ReduceDest dest[RB_MAX_DEST]; };
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(ReduceBatch rb) {
+  __shared__ float red[16][64];
+  const ReduceDest& d = rb.dest[blockIdx.y];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int total = d.T * 1024;
+  const int idx = blockIdx.x * 64 + o;
+  if (blockIdx.x * 64 >= total + 32) return;                       // (workgroup-uniform)
+  const bool is_w = idx < total, is_b = !is_w && d.db != nullptr && idx < total + 32;
+  float* dst = nullptr;
+  if (is_w) { const int oc = idx & 31, i = (idx >> 5) & 31, tp = idx >> 10; dst = d.dW + ((long)oc * 32 + i) * d.T + tp; }
+  else if (is_b) dst = d.db + (idx - total);
+  float v = 0.f;
+  bool have = false;
+  for (int j = 0; j < d.njobs; ++j) {
+    const ReduceJob& jb = d.job[j];
+    float s = 0.f;
+    if (is_w) {
+      const float* src = jb.partial + idx;
+#pragma unroll 8
+      for (int c = sl; c < jb.nchunks; c += 16) s += src[(long)c * total];
+    } else if (is_b) {
+      const float* src = jb.partial_db + (idx - total);
+#pragma unroll 8
+      for (int c = sl; c < jb.nchunks; c += 16) s += src[c * 32];
+    }
+    __syncthreads();
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && dst != nullptr) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][o];
+      if (jb.accumulate) { if (!have) { v = *dst; have = true; } v = v + t; }
+      else { v = t; have = true; }
+    }
+  }
+  if (sl == 0 && dst != nullptr) *dst = v;
+}
+
+#include <mutex>
+#include <vector>
+struct PendingReduce { const float* partial; const float* partial_db; int nchunks, T; float* dW; float* db; int accumulate; };
+static std::mutex g_defer_mutex;
+static bool g_defer_on = false;
+static std::vector<PendingReduce> g_defer_jobs;
+
+// every weight-gradient entry point ends in this
+static void wgrad_reduce(hipStream_t st, const float* partial, const float* partial_db, int nchunks, int T, float* dW, float* db,
+                         int accumulate) {
+  {
+    std::lock_guard<std::mutex> lock(g_defer_mutex);
+    if (g_defer_on) { g_defer_jobs.push_back({partial, partial_db, nchunks, T, dW, db, accumulate}); return; }
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st, partial, partial_db, nchunks, T,
+                     dW, db, accumulate);
+}
+
+extern "C" int as_wgrad_defer(int on) {
+  std::lock_guard<std::mutex> lock(g_defer_mutex);
+  const int prev = g_defer_on ? 1 : 0;
+  g_defer_on = on != 0;
+  return prev;
+}
+
+extern "C" int as_wgrad_defer_pending(void) {
+  std::lock_guard<std::mutex> lock(g_defer_mutex);
+  return (int)g_defer_jobs.size();
+}
+
+static void launch_reduce_batch(const ReduceBatch& rb, hipStream_t st) {
+  int tmax = 0;
+  for (int i = 0; i < rb.ndest; ++i) tmax = rb.dest[i].T > tmax ? rb.dest[i].T : tmax;
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(as_div_up(tmax * 1024 + 32, 64), rb.ndest), dim3(1024), 0, st, rb);
+}
+
+extern "C" int as_wgrad_defer_flush(void* stream) {
+  std::vector<PendingReduce> jobs;
+  {
+    std::lock_guard<std::mutex> lock(g_defer_mutex);
+    jobs.swap(g_defer_jobs);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ReduceBatch rb;
+  rb.ndest = 0;
+  for (const PendingReduce& pj : jobs) {
+    int di = -1;
+    for (int i = 0; i < rb.ndest; ++i) if (rb.dest[i].dW == pj.dW) di = i;
+    if (di >= 0 && (rb.dest[di].njobs == RB_MAX_JOBS || rb.dest[di].T != pj.T || rb.dest[di].db != pj.db)) {
+      launch_reduce_batch(rb, st);          // a third job for a destination: what is gathered so far goes first (order!)
+      rb.ndest = 0; di = -1;
+    }
+    if (di < 0) {
+      if (rb.ndest == RB_MAX_DEST) { launch_reduce_batch(rb, st); rb.ndest = 0; }
+      di = rb.ndest++;
+      rb.dest[di].dW = pj.dW; rb.dest[di].db = pj.db; rb.dest[di].T = pj.T; rb.dest[di].njobs = 0;
+    }
+    ReduceJob& jb = rb.dest[di].job[rb.dest[di].njobs++];
+    jb.partial = pj.partial; jb.partial_db = pj.partial_db; jb.nchunks = pj.nchunks; jb.accumulate = pj.accumulate;
+  }
+  if (rb.ndest > 0) launch_reduce_batch(rb, st);
+  AS_CHECK_LAUNCH("as_wgrad_defer_flush");
+  return AS_OK;
+}
+
 // ---------------------------------------------------------------------------------
 // Host side
 static int fill_taps(const as_pcl* gin, const as_conv_shape* s, int* tap_off, const char* who) {
@@ -558,8 +675,7 @@ extern "C" int as_conv32_wgrad_bnapply(const float* x, const as_pcl* gin, const 
   as_prof_mark(3, st, 1, 0.0);
   if (int e = conv32_wgrad_lds_launch(x, gin, g_a, gout, s, workspace, partial_db, &bn, stream)) return e;
   as_prof_mark(3, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
-                     workspace, partial_db, slabs, T, dW, db, accumulate);
+  wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv32_wgrad_bnapply(reduce)");
   return AS_OK;
 }
@@ -595,8 +711,7 @@ extern "C" int as_conv32_bwd_fused(const float* x, const as_pcl* gin, const floa
                                       reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
   as_prof_mark(AS_PROF_BWD_FUSED, st, 0, 2.0 * 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);   // dgrad + wgrad
   AS_CHECK_LAUNCH("as_conv32_bwd_fused");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
-                     workspace, partial_db, slabs, T, dW, db, accumulate);
+  wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv32_bwd_fused(reduce)");
   return AS_OK;
 }
@@ -766,8 +881,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
     as_prof_mark(3, st, 1, 0.0);
     if (int e = conv32_wgrad_lds_launch(x, gin, gz, gout, s, workspace, partial_db, nullptr, stream)) return e;
     as_prof_mark(3, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
-                       workspace, partial_db, slabs, T, dW, db, accumulate);
+    wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
     AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
     return AS_OK;
   }
@@ -778,8 +892,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
     as_prof_mark(AS_PROF_WGRAD3D_LDS, st, 1, 0.0);
     if (int e = conv3d_wgrad_lds_launch(x, gin, gz, gout, workspace, partial_db, stream)) return e;
     as_prof_mark(AS_PROF_WGRAD3D_LDS, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
-                       workspace, partial_db, slabs, T, dW, db, accumulate);
+    wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
     AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
     return AS_OK;
   }
@@ -796,8 +909,7 @@ extern "C" int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* g
   else launch_wgrad<1>(a, T, nchunks, st);
   as_prof_mark(1, st, 0, 2.0 * (double)gout->B * gout->D * gout->H * gout->W * 1024.0 * T);
   AS_CHECK_LAUNCH("as_conv32_wgrad");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st,
-                     a.partial, a.partial_db, nchunks, T, dW, db, accumulate);
+  wgrad_reduce(st, a.partial, a.partial_db, nchunks, T, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv32_wgrad(reduce)");
   return AS_OK;
 }

@@ -119,6 +119,16 @@ int as_conv32_bwd_fused(const float* x, const as_pcl* gin, const float* g_a, con
                         const float* next_scale, const float* next_shift, const float* next_mean, float* g_x,
                         float* dW, float* db, int accumulate, float* next_bn_workspace, float* workspace, void* stream);
 
+/* ---- deferred weight-gradient reductions.  Every weight-gradient entry point of the 32->32 family (as_conv32_wgrad,
+ * as_conv32_wgrad_bnapply, as_conv32_bwd_fused) ends in a small reduction of per-workgroup slabs into dW / db.  Between
+ * as_wgrad_defer(1) and as_wgrad_defer_flush() those reductions are only recorded and then run in ONE launch, the jobs of a
+ * destination in recording order with the arithmetic of the separate launches.  The caller keeps the workspaces it passed
+ * alive until the flush.  as_wgrad_defer returns the previous setting; the record is process-global (autograd runs backward
+ * on its own thread). */
+int as_wgrad_defer(int on);
+int as_wgrad_defer_pending(void);
+int as_wgrad_defer_flush(void* stream);
+
 /* ---- training forward of a full-resolution refinement layer that forms its operand on the way in (csrc/conv32_act.hip):
  * the PREVIOUS BasicBlock's BatchNorm2d + LeakyReLU + skip connection (stereo_net.py:10-18,33-51,97) are applied to that
  * block's pre-activation while it is staged, the activated tensor is written back once as a by-product (the backward pass

@@ -466,6 +466,54 @@ def test_weight_gradients_on_a_side_stream_equal_the_one_stream_order():
   parity_note("wgrad_side_stream", forked_weight_gradients_per_step=results[1][4] // 2, bit_identical=True)
 
 
+def test_deferred_weight_gradient_reductions_equal_the_immediate_ones():
+  """Inside a step the slab reductions behind the weight-gradient kernels are recorded and run in ONE launch when backward is
+  over (as_wgrad_defer / as_wgrad_defer_flush; a layer used by both feature towers is one destination with two jobs, applied
+  in order).  Same arithmetic as the ~30 separate launches: losses, gradients, weights and BatchNorm buffers must be bit for
+  bit those of immediate reduction — eagerly and in graph replay — and the library must really have deferred."""
+  from adaptive_stereo import hip_ops, _native as nat
+  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
+  H, W, B = 96, 256, 2
+  batches = [syn.stereo_pair(B, H, W, seed=s) for s in (81, 82, 83, 84)]
+  batches = [(l.to(DEV), r.to(DEV)) for l, r in batches]
+  results, recorded = [], []
+  prev = hip_ops.set_defer_reduce(False)
+  try:
+    for defer, use_graph in ((False, False), (True, False), (True, True)):
+      hip_ops.set_defer_reduce(defer)
+      fnet, snet = build(meta)
+      adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+      orig = hip_ops.flush_deferred_reductions
+      seen = []
+      def counting():
+        seen.append(nat.load().as_wgrad_defer_pending())
+        return orig()
+      hip_ops.flush_deferred_reductions = counting
+      try:
+        adapter.step(*batches[0])
+        if use_graph:
+          adapter.capture(*batches[0], warmup=1)
+        else:
+          adapter.step(*batches[0])
+      finally:
+        hip_ops.flush_deferred_reductions = orig
+      recorded.append(max(seen) if seen else 0)
+      losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
+      torch.cuda.synchronize()
+      bufs = torch.cat([b.detach().double().reshape(-1) for net in (fnet, snet) for _, b in sorted(net.named_buffers())])
+      results.append((losses, adapter.arena.params.clone(), adapter.arena.grads.clone(), bufs))
+  finally:
+    hip_ops.set_defer_reduce(prev)
+  assert recorded[0] == 0 and recorded[1] >= 20 and recorded[2] >= 20, recorded
+  ref = results[0]
+  for got in results[1:]:
+    assert got[0] == ref[0], (got[0], ref[0])
+    for a, b in zip(got[1:], ref[1:]):
+      assert torch.equal(a, b)
+  from conftest import parity_note
+  parity_note("deferred_reductions", recorded_per_step=recorded[1], bit_identical=True)
+
+
 def test_direct_gradient_accumulation_equals_autograd_accumulation():
   """Backward kernels that add parameter gradients straight into the flat arena (hip_ops.grad_sinks) must leave
   the same bits there as autograd's own AccumulateGrad route (feature_net is used twice per step, so the
