@@ -81,6 +81,9 @@ _SIGNATURES = {
   "as_conv32_wgrad_bnapply_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_wgrad_bnapply": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_float,
                                       c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+  "as_conv32to1_bnsums_ok": (c_int, [_P(Pcl), _P(ConvShape)]),
+  "as_conv32to1_bnsums_parts": (c_int, [_P(Pcl)]),
+  "as_conv32to1_dgrad_bnsums": (c_int, [c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp, c_vp]),
   "as_wgrad_defer": (c_int, [c_int]),
   "as_wgrad_defer_pending": (c_int, []),
   "as_wgrad_defer_flush": (c_int, [c_vp]),

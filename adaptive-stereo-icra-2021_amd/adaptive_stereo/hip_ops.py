@@ -199,8 +199,15 @@ class _WgradSide(object):
 
 
 _WGRAD_SIDE = os.environ.get("AS_WGRAD_SIDE", "0") == "1"
+_TAIL_BNSUMS = os.environ.get("AS_TAIL_BNSUMS", "1") != "0"   # conv2d_out's data gradient also sums for the last block's BN backward
 _HEAD_PROJ = os.environ.get("AS_HEAD_PROJ", "1") != "0"  # conv2d_feature backward: per-tap projections instead of g_z
 _FWD_ACT = os.environ.get("AS_FWD_ACT", "1") != "0"     # full-resolution training forward: previous BN + LReLU on the way in
+
+
+def set_tail_bnsums(enabled):
+  global _TAIL_BNSUMS
+  prev, _TAIL_BNSUMS = _TAIL_BNSUMS, bool(enabled)
+  return prev
 
 
 def set_head_proj(enabled):
@@ -1231,16 +1238,25 @@ class EdgeRefineFn(torch.autograd.Function):
     sinks = ctx.sinks
     g_a = POOL.get(g, dev)
     ws = _empty(lib.as_conv32to1_bwd_workspace(g, s33), dev)
+    sums = None
     if _sink(sinks, 28) is not None and _sink(sinks, 29) is not None:
-      call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(sinks[28]), ptr(sinks[29]), 1,
-           ptr(ws), stream())
+      if _TAIL_BNSUMS and ctx.train and _BN_SYNC is None and lib.as_conv32to1_bnsums_ok(g, s33) == 1:
+        # the data gradient also leaves stage 1 of the last block's BatchNorm backward behind (its own pass otherwise)
+        nws = _empty(lib.as_bn_bwd_workspace(g), dev)
+        call("as_conv32to1_dgrad_bnsums", ptr(g_pre), g, s33, ptr(w_out), ptr(g_a), ptr(zs[5]), ptr(sts[5].scale),
+             ptr(sts[5].shift), ptr(sts[5].mean), LEAKY_SLOPE, ptr(nws), stream())
+        sums = BnBwdSums(nws, lib.as_conv32to1_bnsums_parts(g))
+        call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), None, ptr(sinks[28]), ptr(sinks[29]), 1,
+             ptr(ws), stream())
+      else:
+        call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(sinks[28]), ptr(sinks[29]), 1,
+             ptr(ws), stream())
     else:
       g_wout, g_bout = torch.empty_like(w_out), _empty(1, dev)
       call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout), 0,
            ptr(ws), stream())
       grads[28], grads[29] = g_wout, g_bout
 
-    sums = None
     for l in range(5, -1, -1):
       wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
       # the data gradient of block l is the output gradient of block l-1 (or of conv2d_feature): stage 1 of that

@@ -280,6 +280,11 @@ struct Thin2dBwdArgs {
   float* partial;        // [blocks][289] (wgrad)
   PclDev g;
   int nchunks, chunks_per_row;
+  // BNSUMS flavour of the data gradient: stage 1 of the BatchNorm backward whose output gradient g_a is (the last
+  // refinement block's), from the values in registers: sum g_y and sum g_y*(z - mean) per channel, one fp64 slab [64] per
+  // workgroup in the layout bn_bwd_finalize reads
+  const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; float slope;
+  double* bn_partial;
 };
 
 __device__ inline void thin_stage_g(const Thin2dBwdArgs& p, float (*sg)[132], int b, int y, int x0) {
@@ -292,13 +297,23 @@ __device__ inline void thin_stage_g(const Thin2dBwdArgs& p, float (*sg)[132], in
 }
 
 // g_a[v][c] = sum_t g_out[v - off_t] w[c][t]
+// BNSUMS: g_a is the output gradient of the last refinement block; its BatchNorm backward starts with per-channel sums over
+// g_a and that block's pre-activation z (a pass of its own: read g_a, read z, 89 us at 4 pairs) — taken here from the
+// registers that hold g_a anyway, at the price of the z read.
+template <bool BNSUMS>
 __global__ __launch_bounds__(256) void conv32to1_2d_dgrad_kernel(Thin2dBwdArgs p) {
   __shared__ float sg[3][132];
-  const int c4 = threadIdx.x & 7;
+  __shared__ float red[2][32][33];
+  const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
   f32x4 wv[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k)
     wv[k] = (f32x4){p.w[(c4 * 4 + 0) * 9 + k], p.w[(c4 * 4 + 1) * 9 + k], p.w[(c4 * 4 + 2) * 9 + k], p.w[(c4 * 4 + 3) * 9 + k]};
+  f32x4 bsc, bsh, bmu, s_dy = {0.f, 0.f, 0.f, 0.f}, s_dx = {0.f, 0.f, 0.f, 0.f};
+  if (BNSUMS) {
+    bsc = *reinterpret_cast<const f32x4*>(p.bn_scale + c4 * 4); bsh = *reinterpret_cast<const f32x4*>(p.bn_shift + c4 * 4);
+    bmu = *reinterpret_cast<const f32x4*>(p.bn_mean + c4 * 4);
+  }
   for (int ch = blockIdx.x; ch < p.nchunks; ch += gridDim.x) {
     const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
     const int y = rowi % p.g.H, b = rowi / p.g.H, x0 = cx * 128;
@@ -306,7 +321,16 @@ __global__ __launch_bounds__(256) void conv32to1_2d_dgrad_kernel(Thin2dBwdArgs p
     __syncthreads();
     thin_stage_g(p, sg, b, y, x0);
     __syncthreads();
-    float* dst = p.g_a + (((long)b * p.g.Hp + (y + p.g.ph)) * p.g.Wp + (x0 + p.g.pw)) * 32;
+    const long voff = (((long)b * p.g.Hp + (y + p.g.ph)) * p.g.Wp + (x0 + p.g.pw)) * 32;
+    float* dst = p.g_a + voff;
+    f32x4 zz[4];
+    if (BNSUMS) {
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int f = threadIdx.x + 256 * k4;
+        if (f < nf4) zz[k4] = *reinterpret_cast<const f32x4*>(p.bn_z + voff + f * 4);
+      }
+    }
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       const int f = threadIdx.x + 256 * k4;
@@ -319,7 +343,27 @@ __global__ __launch_bounds__(256) void conv32to1_2d_dgrad_kernel(Thin2dBwdArgs p
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) acc += sg[2 - ky][vx + 2 - kx] * wv[ky * 3 + kx];
         *reinterpret_cast<f32x4*>(dst + f * 4) = acc;
+        if (BNSUMS) {
+          const f32x4 yy = zz[k4] * bsc + bsh;
+          f32x4 gy;
+          gy.x = yy.x > 0.f ? acc.x : acc.x * p.slope; gy.y = yy.y > 0.f ? acc.y : acc.y * p.slope;
+          gy.z = yy.z > 0.f ? acc.z : acc.z * p.slope; gy.w = yy.w > 0.f ? acc.w : acc.w * p.slope;
+          s_dy += gy; s_dx += gy * (zz[k4] - bmu);
+        }
       }
+    }
+  }
+  if (BNSUMS) {
+    // 32 threads share a channel group: fixed-order sum through LDS, fp64 slab
+    __syncthreads();
+    red[0][vl][c4 * 4 + 0] = s_dy.x; red[0][vl][c4 * 4 + 1] = s_dy.y; red[0][vl][c4 * 4 + 2] = s_dy.z; red[0][vl][c4 * 4 + 3] = s_dy.w;
+    red[1][vl][c4 * 4 + 0] = s_dx.x; red[1][vl][c4 * 4 + 1] = s_dx.y; red[1][vl][c4 * 4 + 2] = s_dx.z; red[1][vl][c4 * 4 + 3] = s_dx.w;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      double sum = 0.0;
+      for (int j = 0; j < 32; ++j) sum += (double)red[which][j][c];
+      p.bn_partial[(long)blockIdx.x * 64 + which * 32 + c] = sum;
     }
   }
 }
@@ -501,7 +545,7 @@ extern "C" int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl
     q.g_out = g_out; q.a = a; q.w = w; q.g_a = g_a; q.partial = workspace; q.g = as_make_dev(g);
     q.chunks_per_row = (g->W + 127) / 128; q.nchunks = g->B * g->H * q.chunks_per_row;
     if (g_a) {
-      hipLaunchKernelGGL(conv32to1_2d_dgrad_kernel, dim3(q.nchunks > 16384 ? 16384 : q.nchunks), dim3(256), 0, st, q);
+      hipLaunchKernelGGL(conv32to1_2d_dgrad_kernel<false>, dim3(q.nchunks > 16384 ? 16384 : q.nchunks), dim3(256), 0, st, q);
       AS_CHECK_LAUNCH("as_conv32to1_bwd(2d dgrad)");
     }
     if (g_w || g_bias) {
@@ -529,6 +573,34 @@ extern "C" int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl
                        workspace, (int)nb, p.k.ntaps, g_w, g_bias, accumulate);
     AS_CHECK_LAUNCH("as_conv32to1_bwd(reduce)");
   }
+  return AS_OK;
+}
+
+// Data gradient of the 2-D 32->1 output layer with stage 1 of the BatchNorm backward that consumes it (see
+// conv32to1_2d_dgrad_kernel<true>): bn_workspace receives as_conv32to1_bnsums_parts(g) fp64 slabs for as_bn_act_bwd_given.
+#define THIN_BNSUMS_BLOCKS 1024
+extern "C" int as_conv32to1_bnsums_ok(const as_pcl* g, const as_conv_shape* s) {
+  if (!g || !s || !as_pcl_ok(g)) return AS_ERR_ARG;
+  return thin2d_applicable(g, s) ? 1 : 0;
+}
+extern "C" int as_conv32to1_bnsums_parts(const as_pcl* g) {
+  if (!g || !as_pcl_ok(g)) return AS_ERR_ARG;
+  const long nch = (long)g->B * g->H * ((g->W + 127) / 128);
+  return (int)(nch < THIN_BNSUMS_BLOCKS ? nch : THIN_BNSUMS_BLOCKS);
+}
+extern "C" int as_conv32to1_dgrad_bnsums(const float* g_out, const as_pcl* g, const as_conv_shape* s, const float* w, float* g_a,
+                                         const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                         float slope, float* bn_workspace, void* stream) {
+  AS_CHECK_ARG(g && s && as_pcl_ok(g) && thin2d_applicable(g, s), "as_conv32to1_dgrad_bnsums: configuration not supported");
+  AS_CHECK_ARG(g_out && w && g_a && bn_z && bn_scale && bn_shift && bn_mean && bn_workspace, "as_conv32to1_dgrad_bnsums: null pointer");
+  AS_CHECK_ARG(((uintptr_t)bn_workspace & 7) == 0, "as_conv32to1_dgrad_bnsums: workspace must be 8-byte aligned");
+  Thin2dBwdArgs q;
+  q.g_out = g_out; q.a = nullptr; q.w = w; q.g_a = g_a; q.partial = nullptr; q.g = as_make_dev(g);
+  q.chunks_per_row = (g->W + 127) / 128; q.nchunks = g->B * g->H * q.chunks_per_row;
+  q.bn_z = bn_z; q.bn_scale = bn_scale; q.bn_shift = bn_shift; q.bn_mean = bn_mean; q.slope = slope;
+  q.bn_partial = reinterpret_cast<double*>(bn_workspace);
+  hipLaunchKernelGGL(conv32to1_2d_dgrad_kernel<true>, dim3(as_conv32to1_bnsums_parts(g)), dim3(256), 0, (hipStream_t)stream, q);
+  AS_CHECK_LAUNCH("as_conv32to1_dgrad_bnsums");
   return AS_OK;
 }
 

@@ -318,6 +318,15 @@ int64_t as_conv32to1_bwd_workspace(const as_pcl* g, const as_conv_shape* s);
 int as_conv32to1_bwd(const float* g_out, const float* a, const as_pcl* g, const as_conv_shape* s,
                      const float* w, float* g_a, float* g_w, float* g_bias, int accumulate, float* workspace,
                      void* stream);
+/* Data gradient of the 2-D 3x3 32->1 output layer (conv2d_out, stereo_net.py:102) that also produces stage 1 of the
+ * BatchNorm backward consuming it — per-channel sums of g_a*lrelu'(z*scale+shift) and of that times (z - mean) — as
+ * as_conv32to1_bnsums_parts(g) fp64 slabs in bn_workspace (as_bn_bwd_workspace floats), for as_bn_act_bwd_given.
+ * Replaces as_conv32to1_bwd(g_a only) + the as_bn_bwd_sums pass over g_a and z. */
+int as_conv32to1_bnsums_ok(const as_pcl* g, const as_conv_shape* s);
+int as_conv32to1_bnsums_parts(const as_pcl* g);
+int as_conv32to1_dgrad_bnsums(const float* g_out, const as_pcl* g, const as_conv_shape* s, const float* w, float* g_a,
+                              const float* bn_z, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                              float slope, float* bn_workspace, void* stream);
 
 /* ---- thin-input convolution: Cin <= 4 -> 32 on "PCL4" ([B][H+2ph][W+2pw][4], zero halo) -----
  * EdgeAwareRefinement.conv2d_feature = nn.Conv2d(4,32,3,padding=1) over cat([disparity, rgb])

@@ -525,6 +525,7 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
   # (conv2d_feature's backward has a sinks-only flavour that sums its weight gradient on the matrix cores in another order:
   # the comparison is about the accumulation ROUTE, so both runs use the flavour both routes have)
   prev_proj = hip_ops.set_head_proj(False)
+  prev_tail = hip_ops.set_tail_bnsums(False)
   try:
     for direct in (False, True):
       hip_ops.set_direct_grad_accumulation(direct)
@@ -537,6 +538,7 @@ def test_direct_gradient_accumulation_equals_autograd_accumulation():
   finally:
     hip_ops.set_direct_grad_accumulation(True)
     hip_ops.set_head_proj(prev_proj)
+    hip_ops.set_tail_bnsums(prev_tail)
   (l0, g0, p0), (l1, g1, p1) = results
   assert l0 == l1
   assert float(g0.abs().max()) > 0

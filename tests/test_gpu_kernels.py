@@ -649,6 +649,43 @@ def test_conv4_wgrad_with_per_tap_projections_instead_of_g_z(B, H, W):
   parity_note("head_proj[B%d H%d W%d]" % (B, H, W), max_err_vs_fp64=err_new, two_launch_path_err=err_ref, scale=scale)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 37, 150), (1, 61, 1242), (3, 5, 129)])
+def test_output_layer_data_gradient_with_batchnorm_backward_sums(B, H, W):
+  """as_conv32to1_dgrad_bnsums — conv2d_out's data gradient that also leaves stage 1 of the consuming BatchNorm backward
+  behind — against as_conv32to1_bwd followed by as_bn_act_bwd's own stage 1: g_a bit for bit, the per-channel parameter
+  gradients that come out of the sums to fp32 summation order."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  s33 = ops.conv_shape_2d(1)
+  lib = nat.load()
+  assert lib.as_conv32to1_bnsums_ok(g, s33) == 1
+  g_pre = rnd(B, 1, H, W, seed=1).to(DEV).contiguous()
+  a = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=2).to(DEV), g)
+  z = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=3).to(DEV), g)
+  w_out = (rnd(1, 32, 3, 3, seed=4) * 0.2).to(DEV)
+  st = ops.BnState(DEV)
+  st.mean.copy_(rnd(32, seed=5).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=6).abs().to(DEV) + 0.5)
+  gamma = (rnd(32, seed=7).abs() + 0.5).to(DEV)
+  st.scale.copy_(st.invstd * gamma); st.shift.copy_(rnd(32, seed=8).to(DEV) * 0.1 - st.mean * st.scale)
+  # two passes
+  g_a_ref = ops.pcl_zeros(g, DEV)
+  ws = torch.empty(lib.as_conv32to1_bwd_workspace(g, s33), device=DEV)
+  gw, gb = torch.zeros_like(w_out), torch.zeros(1, device=DEV)
+  nat.call("as_conv32to1_bwd", nat.ptr(g_pre), nat.ptr(a), g, s33, nat.ptr(w_out), nat.ptr(g_a_ref), nat.ptr(gw), nat.ptr(gb), 0,
+           nat.ptr(ws), nat.stream())
+  gz_ref, gg_ref, gb_ref = ops.bn_act_bwd(g_a_ref, z, st, gamma, g, True)
+  # one pass + given sums
+  g_a = ops.pcl_zeros(g, DEV)
+  nws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  nat.call("as_conv32to1_dgrad_bnsums", nat.ptr(g_pre), g, s33, nat.ptr(w_out), nat.ptr(g_a), nat.ptr(z), nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), 0.2, nat.ptr(nws), nat.stream())
+  assert torch.equal(ops.pcl_view(g_a, g), ops.pcl_view(g_a_ref, g))
+  gz, gg, gbeta = ops.bn_act_bwd(g_a, z, st, gamma, g, True, sums=ops.BnBwdSums(nws, lib.as_conv32to1_bnsums_parts(g)))
+  n = B * H * W
+  close(gg, gg_ref, 2e-6 * n ** 0.5 * float(gg_ref.abs().max()) + 1e-5, 1e-5, "g_gamma")
+  close(gbeta, gb_ref, 2e-6 * n ** 0.5 * float(gb_ref.abs().max()) + 1e-5, 1e-5, "g_beta")
+  close(ops.pcl_interior(ops.pcl_view(gz, g), g), ops.pcl_interior(ops.pcl_view(gz_ref, g), g), 2e-5, 1e-4, "g_z")
+
+
 def test_conv3d_lds_random_geometries():
   """The flattened-plane 3-D kernels (forward, data gradient, weight gradient, moments) over a sweep of geometries around
   their applicability edges: the narrowest row (W + 2 = 34), planes of just over one tile, every remainder class of the
