@@ -601,26 +601,46 @@ static int conv4_wgrad_rows_grid(const as_pcl* gout) {
 }
 
 // dW[co][c][t] = sum_chunks partial[chunk][k>>5][k&31][co], k = 4t + c
-// 32 lanes per output element: lane q sums chunks q, q+32, ..., then a fixed-order butterfly (deterministic).
-__global__ void conv4_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
-                                          int nchunks, int NB, int T, int Cin, float* __restrict__ dW,
-                                          float* __restrict__ db, int accumulate) {
-  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  const int q = threadIdx.x & 31;
-  const int total = 32 * Cin * T;
+// 1024 threads = 64 consecutive slab elements x 16 slab slices (the scheme of wgrad_reduce_kernel): every thread sums every
+// 16th slab of its element — consecutive threads read consecutive floats of one slab — then the slices are added in fixed
+// order through LDS (deterministic).  The first form gave each output element to 32 lanes that walked the slabs with a
+// stride of a whole slab: 17 us for 8 MB of slabs; this one 5.
+__global__ __launch_bounds__(1024) void conv4_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db,
+                                                                   int nchunks, int NB, int T, int Cin, float* __restrict__ dW,
+                                                                   float* __restrict__ db, int accumulate) {
+  __shared__ float red[16][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int nk = 4 * T;                                // k rows that exist (the slab holds NB * 32)
+  const int total = nk * 32;                           // slab elements [k][co] that matter
+  const int idx = blockIdx.x * 64 + o;
+  const bool is_w = idx < total, is_b = !is_w && db != nullptr && idx < total + 32;
   float s = 0.f;
-  if (idx < total) {
-    const int t = idx % T, c = (idx / T) % Cin, co = idx / (T * Cin);
-    const int k = 4 * t + c;
-    for (int ch = q; ch < nchunks; ch += 32) s += partial[(((long)ch * NB + (k >> 5)) * 32 + (k & 31)) * 32 + co];
-  } else if (db != nullptr && idx < total + 32) {
-    for (int ch = q; ch < nchunks; ch += 32) s += partial_db[ch * 32 + (idx - total)];
+  if (is_w) {
+    const float* src = partial + idx;                  // element (k, co) sits at k*32 + co of every slab
+    const long pitch = (long)NB * 1024;
+#pragma unroll 8
+    for (int c = sl; c < nchunks; c += 16) s += src[c * pitch];
+  } else if (is_b) {
+    const float* src = partial_db + (idx - total);
+#pragma unroll 8
+    for (int c = sl; c < nchunks; c += 16) s += src[c * 32];
   }
+  red[sl][o] = s;
+  __syncthreads();
+  if (sl == 0 && (is_w || is_b)) {
+    float t = 0.f;
 #pragma unroll
-  for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 32);
-  if (q != 0) return;
-  if (idx < total) dW[idx] = accumulate ? dW[idx] + s : s;
-  else if (db != nullptr && idx < total + 32) db[idx - total] = accumulate ? db[idx - total] + s : s;
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    if (is_w) {
+      const int co = idx & 31, k = idx >> 5, tp = k >> 2, c = k & 3;
+      if (c < Cin) {
+        float* dst = dW + ((long)co * Cin + c) * T + tp;
+        *dst = accumulate ? *dst + t : t;
+      }
+    } else {
+      db[idx - total] = accumulate ? db[idx - total] + t : t;
+    }
+  }
 }
 
 // ---- host -------------------------------------------------------------------------------------------------
@@ -766,7 +786,7 @@ static int conv4_wgrad_rows_launch(const float* x4, const as_pcl* gin, const flo
   else if (apply) hipLaunchKernelGGL((conv4_wgrad_rows_kernel<true, false>), dim3(grid), dim3(256), 0, st, r);
   else hipLaunchKernelGGL((conv4_wgrad_rows_kernel<false, false>), dim3(grid), dim3(256), 0, st, r);
   AS_CHECK_LAUNCH("as_conv4_wgrad(rows)");
-  hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up((32 * Cin * 9 + 32) * 32, 256)), dim3(256), 0, st, r.partial,
+  hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up(4 * 9 * 32 + 32, 64)), dim3(1024), 0, st, r.partial,
                      r.partial_db, grid, 2, 9, Cin, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv4_wgrad(reduce)");
   return AS_OK;
@@ -854,7 +874,7 @@ extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* g
   }
   AS_CHECK_LAUNCH("as_conv4_wgrad");
   const int T = a.ntaps;
-  hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up((32 * Cin * T + 32) * 32, 256)), dim3(256), 0, st, a.partial,
+  hipLaunchKernelGGL(conv4_wgrad_reduce_kernel, dim3(as_div_up(4 * T * 32 + 32, 64)), dim3(1024), 0, st, a.partial,
                      a.partial_db, nchunks, nb, T, Cin, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv4_wgrad(reduce)");
   return AS_OK;
