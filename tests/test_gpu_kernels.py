@@ -1130,3 +1130,41 @@ def test_conv32_forward_with_previous_activation_on_the_way_in(B, H, W, dil, ski
   assert float(stats.cnt.sum()) == float(B * H * W)
   from conftest import parity_note
   parity_note("conv32_act[%s]" % tag, by_product_bit_identical=a_exact, z_bit_identical=z_exact)
+
+
+def test_fused_full_resolution_kernels_refuse_unsupported_geometry():
+  """as_conv32_act_fwd / as_conv32_bwd_fused are built for the refinement's geometry (2-D 3x3, dilation <= 8 inside an 8-voxel
+  halo, rows of >= 128 / 64 pixels, enough tiles for the fixed grid): everything else is declined by the *_ok query and
+  refused with an error by the entry point — never launched."""
+  lib = nat.load()
+  s1 = ops.conv_shape_2d(1)
+  big = Pcl(2, 1, 160, 1242, 0, 8, 8)
+  assert lib.as_conv32_act_ok(big, big, s1) == 1 and lib.as_conv32_bwd_fused_ok(big, big, s1) == 1
+  cases = [(Pcl(2, 1, 96, 256, 0, 8, 8), s1, "too few tiles for 512 workgroups"),
+           (Pcl(2, 1, 400, 100, 0, 8, 8), s1, "rows narrower than a segment (act) / too few tiles"),
+           (Pcl(2, 1, 160, 1242, 0, 4, 4), ops.conv_shape_2d(8), "dilation reaches beyond the halo"),
+           (Pcl(2, 1, 160, 1242, 0, 8, 4), s1, "halo columns < 8")]
+  for g, shape, why in cases:
+    assert lib.as_conv32_act_ok(g, g, shape) == 0, why
+  for g, shape, why in cases[:1] + cases[2:]:
+    assert lib.as_conv32_bwd_fused_ok(g, g, shape) == 0, why
+  g = cases[0][0]
+  buf = [ops.pcl_zeros(g, DEV) for _ in range(4)]
+  st = ops.BnState(DEV)
+  wp = torch.zeros(9 * 1024, device=DEV)
+  stats = ops.StatParts(lib.as_conv32_act_parts(), DEV)
+  with pytest.raises(RuntimeError, match="not supported"):
+    nat.call("as_conv32_act_fwd", nat.ptr(buf[0]), nat.ptr(buf[1]), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(buf[2]), g,
+             nat.ptr(wp), None, 0.2, nat.ptr(buf[3]), g, s1, nat.ptr(stats.mean), nat.ptr(stats.m2), nat.ptr(stats.cnt), nat.stream())
+  with pytest.raises(RuntimeError, match="slope"):
+    nat.call("as_conv32_act_fwd", nat.ptr(ops.pcl_zeros(big, DEV)), None, nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(ops.pcl_zeros(big, DEV)), big, nat.ptr(wp), None, 1.5, nat.ptr(ops.pcl_zeros(big, DEV)), big, s1, None, None,
+             None, nat.stream())
+  ws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  fws = torch.empty(lib.as_conv32_bwd_fused_workspace(), device=DEV)
+  dW, db = torch.zeros(32, 32, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+  coef = torch.zeros(96, device=DEV)
+  with pytest.raises(RuntimeError, match="not supported"):
+    nat.call("as_conv32_bwd_fused", nat.ptr(buf[0]), g, nat.ptr(buf[1]), nat.ptr(buf[2]), g, s1, nat.ptr(wp), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(buf[2]), nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(st.mean), nat.ptr(buf[3]), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.ptr(fws), nat.stream())
