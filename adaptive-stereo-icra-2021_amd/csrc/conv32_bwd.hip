@@ -11,8 +11,8 @@
 // How both gradients come out of one staged copy:
 //   * a workgroup walks a COMB of rows, y = r, r+d, r+2d, .. of a 64-pixel column segment: the data gradient of row y needs
 //     the g_z rows y-d, y, y+d — the previous, the current and the next row of the comb — so a ring of three g_z rows in LDS
-//     is all it takes for ANY dilation, and every g_a / z row is fetched and turned into g_z exactly once per comb chunk
-//     (+2 rows of run-in);
+//     is all it takes for ANY dilation, and every g_a / z row is fetched and turned into g_z exactly once per comb piece
+//     (+2 rows of run-in); the launch's tiles are cut into equal ranges, one per workgroup (see the role function);
 //   * the weight gradient is paired the other way round,  dW[kh,kw] = sum_u x[y][u]^T g_z[y-(kh-1)d][u-(kw-1)d]  (the same
 //     sum as sum_v x[v+off]^T g_z[v], re-indexed): the CENTRE x row meets the three g_z rows that are staged anyway, so x
 //     needs one row in LDS, not three;
@@ -21,7 +21,9 @@
 //     32 channels by 32 lanes, addresses = base + immediates); the element-wise pass writes both;
 //   * waves 0-1 run the data gradient of the segment's two 32-pixel halves (weights resident: 144 registers), waves 2-3 the
 //     weight gradient of the same halves (nine accumulators: 144 registers): 144 MFMAs per wave and tile either way;
-//     80 KB of LDS, two workgroups per CU cover each other's DMA waits and element-wise passes.
+//     77 KB of LDS, two workgroups per CU cover each other's barrier waits and element-wise passes.
+// Measured at 4 pairs: 605-630 us per layer = 70-72 % of the fp32 matrix peak for both gradients (DESIGN 4 has the phase
+// costs and what the first versions lost where).
 #include "as_common.h"
 #include "conv32_bwd.h"
 #include <cstdio>
@@ -35,7 +37,14 @@
 #define BW_COEF_OFF (BW_X_OFF + 2 * BW_XROW_BYTES)   // 77,824: k1, k2, k3, scale, shift, mean [6][32]
 #define BW_LDS_BYTES (BW_COEF_OFF + 6 * 128)          // 78,592
 #define BW_GRID 512                     // two resident workgroups per CU (AS_BW_GRID in the environment: experiments)
-static int bw_grid(void) { static const int g = [] { const char* e = getenv("AS_BW_GRID"); const int v = e ? atoi(e) : BW_GRID; return v >= 64 && v <= BW_GRID ? v : BW_GRID; }(); return g; }
+static int bw_grid(void) {
+  static const int g = [] {
+    const char* e = getenv("AS_BW_GRID");
+    const int v = e ? atoi(e) : BW_GRID;
+    return v >= 64 && v <= BW_GRID ? v : BW_GRID;
+  }();
+  return g;
+}
 
 struct BwdArgs {
   const float* x;          // layer input a_{l-1} (PCL)
