@@ -21,6 +21,10 @@ struct Conv4Args {
   int tap_off[AS_MAX_TAPS];
 };
 
+// NT = number of taps at compile time (0: run-time loop).  With a run-time tap loop every tap was a dependent round trip
+// (load the pixel, two MFMAs, next tap): 59 us at 4 pairs for the feature extractor's 5x5 stride-2 input layer, 90 MB of
+// traffic.  Unrolled, all of a tile's pixel and weight loads are in flight before the first MFMA.
+template <int NT>
 __global__ __launch_bounds__(256) void conv4_fwd_kernel(Conv4Args p) {
   __shared__ float red[4][32];
   __shared__ float bmean[32];
@@ -34,14 +38,32 @@ __global__ __launch_bounds__(256) void conv4_fwd_kernel(Conv4Args p) {
   const float* xa = p.x4 + (long)in_vox * 4;
   f32x16 acc;
   conv_init_acc(acc, p.ep.bias, li);
-  for (int tp = 0; tp < p.ntaps; ++tp) {
-    const f32x4 q = *reinterpret_cast<const f32x4*>(xa + (long)p.tap_off[tp] * 4);
-    const float b0 = p.wp[(tp * 2 + 0) * 64 + lane];
-    const float b1 = p.wp[(tp * 2 + 1) * 64 + lane];
-    const float a0 = h ? q.y : q.x;
-    const float a1 = h ? q.w : q.z;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+  if (NT > 0) {
+    f32x4 q[NT > 0 ? NT : 1];
+    float b0[NT > 0 ? NT : 1], b1[NT > 0 ? NT : 1];
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+      q[tp] = *reinterpret_cast<const f32x4*>(xa + (long)p.tap_off[tp] * 4);
+      b0[tp] = p.wp[(tp * 2 + 0) * 64 + lane];
+      b1[tp] = p.wp[(tp * 2 + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+      const float a0 = h ? q[tp].y : q[tp].x;
+      const float a1 = h ? q[tp].w : q[tp].z;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[tp], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[tp], acc, 0, 0, 0);
+    }
+  } else {
+    for (int tp = 0; tp < p.ntaps; ++tp) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(xa + (long)p.tap_off[tp] * 4);
+      const float b0 = p.wp[(tp * 2 + 0) * 64 + lane];
+      const float b1 = p.wp[(tp * 2 + 1) * 64 + lane];
+      const float a0 = h ? q.y : q.x;
+      const float a1 = h ? q.w : q.z;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+    }
   }
   TileStats ts;
   conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.M - (int)blockIdx.x * 128), red, bmean, &ts);
@@ -733,7 +755,9 @@ extern "C" int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* pac
   a.gin = as_make_dev(gin); a.gout = as_make_dev(gout);
   const int64_t M = (int64_t)gout->B * gout->H * gout->W;
   a.M = (int)M; a.stride = s->stride; a.ntaps = fill_taps4(gin, s, a.tap_off);
-  hipLaunchKernelGGL(conv4_fwd_kernel, dim3(as_div_up(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  if (a.ntaps == 25) hipLaunchKernelGGL(conv4_fwd_kernel<25>, dim3(as_div_up(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  else if (a.ntaps == 9) hipLaunchKernelGGL(conv4_fwd_kernel<9>, dim3(as_div_up(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv4_fwd_kernel<0>, dim3(as_div_up(M, 128)), dim3(256), 0, (hipStream_t)stream, a);
   AS_CHECK_LAUNCH("as_conv4_fwd");
   return AS_OK;
 }
