@@ -228,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
       wait_row();                                          // the prefetch is home (requested ~9,000 cycles ago); older
 #endif
       float* z_base = p.ep.z + ((img + y + p.g.ph) * Wp + xw + p.g.pw) * 32;   // than every store below
+      // The stores read the accumulator straight out of the last MFMA.  A 16-pass MFMA's result may be read by a vector-
+      // memory instruction 18 wait states later at the earliest; hipcc inserts those for its own stores (s_nop 15, s_nop 1)
+      // but cannot see into inline asm, and the ~17 scalar instructions in between are not a guarantee.
+      asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
 #define CA_ST(r) ca_store_imm<CA_ROW_IMM(r)>(z_base, io_off, acc[r]);
       CA_FOR_ROWS(CA_ST)
 #undef CA_ST

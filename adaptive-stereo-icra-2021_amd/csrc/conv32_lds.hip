@@ -273,6 +273,13 @@ __device__ __forceinline__ void conv32_lds_body(const ConvLdsArgs& p) {
     AS_TRACE(4);
     const int next_tile = tile + p.wg_per_xcd;
     if (next_tile < t_end) issue_tile_dma(p, next_tile, lds0, wave, dma_lane_off);
+    else if ((MODE == 0 || MODE == 2) && RES == 0) {
+      // These flavours store the accumulator straight out of the last MFMA through inline asm.  A 16-pass MFMA's result may
+      // be read by a vector-memory instruction 18 wait states later at the earliest; hipcc inserts those for its own stores
+      // but cannot see into inline asm.  With a next tile the DMA issue above is far longer than that; without one (the
+      // workgroup's last tile) nothing else stands between the barrier and the stores.
+      asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
     AS_TRACE(5);
 
