@@ -312,6 +312,7 @@ def main():
         traffic = int((ks["conv32_lds_kernel<0, false>"]["hbm_bytes_per_launch"] + ks["conv32_lds_kernel<3, true>"]["hbm_bytes_per_launch"]) / 2)
       traffic_detail = {"pairs_per_launch": rec.get("pairs_per_launch"),
                         "backward_fused": pmc_row("conv32_bwd_fused_kernel"),
+                        "forward_with_activation_on_the_way_in": pmc_row("conv32_act_kernel<true>"),
                         "forward": pmc_row("conv32_lds_kernel<0, false>"),
                         "dgrad_with_skip_and_bn_sums": pmc_row("conv32_lds_kernel<3, true>"),
                         "cost_aggregation_3d": {k: pmc_row(k) for k in ks if k.startswith(("agg3d", "agg_tail", "conv3d"))}}
