@@ -347,7 +347,10 @@ class OnlineAdapter(object):
       six = torch.zeros(6, dtype=torch.float32, device=total.device)
       six[:4] = self.scalars
       if replay_loss is not None:
-        n_gt = (replay[2] > 0).sum().to(torch.float32).clamp(min=1.0)
+        # the UNCLAMPED local count travels: the reference's whole-batch denominator is max(sum_r n_r, 1)
+        # (loss_functions.py:13), not sum_r max(n_r, 1) — a rank whose replay ground truth has no valid pixel adds 0
+        # (its local khamis term is 0 as well: KhamisLossFn returns 0 for an empty mask)
+        n_gt = (replay[2] > 0).sum().to(torch.float32)
         six[4] = n_gt; six[5] = replay_loss.detach() * n_gt
       dist.all_reduce(six, op=dist.ReduceOp.SUM, group=self.pg)
       loss = six[1] / six[0]
@@ -356,8 +359,9 @@ class OnlineAdapter(object):
         # whole-batch Khamis loss = (sum over ranks of the local sums) / (count over ranks); the gradient arena is
         # divided by the valid-pixel count N after its all-reduce, so this rank back-propagates
         # sum_r(monodepth) + w * (N / M) * sum_r(khamis) = ... + w * (N / M) * n_r * khamis_r
-        dp_terms = (total, m8, replay_loss, er_loss_weight * six[0] / six[4] * n_gt, six[0])
-        replay_loss = six[5] / six[4]
+        replay_coef, replay_whole = replay_whole_batch_terms(six, n_gt, er_loss_weight)
+        dp_terms = (total, m8, replay_loss, replay_coef, six[0])
+        replay_loss = replay_whole
       else:
         dp_terms = (total, m8, None, None, six[0])
     if self.fcs_smoothed is None:
@@ -551,6 +555,17 @@ class OnlineAdapter(object):
     self._dp_backward(total, m8)
     allreduce_gradients_and_scalars(self.arena, self.pg)
     return self._dp_results()
+
+
+def replay_whole_batch_terms(six, n_gt_local, er_loss_weight):
+    """The experience-replay (Khamis) term under data parallelism.  ``six`` = the all-reduced
+    [valid count N, loss sum, FCS sum, FCS count, replay ground-truth count M (UNCLAMPED per rank), replay loss sum].
+    Returns (the coefficient this rank's local khamis MEAN is back-propagated with, the whole-batch replay loss).
+    Whole batch: khamis = (sum_r S_r) / max(sum_r n_r, 1) (loss_functions.py:13).  The gradient arena is divided by N after
+    its all-reduce, and a rank holds its local mean S_r / max(n_r, 1), so the rank back-propagates
+    w * (N / M) * n_r * mean_r with M = max(sum_r n_r, 1); a rank without a valid ground-truth pixel contributes 0."""
+    m_total = six[4].clamp(min=1.0)
+    return er_loss_weight * six[0] / m_total * n_gt_local, six[5] / m_total
 
 
 def _adjacent_or_cat(left, right):

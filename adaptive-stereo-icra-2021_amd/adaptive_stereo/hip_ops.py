@@ -103,9 +103,6 @@ class PclPool(object):
   def put(self, buf, g: Pcl, channels=32):
     if buf is None:
       return
-    if buf.data_ptr() in _WgradSide.held:                # still being read by a weight gradient on the side stream
-      _WgradSide.deferred.append((buf, g, channels))
-      return
     self.free.setdefault(self._key(buf.device, g, channels), []).append(buf)
 
   def clear(self):
@@ -127,21 +124,24 @@ class _RmwOrder(object):
   cost) unless a caller opens a multi-stream region."""
   enabled = False
   last = {}          # data_ptr -> (stream handle, event recorded after the last read-modify-write)
+  streams = {}       # stream handle -> torch stream, every stream that recorded such an event in this region
 
 
 def rmw_order_reset(enabled):
   """Opens (True) or closes (False) a multi-stream region; forgets events of the previous region (an event recorded
-  outside a graph capture must not be waited on inside it).  Closing joins the weight-gradient side stream."""
+  outside a graph capture must not be waited on inside it).  Closing runs the deferred weight-gradient reductions."""
   if not enabled:
-    _wgrad_side_join()
     flush_deferred_reductions()
   _RmwOrder.enabled = bool(enabled)
   _RmwOrder.last = {}
+  _RmwOrder.streams = {}
   if enabled and _DEFER_REDUCE and torch.cuda.is_available():
+    lib = nat.load()
+    if lib.as_wgrad_defer_pending() != 0 or _DeferredReduce.keep:
+      raise RuntimeError("adaptive_stereo: a multi-stream region opens while weight-gradient reductions of an earlier one "
+                         "are still pending (a region was left without rmw_order_reset(False))")
     _DeferredReduce.on = True
-    nat.load().as_wgrad_defer(1)
-  if enabled and _WGRAD_SIDE and torch.cuda.is_available():
-    _WgradSide.origin = torch.cuda.current_stream().cuda_stream
+    lib.as_wgrad_defer(1)
 
 
 class _DeferredReduce(object):
@@ -152,7 +152,7 @@ class _DeferredReduce(object):
   keep = []
 
 
-_DEFER_REDUCE = os.environ.get("AS_DEFER_REDUCE", "1") != "0"
+_DEFER_REDUCE = True       # set_defer_reduce(False): every reduction right behind its kernel (the parity test compares both)
 
 
 def set_defer_reduce(enabled):
@@ -169,7 +169,10 @@ def _keep_for_deferred_reduce(ws):
 def flush_deferred_reductions():
   """Runs the recorded weight-gradient reductions (one launch) on the current stream and ends the deferral.  Called when the
   multi-stream region closes and, under data parallelism, before the gradient all-reduce.  Everything that produced a slab
-  must already be ordered before the current stream (after backward() it is: autograd joins its streams)."""
+  must already be ordered before the current stream: join_region_streams() makes that explicit for every stream that
+  issued work inside the region (autograd itself only joins streams through defined gradients, and the Functions here
+  return None for sunk parameters)."""
+  join_region_streams()
   if not _DeferredReduce.on:
     return
   lib = nat.load()
@@ -179,29 +182,11 @@ def flush_deferred_reductions():
   _DeferredReduce.keep = []
 
 
-class _WgradSide(object):
-  """Weight gradients are leaves of the backward pass: nothing before the optimizer reads them, while the data gradient
-  they sit next to is the critical path.  Inside a multi-stream region the accumulate-into-sink weight gradients of the
-  small layers (1/16-resolution feature tower, the 3-D aggregation layers: 10-60 us kernels on a few dozen workgroups)
-  are issued on a side stream that waits for their operand and is joined when the region closes; in a captured graph
-  they become a parallel branch.  Only work issued on the stream that opened the region forks (a fork from an already
-  forked stream inside a capture crashed hipStreamEndCapture on ROCm 7.2); the accumulation order into a
-  sink is kept by the read-modify-write events, so results are bit-identical to the one-stream order.
-  OFF by default (AS_WGRAD_SIDE=1 / set_wgrad_side(True) turn it on): measured on MI355X the 20 forks of a step make it
-  SLOWER — 10.44 against 10.02 ms at 4 pairs, 4.04 against 3.73 ms at one pair (tests/tools/ab_wgrad_side.sh).  The big
-  kernels are persistent grids sized for an empty chip (a side kernel holding CUs when one starts serialises its
-  workgroups), and every cross-branch edge of the captured graph costs a few microseconds of its own."""
-  origin = None      # stream handle that opened the region
-  stream = None      # the side stream (created once)
-  used = False
-  held = set()       # data_ptr of PCL-pool buffers a side-stream kernel still reads
-  deferred = []      # (buffer, geometry, channels) returned to the pool while held: handed back at the join
-
-
-_WGRAD_SIDE = os.environ.get("AS_WGRAD_SIDE", "0") == "1"
-_TAIL_BNSUMS = os.environ.get("AS_TAIL_BNSUMS", "1") != "0"   # conv2d_out's data gradient also sums for the last block's BN backward
-_HEAD_PROJ = os.environ.get("AS_HEAD_PROJ", "1") != "0"  # conv2d_feature backward: per-tap projections instead of g_z
-_FWD_ACT = os.environ.get("AS_FWD_ACT", "1") != "0"     # full-resolution training forward: previous BN + LReLU on the way in
+_TAIL_BNSUMS = True        # conv2d_out's data gradient also sums for the last block's BatchNorm backward
+_HEAD_PROJ = True          # conv2d_feature backward: per-tap projections instead of g_z
+_FWD_ACT = True            # full-resolution training forward: previous BatchNorm + LeakyReLU applied on the way in
+# (module switches, each with a setter: tests/test_gpu_end_to_end.py runs both routes and compares them; timing A/B of a
+# route is a tool's business — tests/tools/ab_switch.py — not the environment's)
 
 
 def set_tail_bnsums(enabled):
@@ -222,37 +207,6 @@ def set_fwd_act(enabled):
   return prev
 
 
-def set_wgrad_side(enabled):
-  global _WGRAD_SIDE
-  prev, _WGRAD_SIDE = _WGRAD_SIDE, bool(enabled)
-  return prev
-
-
-def _wgrad_side_stream():
-  """The side stream if the current stream may fork to it, else None."""
-  if not _WGRAD_SIDE or not _RmwOrder.enabled or _WgradSide.origin is None:
-    return None
-  if torch.cuda.current_stream().cuda_stream != _WgradSide.origin:
-    return None
-  if _WgradSide.stream is None:
-    _WgradSide.stream = torch.cuda.Stream()
-  return _WgradSide.stream
-
-
-def _wgrad_side_join():
-  if _WgradSide.used:
-    cur = torch.cuda.current_stream()
-    if cur.cuda_stream != _WgradSide.origin:
-      raise RuntimeError("adaptive_stereo: the multi-stream region is closed on a different stream than it was opened on")
-    cur.wait_stream(_WgradSide.stream)
-    _WgradSide.used = False
-  _WgradSide.held = set()
-  deferred, _WgradSide.deferred = _WgradSide.deferred, []
-  for buf, g, channels in deferred:
-    POOL.put(buf, g, channels)
-  _WgradSide.origin = None
-
-
 def _rmw_wait(t):
   if _RmwOrder.enabled and t is not None:
     last = _RmwOrder.last.get(t.data_ptr())
@@ -267,6 +221,19 @@ def _rmw_done(t):
     ev = torch.cuda.Event()
     ev.record(cur)
     _RmwOrder.last[t.data_ptr()] = (cur.cuda_stream, ev)
+    _RmwOrder.streams[cur.cuda_stream] = cur
+
+
+def join_region_streams():
+  """The current stream waits for every other stream that updated a shared buffer inside the open multi-stream region
+  (weight-gradient slabs and gradient sinks written on the right tower's stream are read by the flush and the optimizer
+  on this one).  Until round 3 this edge was implicit (the left tower's _rmw_wait chain happened to order it)."""
+  if not _RmwOrder.enabled:
+    return
+  cur = torch.cuda.current_stream()
+  for handle, st in list(_RmwOrder.streams.items()):
+    if handle != cur.cuda_stream:
+      cur.wait_stream(st)
 
 
 # ----------------------------------------------------------------------------------------
@@ -453,20 +420,6 @@ def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, s
   dev = x.device
   taps = shape.taps()
   if sink_w is not None and (sink_b is not None or not want_bias):
-    side = _wgrad_side_stream()
-    if side is not None:
-      side.wait_stream(torch.cuda.current_stream())      # the operands are ready where the caller stands
-      with torch.cuda.stream(side):
-        ws_side = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
-        _keep_for_deferred_reduce(ws_side)
-        _rmw_wait(sink_w)
-        call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(sink_w), ptr(sink_b), 1, ptr(ws_side), stream())
-        _rmw_done(sink_w)
-      for t in (x, gz):                                  # neither the caching allocator nor the PCL pool may hand the
-        t.record_stream(side)                            # operands to other work before the side stream is joined
-        _WgradSide.held.add(t.data_ptr())
-      _WgradSide.used = True
-      return None, None
     ws = _empty(lib.as_conv32_wgrad_workspace(gin, gout, shape), dev)
     _keep_for_deferred_reduce(ws)
     _rmw_wait(sink_w)
@@ -479,11 +432,8 @@ def conv32_wgrad(x, gin: Pcl, gz, gout: Pcl, shape: ConvShape, want_bias=True, s
   else:
     dW = _empty(32 * 32 * taps, dev).view(32, 32, shape.kh, shape.kw)
   db = _empty(32, dev) if want_bias else None
-  prev = lib.as_wgrad_defer(0)          # autograd reads these tensors as soon as we return: reduce now
-  try:
-    call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(dW), ptr(db), 0, ptr(ws), stream())
-  finally:
-    lib.as_wgrad_defer(prev)
+  # (accumulate = 0: the library reduces right away even inside a deferral region — autograd reads dW on return)
+  call("as_conv32_wgrad", ptr(x), gin, ptr(gz), gout, shape, ptr(dW), ptr(db), 0, ptr(ws), stream())
   return dW, db
 
 
@@ -762,9 +712,6 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
 _AGG3D = True            # False: the first-generation path (conv3d_lds + finalize + element-wise pass per layer)
 _AGG_TAIL = True         # False: conv3d_alone and the soft-argmax as two launches (conv32to1_fwd + softargmax_fwd)
 _BWD_FUSED = True        # False: a full-resolution layer's backward as two launches (wgrad + BN stage 3 | dgrad + BN stage 1)
-import os as _os
-if _os.environ.get("AS_BWD_FUSED") == "0":      # A/B measurements only
-  _BWD_FUSED = False
 
 
 def set_agg3d(flag: bool):

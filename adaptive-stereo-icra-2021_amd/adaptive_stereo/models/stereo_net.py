@@ -162,6 +162,7 @@ class StereoNet(nn.Module):
     # By-products of the fused soft-argmax kernel; feature_contrast_mean() picks the FCS up
     # from the logits tensor instead of sorting the volume again.
     logits._as_fcs = fcs
+    logits._as_fcs_version = logits._version     # feature_contrast_mean uses the by-product only while the logits are unmodified
     logits._as_argmax = argmax
 
     coarse_scale = self.input_scale + self.k

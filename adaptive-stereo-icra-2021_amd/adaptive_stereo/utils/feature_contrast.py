@@ -3,8 +3,9 @@
 The reference sorts the whole [B,Dc,Hc,Wc] volume along Dc to take ``max - mean(sorted[2:])``.
 Only the two largest values and the sum are needed: fcs = m1 - (sum - m1 - m2)/(Dc-2), which the
 soft-argmax kernel already produces in the same pass over the logits.  StereoNet.forward attaches
-that by-product to the logits tensor; a volume that did not come from StereoNet is scored by
-running the kernel on it.
+that by-product to the logits tensor together with the tensor's version counter; a volume that did not
+come from StereoNet — or one a caller has edited in place since (the counter moved) — is scored by running
+the kernel on it, as the reference recomputes on every call.
 """
 import torch
 
@@ -14,7 +15,7 @@ from .. import _native as nat
 def feature_contrast_mean(cost_volume):
   nat.require_gpu(cost_volume)
   cached = getattr(cost_volume, "_as_fcs", None)
-  if cached is not None:
+  if cached is not None and getattr(cost_volume, "_as_fcs_version", None) == cost_volume._version:
     return cached
   with torch.no_grad():
     logits = nat.f32c(cost_volume.detach())

@@ -345,12 +345,12 @@ int agg3d_units(const as_pcl* g) {
 
 template <int IN, int EPI>
 static int agg_launch_t(const Agg3dArgs& a, int lds_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsPerDevice attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(agg3d_kernel<IN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { as_set_error("as_agg3d_fwd: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((agg3d_kernel<IN, EPI>), dim3(8 * a.per_xcd), dim3(256), lds_bytes, st, a);
   return AS_OK;

@@ -233,12 +233,12 @@ extern "C" int as_agg_tail_ok(const as_pcl* g) {
 
 template <int IN, int NK, bool OUT>
 static int tail_launch_t(const TailArgs& a, int grid, int lds_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsPerDevice attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(agg_tail_kernel<IN, NK, OUT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { as_set_error("as_agg_tail_fwd: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((agg_tail_kernel<IN, NK, OUT>), dim3(grid), dim3(256), lds_bytes, st, a);
   return AS_OK;

@@ -71,6 +71,16 @@ static inline bool as_pcl_ok(const as_pcl* g) {
   return n < ((int64_t)1 << 31);   // kernels index with 32-bit element offsets
 }
 
+// A "done once" flag PER HIP DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only, so a
+// process that drives a second GPU must set it there too (a process-wide flag skipped it: its launches asking for more than
+// 64 KB of LDS then failed).
+struct AsPerDevice {
+  bool done[32] = {};
+  static int dev() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 32 ? d : -1; }
+  bool get() const { const int d = dev(); return d >= 0 && done[d]; }
+  void set() { const int d = dev(); if (d >= 0) done[d] = true; }
+};
+
 static inline int as_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Wave-level sum over all 64 lanes (result in every lane).

@@ -31,16 +31,10 @@
 #define CA_WLDS_OFF (CA_COEF_OFF + 256) // 55,552: B fragments of the taps that are not register-resident [2][4][64][4]
 #define CA_RES 5                        // taps resident in registers (80); with 7 and the 40-register prefetch hipcc spilled 48 registers
 #define CA_LDS_BYTES (CA_WLDS_OFF + (9 - CA_RES) * 4096)   // 71,936
-#define CA_GRID 512                     // two resident workgroups per CU (AS_CA_GRID in the environment: experiments)
-#include <cstdlib>
-static int ca_grid(void) {
-  static const int g = [] {
-    const char* e = getenv("AS_CA_GRID");
-    const int v = e ? atoi(e) : CA_GRID;
-    return v >= 64 && v <= CA_GRID ? v : CA_GRID;
-  }();
-  return g;
-}
+#ifndef CA_GRID
+#define CA_GRID 512                     // two resident workgroups per CU (tests/tools/grid_sweep.sh rebuilds with EXTRA=-DCA_GRID=n)
+#endif
+static int ca_grid(void) { return CA_GRID; }
 
 struct ActArgs {
   const float* zin;        // previous layer's pre-activation
@@ -302,13 +296,13 @@ int conv32_act_parts(void) { return ca_grid(); }
 int conv32_act_launch(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift, float* a_out,
                       const as_pcl* g, const as_conv_shape* s, const float* packed_w, const float* bias, float slope,
                       float* z, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream) {
-  static bool attr_set[2] = {false, false};
+  static AsPerDevice attr_set[2];
   const int fi = a_prevprev != nullptr ? 1 : 0;
   const void* fn = fi ? reinterpret_cast<const void*>(conv32_act_kernel<true>) : reinterpret_cast<const void*>(conv32_act_kernel<false>);
-  if (!attr_set[fi]) {
+  if (!attr_set[fi].get()) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);
     if (e != hipSuccess) { as_set_error("as_conv32_act_fwd: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
-    attr_set[fi] = true;
+    attr_set[fi].set();
   }
   ActArgs a;
   a.zin = z_prev; a.ain = a_prevprev; a.in_scale = in_scale; a.in_shift = in_shift; a.a_out = a_out; a.wq = packed_w;

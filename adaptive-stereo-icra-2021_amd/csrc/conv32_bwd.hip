@@ -36,15 +36,10 @@
 #define BW_XROW_BYTES (64 * 128)        //         pairing shifts g_z, not x: no halo)
 #define BW_COEF_OFF (BW_X_OFF + 2 * BW_XROW_BYTES)   // 77,824: k1, k2, k3, scale, shift, mean [6][32]
 #define BW_LDS_BYTES (BW_COEF_OFF + 6 * 128)          // 78,592
-#define BW_GRID 512                     // two resident workgroups per CU (AS_BW_GRID in the environment: experiments)
-static int bw_grid(void) {
-  static const int g = [] {
-    const char* e = getenv("AS_BW_GRID");
-    const int v = e ? atoi(e) : BW_GRID;
-    return v >= 64 && v <= BW_GRID ? v : BW_GRID;
-  }();
-  return g;
-}
+#ifndef BW_GRID
+#define BW_GRID 512                     // two resident workgroups per CU (tests/tools/grid_sweep.sh rebuilds with EXTRA=-DBW_GRID=n)
+#endif
+static int bw_grid(void) { return BW_GRID; }
 
 struct BwdArgs {
   const float* x;          // layer input a_{l-1} (PCL)
@@ -455,12 +450,12 @@ int conv32_bwd_fused_launch(const float* x, const float* g_a, const float* z, co
                             const float* coef, float slope, const float* next_z, const float* next_scale,
                             const float* next_shift, const float* next_mean, float* g_x, float* partial,
                             float* partial_db, double* next_partial, void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsPerDevice attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_bwd_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS_BYTES);
     if (e != hipSuccess) { as_set_error("as_conv32_bwd_fused: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
-    attr_set = true;
+    attr_set.set();
   }
   BwdArgs a;
   a.x = x; a.ga = g_a; a.z = z; a.wq = packed_wt; a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = mean; a.bn_coef = coef;

@@ -414,15 +414,15 @@ int conv32_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
                                                                                               : AS_LDS_PICK(3, has_res);
   if (res_self) fn = reinterpret_cast<const void*>(conv32_lds_skip_kernel);
 #undef AS_LDS_PICK
-  static bool attr_set[9] = {false, false, false, false, false, false, false, false, false};
+  static AsPerDevice attr_set[9];
   const int fi = res_self ? 8 : mode * 2 + (has_res ? 1 : 0);
-  if (!attr_set[fi]) {
+  if (!attr_set[fi].get()) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES);
     if (e != hipSuccess) {
       as_set_error("conv32_lds: cannot reserve %d bytes of LDS: %s", TL_LDS_BYTES, hipGetErrorString(e));
       return AS_ERR_LAUNCH;
     }
-    attr_set[fi] = true;
+    attr_set[fi].set();
   }
 #ifdef AS_LDS_TRACE_BUILD
   static int trace_countdown = -2;
@@ -768,8 +768,8 @@ bool conv32_wgrad_bnapply_ok(const as_pcl* gout) { return wgrad_lds2(gout); }
 int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
                             const as_conv_shape* s, float* partial, float* partial_db, const WgradBnApply* bn,
                             void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsPerDevice attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv32_wgrad_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, TLW_LDS_BYTES);
     if (e == hipSuccess)
@@ -782,7 +782,7 @@ int conv32_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, 
       as_set_error("conv32_wgrad_lds: cannot reserve %d bytes of LDS: %s", TLW2_LDS_BYTES, hipGetErrorString(e));
       return AS_ERR_LAUNCH;
     }
-    attr_set = true;
+    attr_set.set();
   }
   WgradLdsArgs a;
   a.x = x; a.gz = gz; a.partial = partial; a.partial_db = partial_db;

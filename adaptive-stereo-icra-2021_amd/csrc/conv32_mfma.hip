@@ -132,11 +132,12 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
 // is mostly idle.  Here a workgroup owns ONE 32-voxel tile and its four waves split the taps (wave w takes taps w, w+4, ...):
 // a quarter of the chain, four times the workgroups; waves 1-3 hand their partial accumulators over through LDS and wave 0
 // adds them in fixed order and runs the ordinary epilogue (one BatchNorm partial per 32 voxels).  A different summation order
-// than the one-wave chain (four partial sums), deterministic.  AS_SPLITK=0 in the environment turns it off (A/B runs).
+// than the one-wave chain (four partial sums), deterministic.  (Build with EXTRA=-DCONV32_SPLITK_MAX_M=0 for an A/B run.)
+#ifndef CONV32_SPLITK_MAX_M
 #define CONV32_SPLITK_MAX_M 32768
+#endif
 static inline bool conv32_splitk_applies(int ntaps, long M) {
-  static const bool enabled = [] { const char* e = getenv("AS_SPLITK"); return !(e && e[0] == '0'); }();
-  return enabled && ntaps == 9 && M <= CONV32_SPLITK_MAX_M;
+  return ntaps == 9 && M <= CONV32_SPLITK_MAX_M;
 }
 
 template <int NT>
@@ -452,7 +453,9 @@ static void wgrad_reduce(hipStream_t st, const float* partial, const float* part
                          int accumulate) {
   {
     std::lock_guard<std::mutex> lock(g_defer_mutex);
-    if (g_defer_on) { g_defer_jobs.push_back({partial, partial_db, nchunks, T, dW, db, accumulate}); return; }
+    // only reductions that ACCUMULATE into a gradient sink wait for the flush; a dW that is handed back to the caller
+    // (accumulate == 0: autograd reads it as soon as the entry point returns) is reduced right here
+    if (g_defer_on && accumulate) { g_defer_jobs.push_back({partial, partial_db, nchunks, T, dW, db, accumulate}); return; }
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(as_div_up(T * 1024 + 32, 64)), dim3(1024), 0, st, partial, partial_db, nchunks, T,
                      dW, db, accumulate);

@@ -182,12 +182,12 @@ int conv3d_lds_launch(const float* x, const as_pcl* gin, const float* packed_w, 
   a.run = conv3d_run(gin);
   a.groups = (a.run + 7) / 8;
   const int lds_bytes = a.groups * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsPerDevice attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) { as_set_error("as_conv32_fwd(3-D LDS): %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL(conv3d_lds_kernel, dim3(conv3d_lds_grid(gout)), dim3(256), lds_bytes, (hipStream_t)stream, a);
   AS_CHECK_LAUNCH("as_conv32_fwd(3-D LDS)");
@@ -342,12 +342,12 @@ int conv3d_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, 
   a.run = conv3d_run(gin);
   a.xgroups = (a.run + 7) / 8;
   const int lds_bytes = a.xgroups * 1024 + 16384;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsPerDevice attr_set;
+  if (!attr_set.get()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_wgrad_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     if (e != hipSuccess) { as_set_error("as_conv32_wgrad(3-D LDS): %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL(conv3d_wgrad_lds_kernel, dim3(3 * a.nchunks), dim3(256), lds_bytes, (hipStream_t)stream, a);
   AS_CHECK_LAUNCH("as_conv32_wgrad(3-D LDS)");

@@ -96,6 +96,7 @@ GOLDEN_CASES = [
   "crop_96x256_k4_b2_trained",
   "odd_75x131_k3_b1",
   "kitti_375x1242_k4_b1",
+  "kitti_375x1242_k4_b4",
   "sceneflow_540x960_k4_b1",
 ]
 

@@ -59,6 +59,8 @@ CASES = [
   dict(name="crop_96x256_k4_b2_trained", B=2, H=96, W=256, k=4, s=0, maxdisp=192, gain=20.0, dense=True),
   dict(name="odd_75x131_k3_b1", B=1, H=75, W=131, k=3, s=0, maxdisp=96, gain=20.0, dense=True),
   dict(name="kitti_375x1242_k4_b1", B=1, H=375, W=1242, k=4, s=0, maxdisp=192, gain=1.0, dense=False),
+  # the bench workload (bench.py default, BASELINE.json configs[2]/[3]): 4 pairs per GPU, train-mode BatchNorm over the batch
+  dict(name="kitti_375x1242_k4_b4", B=4, H=375, W=1242, k=4, s=0, maxdisp=192, gain=1.0, dense=False),
   # BASELINE.json configs[1]: SceneFlow Flying 960x540, D=192
   dict(name="sceneflow_540x960_k4_b1", B=1, H=540, W=960, k=4, s=0, maxdisp=192, gain=20.0, dense=False),
 ]

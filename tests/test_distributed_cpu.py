@@ -143,3 +143,23 @@ def test_flat_arena_views_and_rebinding():
   assert a.weight.grad.data_ptr() == arena.grads.data_ptr()
   arena.params[: a.weight.numel()] += 1.0    # an update of the arena is an update of the module
   assert torch.allclose(a.weight, w0 + 1.0)
+
+
+def test_replay_term_denominator_is_clamped_after_the_reduction():
+  """Data-parallel experience replay: a rank whose replay ground truth has NO valid pixel must not inflate the whole-batch
+  denominator (the reference divides by max(sum_r n_r, 1), loss_functions.py:13), nor contribute a gradient."""
+  from adaptive_stereo.adaptation import replay_whole_batch_terms
+  w = 0.05
+  for counts in ((0.0, 17.0), (5.0, 3.0), (0.0, 0.0)):
+    sums = [2.5 * n for n in counts]                      # local khamis SUMS
+    local_mean = [s_ / max(n, 1.0) for s_, n in zip(sums, counts)]
+    six = torch.tensor([1000.0, 1.0, 1.0, 1.0, sum(counts), sum(m * n for m, n in zip(local_mean, counts))])
+    M = max(sum(counts), 1.0)
+    total_grad_weight = 0.0
+    for r, n in enumerate(counts):
+      coef, whole = replay_whole_batch_terms(six, torch.tensor(n), w)
+      assert abs(float(whole) - sum(sums) / M) < 1e-6
+      total_grad_weight += float(coef) * local_mean[r]     # what this rank back-propagates (before the division by N)
+      if n == 0.0:
+        assert float(coef) == 0.0
+    assert abs(total_grad_weight / 1000.0 - w * sum(sums) / M) < 1e-6

@@ -28,13 +28,29 @@ from oracle import stereo_oracle as orc
 
 DEV = "cuda:0"
 EPE_BAR = 1e-3
-# end-to-end gradient bounds (see test_adapt_step_matches_reference_golden); measured worst cases over the seven
-# fixtures are logged by every run (parity_note) and printed by tests/tools/parity_report.py
-# (worst over the seven fixtures on MI355X, round 2: tensor 6.8e-3 / whole network 4.8e-3 / clip norm 1.8e-4 at gain 1;
-# 2.5e-2 / 1.6e-2 / 1.8e-3 at gain 20, where the soft-argmax multiplies every upstream rounding difference by the gain)
+# End-to-end gradient bounds: DERIVED, not guessed.  tests/golden/reassociation_bound.json (tests/tools/reassociation_bound.py)
+# holds what the REFERENCE's own step does to its gradients when nothing but the fp32 summation order of its convolutions
+# changes (the oracle against itself, every convolution summed tap by tap, six fixtures, both tap orders): per-tensor and
+# whole-network relative L2, clip-norm delta, sign flips.  The loss contains |.|, clamp and a bilinear gather whose derivatives
+# jump, so two correct fp32 forwards that differ by 1e-6 disagree on isolated pixels — measured there: 6.8e-3 / 4.6e-3 /
+# 1.7e-4 at gain 1 and 1.9e-2 / 1.3e-2 / 8.4e-3 at gain 20, where the soft-argmax multiplies every upstream rounding
+# difference by the gain.  The bounds are 2 x the worst measured row of the gain class (a GPU kernel is one more reassociation
+# on top of the reference's own); what a run SAW goes to the log through parity_note.
+import json as _json
+import os as _os
+_REASSOC = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "reassociation_bound.json")))
+
+
+def _measured(gain):
+  rows = [r["backward"] for c in _REASSOC["cases"].values() if (c["gain"] <= 1.0) == (gain <= 1.0) for r in c["rows"].values()]
+  return (max(r["worst_tensor_rel_l2"] for r in rows),
+          max(max(r["whole_stereo_rel_l2"], r["whole_feature_rel_l2"]) for r in rows),
+          max(r["clip_norm_rel_delta"] for r in rows), max(r["sign_flips"] / float(r["elements"]) for r in rows))
+
+
 def grad_bounds(gain):
-  """(per-tensor relative L2, whole-network relative L2, clip-norm relative error)"""
-  return (1.5e-2, 8e-3, 1e-3) if gain <= 1.0 else (4e-2, 2.5e-2, 4e-3)
+  """(per-tensor relative L2, whole-network relative L2, clip-norm relative error, sign-flip fraction): 2 x measured."""
+  return tuple(2.0 * v for v in _measured(gain))
 
 
 BN_ATOL, BN_RTOL = 6e-5, 3e-4      # measured worst: 4.6e-5 absolute on a running_var of the refinement at gain 20
@@ -214,7 +230,9 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
   parity_note("after_step[%s]" % case, gradient_sign_flips=flips, noise_level_elements=noise_elems, checked_elements=checked,
               moved_norm=moved, ref_moved_norm=ref_moved)
   assert ref_moved > 100 * lr and abs(moved - ref_moved) <= 5e-4 * ref_moved, (moved, ref_moved)
-  assert flips <= 0.01 * checked, (flips, checked)
+  # sign disagreements: at most twice the fraction the reference shows against its own reassociated self (+ a few counts:
+  # the fixtures hold sub-samples)
+  assert flips <= grad_bounds(meta["gain"])[3] * checked + 8, (flips, checked)
 
 
 def test_gpu_matches_oracle_on_fresh_inputs():
@@ -303,6 +321,14 @@ def test_full_size_properties_kitti():
     pred_c = out["pred_disp_l/4"] / 16.0
     assert float(pred_c.min()) >= 0.0 and float(pred_c.max()) <= 11.0 + 1e-4
     assert float(feature_contrast_mean(logits).min()) >= 0.0
+    # 3b. the FCS by-product attached to the logits is only trusted while the tensor is unmodified: after an in-place edit
+    #     the score is recomputed, as the reference recomputes on every call (utils/feature_contrast.py:12-23)
+    edited = out_again["cost_volume_l/4"]
+    before = feature_contrast_mean(edited).clone()
+    edited[:, 3] += 7.0                                  # plane 3 becomes the maximum everywhere
+    after = feature_contrast_mean(edited)
+    srt = torch.sort(edited, dim=1, descending=True)[0]
+    assert float((after - (srt[:, 0] - srt[:, 2:].mean(dim=1))).abs().max()) < 1e-4 and float((after - before).abs().min()) > 1.0
     # 4. identical left/right features => the d=0 plane of the volume is zero and the volume is
     #    antisymmetric under swapping the operands
     g = ops.Pcl(B, 12, 24, 78, 1, 1, 1)
@@ -416,54 +442,6 @@ def test_two_stream_feature_extraction_equals_one_stream():
     assert got[0] == ref[0], (got[0], ref[0])
     for a, b in zip(got[1:], ref[1:]):
       assert torch.equal(a, b)
-
-
-def test_weight_gradients_on_a_side_stream_equal_the_one_stream_order():
-  """Inside a step's multi-stream region the accumulate-into-sink weight gradients of the small layers run on a side
-  stream next to the data-gradient chain (hip_ops._WgradSide); operands are kept alive / out of the buffer pool until
-  the join and the sinks are ordered by events, so eager stepping and graph replay must give the bits of the inline
-  order — losses, weights, gradients, BatchNorm buffers — and the side stream must really have been used."""
-  from adaptive_stereo import hip_ops
-  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
-  H, W, B = 96, 256, 2
-  batches = [syn.stereo_pair(B, H, W, seed=s) for s in (71, 72, 73, 74)]
-  batches = [(l.to(DEV), r.to(DEV)) for l, r in batches]
-  results = []
-  prev = hip_ops.set_wgrad_side(False)
-  try:
-    for side, use_graph in ((False, False), (True, False), (True, True)):
-      hip_ops.set_wgrad_side(side)
-      fnet, snet = build(meta)
-      adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
-      forks = []
-      orig = hip_ops._wgrad_side_stream
-      def counting():
-        st = orig()
-        forks.append(st is not None)
-        return st
-      hip_ops._wgrad_side_stream = counting
-      try:
-        adapter.step(*batches[0])
-        if use_graph:
-          adapter.capture(*batches[0], warmup=1)
-        else:
-          adapter.step(*batches[0])
-      finally:
-        hip_ops._wgrad_side_stream = orig
-      assert any(forks) == side, (side, sum(forks), len(forks))
-      losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
-      torch.cuda.synchronize()
-      bufs = torch.cat([b.detach().double().reshape(-1) for net in (fnet, snet) for _, b in sorted(net.named_buffers())])
-      results.append((losses, adapter.arena.params.clone(), adapter.arena.grads.clone(), bufs, sum(forks)))
-  finally:
-    hip_ops.set_wgrad_side(prev)
-  ref = results[0]
-  for got in results[1:]:
-    assert got[0] == ref[0], (got[0], ref[0])
-    for a, b in zip(got[1:4], ref[1:4]):
-      assert torch.equal(a, b)
-  from conftest import parity_note
-  parity_note("wgrad_side_stream", forked_weight_gradients_per_step=results[1][4] // 2, bit_identical=True)
 
 
 def test_deferred_weight_gradient_reductions_equal_the_immediate_ones():

@@ -12,7 +12,17 @@ order — and the differences are written to tests/golden/reassociation_bound.js
   epe_delta_refined          mean |delta pred_disp_l/0|  (the north-star's EPE, oracle against itself)
   loss_delta
 
-Run in the build container (CPU):  python tests/tools/reassociation_bound.py
+and, for the BACKWARD pass (the same two runs, autograd through the tap sums):
+
+  worst_tensor_rel_l2        max over parameter tensors of |g' - g|_2 / |g|_2   (tensors whose gradient is rounding noise, and
+                             the two single-number output biases, excluded exactly as tests/test_gpu_end_to_end.py excludes them)
+  whole_{stereo,feature}_rel_l2   the same over each network's whole gradient vector
+  clip_norm_rel_delta        relative change of the stereo network's gradient norm (what clip_grad_norm_ scales by)
+  sign_flips / elements      gradient elements above the noise floor whose sign differs (Adam's first step is +-lr by sign)
+
+tests/test_gpu_end_to_end.py:grad_bounds() is derived from these rows.
+
+Run in the build container (CPU):  python tests/tools/reassociation_bound.py [case ...]
 """
 import json
 import os
@@ -29,7 +39,9 @@ from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
 from adaptive_stereo.utils import synthetic as syn       # noqa: E402
 from oracle import stereo_oracle as orc                  # noqa: E402
 
-CASES = ["plumbing_240x320_k3_b1", "crop_96x256_k4_b1", "crop_96x256_k4_b2_trained", "odd_75x131_k3_b1"]
+CASES = ["plumbing_240x320_k3_b1", "crop_96x256_k4_b1", "crop_96x256_k4_b2_trained", "odd_75x131_k3_b1",
+         "kitti_375x1242_k4_b1", "sceneflow_540x960_k4_b1"]
+BIG = ("kitti_375x1242_k4_b1", "sceneflow_540x960_k4_b1")      # full-size cases: the two all-convolution orders only
 
 
 class TapSum(object):
@@ -92,28 +104,64 @@ def run(meta, shim):
   saved = orc.F
   orc.F = shim if shim is not None else saved
   try:
-    res = orc.adapt_step(fp, sp, {}, left, right, meta["k"], meta["s"], meta["maxdisp"], lr=meta["lr"])
+    # no clip, lr 0: p.grad keeps the raw gradients of the step, the parameters do not move
+    res = orc.adapt_step(fp, sp, {}, left, right, meta["k"], meta["s"], meta["maxdisp"], lr=0.0, clip=False)
   finally:
     orc.F = saved
   k, s = meta["k"], meta["s"]
+  grads = {}
+  for net, group in (("stereo", sp), ("feature", fp)):
+    for name, p in group.items():
+      if p.requires_grad and p.grad is not None:
+        grads[(net, name)] = p.grad.detach().clone()
   return (res["outputs"]["cost_volume_l/%d" % (s + k)].detach(), res["outputs"]["pred_disp_l/%d" % s].detach(),
-          float(res["loss"]))
+          float(res["loss"]), grads)
+
+
+def grad_rows(base, other, scale):
+  """The quantities tests/test_gpu_end_to_end.py bounds, for two gradient sets of the same step."""
+  worst = (0.0, "")
+  whole = {"stereo": [0.0, 0.0], "feature": [0.0, 0.0]}
+  flips = elems = 0
+  for (net, name), g in base.items():
+    h = other[(net, name)]
+    diff = (h.double() - g.double())
+    whole[net][0] += float(diff.pow(2).sum()); whole[net][1] += float(g.double().pow(2).sum())
+    if float(g.abs().max()) < 1e-6 * scale or name.endswith(("conv2d_out.bias", "conv3d_alone.bias")):
+      continue
+    rel = float(diff.norm() / g.double().norm())
+    worst = max(worst, (rel, "%s.%s" % (net, name)))
+    live = torch.minimum(g.abs(), h.abs()) >= 1e-6 * scale
+    flips += int(((torch.sign(g) != torch.sign(h)) & live).sum()); elems += int(live.sum())
+  norm = lambda gs: float(torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(v) for (n_, _), v in gs.items() if n_ == "stereo"])))
+  nb, no = norm(base), norm(other)
+  return {"worst_tensor_rel_l2": worst[0], "worst_tensor": worst[1],
+          "whole_stereo_rel_l2": (whole["stereo"][0] / whole["stereo"][1]) ** 0.5,
+          "whole_feature_rel_l2": (whole["feature"][0] / whole["feature"][1]) ** 0.5,
+          "clip_norm_rel_delta": abs(no - nb) / nb, "sign_flips": flips, "elements": elems}
 
 
 def main():
   torch.set_num_threads(8)
+  path = os.path.join(HERE, "..", "golden", "reassociation_bound.json")
   report = {"torch": torch.__version__, "what": __doc__.split("\n")[0], "cases": {}}
+  only = sys.argv[1:]
+  if only and os.path.exists(path):
+    report["cases"] = json.load(open(path))["cases"]          # re-measure the named cases, keep the others
   for case in CASES:
+    if only and case not in only:
+      continue
     meta = Golden(case).meta
     scale = max(1.0, meta["gain"])
-    base_logits, base_pred, base_loss = run(meta, None)
+    base_logits, base_pred, base_loss, base_grads = run(meta, None)
     srt = torch.sort(base_logits, dim=1, descending=True)[0]
     gap = srt[:, 0] - srt[:, 1]
     base_am = torch.argmax(base_logits, dim=1)
     rows = {}
-    for label, shim in (("conv3d_taps_fwd", TapSum(+1, (3,))), ("conv3d_taps_rev", TapSum(-1, (3,))),
-                        ("all_convs_taps_fwd", TapSum(+1, (2, 3))), ("all_convs_taps_rev", TapSum(-1, (2, 3)))):
-      logits, pred, loss = run(meta, shim)
+    variants = (("conv3d_taps_fwd", TapSum(+1, (3,))), ("conv3d_taps_rev", TapSum(-1, (3,))),
+                ("all_convs_taps_fwd", TapSum(+1, (2, 3))), ("all_convs_taps_rev", TapSum(-1, (2, 3))))
+    for label, shim in (variants[2:] if case in BIG else variants):
+      logits, pred, loss, grads = run(meta, shim)
       flips = torch.argmax(logits, dim=1) != base_am
       rows[label] = {
           "logit_delta_over_gain": float((logits - base_logits).abs().max()) / scale,
@@ -121,10 +169,9 @@ def main():
           "max_gap_at_flip_over_gain": float(gap[flips].max()) / scale if bool(flips.any()) else 0.0,
           "epe_delta_refined": float((pred - base_pred).abs().mean()),
           "max_delta_refined": float((pred - base_pred).abs().max()),
-          "loss_delta": abs(loss - base_loss)}
+          "loss_delta": abs(loss - base_loss), "backward": grad_rows(base_grads, grads, scale)}
       print(case, label, rows[label], flush=True)
     report["cases"][case] = {"gain": meta["gain"], "rows": rows}
-  path = os.path.join(HERE, "..", "golden", "reassociation_bound.json")
   with open(path, "w") as f:
     json.dump(report, f, indent=1, sort_keys=True)
 
