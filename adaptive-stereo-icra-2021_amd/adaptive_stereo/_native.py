@@ -46,6 +46,12 @@ class BnMerge(ctypes.Structure):
              [("nparts", ctypes.c_int32), ("momentum", c_float), ("eps", c_float)]
 
 
+class TrunkBn(ctypes.Structure):
+  """as_trunk_bn: a BatchNorm of the small-map trunk still in per-workgroup partials, per statistics group."""
+  _fields_ = [(n, c_vp) for n in ("stat_mean", "stat_m2", "stat_cnt", "gamma", "beta", "state")] + \
+             [("nparts", ctypes.c_int32), ("eps", c_float)]
+
+
 _P = ctypes.POINTER
 _SIGNATURES = {
   # name: (restype, [argtypes])
@@ -103,6 +109,13 @@ _SIGNATURES = {
   "as_agg3d_parts": (c_int, [_P(Pcl)]),
   "as_agg3d_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, _P(BnMerge), c_vp, c_vp, c_int, c_vp, c_vp, c_float, c_vp, c_vp,
                            c_vp, c_vp]),
+  "as_trunk_parts": (c_int, [_P(Pcl), c_int]),
+  "as_trunk_fwd": (c_int, [c_vp, c_vp, _P(TrunkBn), c_vp, _P(Pcl), c_int, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  "as_trunk_finish_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_int, c_int, _P(c_vp), _P(c_vp), c_float, c_vp]),
+  "as_trunk_bwd_workspace": (c_i64, [_P(Pcl), c_int]),
+  "as_trunk_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _P(Pcl), c_int, c_float,
+                           c_vp, c_vp, c_int, c_vp, c_vp]),
+  "as_trunk_finish_bwd": (c_int, [c_vp, c_int, c_int, _P(c_vp), _P(c_vp), c_int, c_vp]),
   "as_agg_tail_ok": (c_int, [_P(Pcl)]),
   "as_agg_tail_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(BnMerge), c_vp, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_conv3d_out_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp]),

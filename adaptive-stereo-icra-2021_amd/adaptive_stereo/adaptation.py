@@ -134,7 +134,7 @@ class OnlineAdapter(object):
 
   def __init__(self, feature_net, stereo_net, height, width, lr=5e-5, clip_grad_norm=True,
                smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None, sync_bn=False,
-               overlap_features=True, force_data_parallel=False):
+               overlap_features=True, force_data_parallel=False, pair_features=True):
     self.feature_net, self.stereo_net = feature_net, stereo_net
     self.scale = stereo_net.input_scale
     self.coarse_scale = stereo_net.input_scale + stereo_net.k
@@ -166,6 +166,9 @@ class OnlineAdapter(object):
     self._capture_origin = None            # handle of the stream a capture opened by capture()/capture_infer() runs on
     self.fork_fallbacks = 0                # times _features_two_streams declined to fork (foreign or nested capture)
     self.overlap_features = overlap_features
+    # train mode: both images of a pair through the feature extractor in ONE pass with two BatchNorm statistics groups
+    # (FeatureExtractorNetwork.forward_pair); False: two passes, side by side on two streams (the round-2 arrangement)
+    self.pair_features = pair_features
     self.infer_batched_features_max = 1 << 30     # pairs per call up to which inference batches left and right images
 
   # -- forward only: evaluate_model.py:52-60 / train.py:94-96 ------------------------------------
@@ -200,6 +203,11 @@ class OnlineAdapter(object):
       return self._features_two_streams(left, right)
     both = self.feature_net(_adjacent_or_cat(left, right))
     return both[:left.shape[0]], both[left.shape[0]:]
+
+  def _features_train(self, left, right):
+    if self.pair_features and hip_ops.trunk_enabled() and hasattr(self.feature_net, "forward_pair"):
+      return self.feature_net.forward_pair(left, right)
+    return self._features_two_streams(left, right)
 
   def _features_two_streams(self, left, right):
     """The two feature extractions of a pair are independent and, at 1/16 resolution, far too small to fill the chip
@@ -255,7 +263,7 @@ class OnlineAdapter(object):
 
   def _forward_maps(self, left, right):
     if self.bn_sync is None:
-      fl, fr = self._features_two_streams(left, right)      # backward follows: autograd replays each part on its stream
+      fl, fr = self._features_train(left, right)
     else:
       fl, fr = self.feature_net(left), self.feature_net(right)   # collectives inside: one stream, one order
     out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
@@ -320,7 +328,7 @@ class OnlineAdapter(object):
         if not train:
           fl, fr = self._features_eval(left, right)
         else:
-          fl, fr = self._features_two_streams(left, right) if two_streams else (self.feature_net(left), self.feature_net(right))
+          fl, fr = self._features_train(left, right) if two_streams else (self.feature_net(left), self.feature_net(right))
         out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
         pred = out["pred_disp_l/{}".format(self.scale)]
         warped, mask = self.warper(right, pred, right_to_left=True)
@@ -330,7 +338,7 @@ class OnlineAdapter(object):
         replay_loss = None
         if replay is not None:
           rl, rr, rgt = replay
-          rfl, rfr = self._features_two_streams(rl, rr) if two_streams else (self.feature_net(rl), self.feature_net(rr))
+          rfl, rfr = self._features_train(rl, rr) if two_streams else (self.feature_net(rl), self.feature_net(rr))
           rout = self.stereo_net(rl, rfl, rfr, "l", output_cost_volume=True)
           replay_loss = khamis_robust_loss(rout["pred_disp_l/{}".format(self.scale)], rgt)
           backprop = loss + er_loss_weight * replay_loss
@@ -568,13 +576,7 @@ def replay_whole_batch_terms(six, n_gt_local, er_loss_weight):
     return er_loss_weight * six[0] / m_total * n_gt_local, six[5] / m_total
 
 
-def _adjacent_or_cat(left, right):
-    """[left; right] along the batch: a view when the two already sit back to back in one buffer, else a copy."""
-    if (left.is_contiguous() and right.is_contiguous() and left.shape == right.shape and left.dtype == right.dtype
-            and left.untyped_storage().data_ptr() == right.untyped_storage().data_ptr()
-            and right.data_ptr() == left.data_ptr() + left.numel() * left.element_size()):
-        return torch.as_strided(left, (2 * left.shape[0],) + tuple(left.shape[1:]), left.stride(), left.storage_offset())
-    return torch.cat([left, right])
+_adjacent_or_cat = hip_ops.adjacent_or_cat
 
 
 def fill_step_scalars(buf, loss_sum, valid_count, fcs_sum, fcs_count):

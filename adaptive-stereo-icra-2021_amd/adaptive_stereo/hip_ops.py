@@ -941,25 +941,57 @@ def _down(n):
   return (n - 1) // 2 + 1
 
 
+_TRUNK = True             # False: the trunk on the generic kernels (conv + finalize + activation launches per block)
+
+
+def set_trunk(flag: bool):
+  """Train-mode trunk of the feature extractor on the one-launch-per-layer kernels (csrc/trunk.hip) or on the generic
+  per-operation kernels (parity tests compare both); returns the previous setting."""
+  global _TRUNK
+  prev, _TRUNK = _TRUNK, bool(flag)
+  return prev
+
+
+def trunk_enabled():
+  return _TRUNK and _BN_SYNC is None
+
+
+def adjacent_or_cat(left, right):
+  """[left; right] along the batch: a view when the two already sit back to back in one buffer, else a copy."""
+  if (left.is_contiguous() and right.is_contiguous() and left.shape == right.shape and left.dtype == right.dtype
+      and left.untyped_storage().data_ptr() == right.untyped_storage().data_ptr()
+      and right.data_ptr() == left.data_ptr() + left.numel() * left.element_size()):
+    return torch.as_strided(left, (2 * left.shape[0],) + tuple(left.shape[1:]), left.stride(), left.storage_offset())
+  return torch.cat([left, right])
+
+
+def _host_ptrs(tensors):
+  return (nat.c_vp * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class FeatureExtractorFn(torch.autograd.Function):
-  """rgb [B,3,H,W] -> features [B,32,Hc,Wc] (NCHW, the public layout).
+  """rgb [G*B,3,H,W] -> features [G*B,32,Hc,Wc] (NCHW, the public layout).  ``groups`` = G statistics groups: G = 2 is the
+  two images of a pair (left batch, then right batch) through ONE pass — the reference calls feature_net twice
+  (adapt.py:72), so train-mode BatchNorm moments, running-statistics updates and gradients are taken per group.
   params: k x (downsample w, b), 6 x (conv w, conv b, bn w, bn b), conv_alone (w, b)."""
 
   @staticmethod
-  def forward(ctx, rgb, k, train, grad_on, bn_buffers, sinks, *params):
-    k = int(k)
+  def forward(ctx, rgb, k, groups, train, grad_on, bn_buffers, sinks, *params):
+    k, groups = int(k), int(groups)
     assert len(params) == 2 * k + 26
     rgb = f32c(rgb)
     params = [f32c(p) for p in params]
     B, C, H, W = rgb.shape
     if C != 3:
       raise RuntimeError("FeatureExtractorFn: expected an RGB image [B,3,H,W]")
+    if groups < 1 or B % groups != 0:
+      raise RuntimeError("FeatureExtractorFn: %d images do not split into %d statistics groups" % (B, groups))
     dev = rgb.device
     lib = nat.load()
     need_bwd = grad_on and any(ctx.needs_input_grad)   # grad_on: the caller's grad mode (forward() itself always runs
     # with grad disabled, and needs_input_grad stays True under torch.no_grad())
 
-    # head: level 0 = image (PCL4, halo 2); level i = output of downsample[i-1]
+    # head: level 0 = image (PCL4, halo 2); level i = output of downsample[i-1].  No BatchNorm: batch-independent
     g4 = Pcl(B, 1, H, W, 0, 2, 2)
     in4 = POOL.get(g4, dev, channels=4)
     call("as_pack_in4", None, ptr(rgb), 3, ptr(in4), g4, stream())
@@ -983,26 +1015,72 @@ class FeatureExtractorFn(torch.autograd.Function):
     g = geoms[-1]
     shape = conv_shape_2d(1)
     tp = params[2 * k:]
-    xs, zs, sts = [levels[-1]], [], []
-    for l in range(6):
-      wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
-      rm, rv = bn_buffers[l]
-      z, a, st = block_forward(xs[-1], g, shape, wl, bl, gamma, beta, rm, rv, train, True, need_bwd)
-      zs.append(z); sts.append(st); xs.append(a)
+    trunk = bool(train) and _TRUNK and _BN_SYNC is None
+    if not trunk and groups != 1 and train:
+      raise RuntimeError("FeatureExtractorFn: several statistics groups in train mode need the trunk kernels "
+                         "(set_trunk(True), no cross-replica BatchNorm)")
+    states = None
+    if trunk:
+      # one launch per layer for all groups: layer l forms its operand a_{l-1} = lrelu(BN(z_{l-1})) + a_{l-2} while staging,
+      # merging BN_{l-1} from the partials launch l-1 left behind, and leaves a_{l-1} as a by-product (csrc/trunk.hip)
+      parts = lib.as_trunk_parts(g, groups)
+      states = torch.empty(6, groups, 5, 32, dtype=torch.float32, device=dev)
+      xs, zs, sts = [levels[-1]], [], []
+      prev_bn, keep = None, []
+      for l in range(7):
+        wl, bl = tp[4 * l], tp[4 * l + 1]
+        z = POOL.get(g, dev)
+        stats = StatParts(groups * parts, dev) if l < 6 else None
+        sm, s2, sc = (stats.mean, stats.m2, stats.cnt) if stats is not None else (None, None, None)
+        if l == 0:
+          call("as_trunk_fwd", ptr(xs[0]), None, None, None, g, groups, ptr(pack_weights(wl, shape, False)), ptr(bl), LEAKY_SLOPE,
+               ptr(z), ptr(sm), ptr(s2), ptr(sc), stream())
+        else:
+          a_prev = POOL.get(g, dev)
+          call("as_trunk_fwd", ptr(zs[-1]), ptr(xs[-1]), prev_bn, ptr(a_prev), g, groups, ptr(pack_weights(wl, shape, False)),
+               ptr(bl), LEAKY_SLOPE, ptr(z), ptr(sm), ptr(s2), ptr(sc), stream())
+          xs.append(a_prev)
+        if l < 6:
+          gamma, beta = tp[4 * l + 2], tp[4 * l + 3]
+          prev_bn = nat.TrunkBn(ptr(sm), ptr(s2), ptr(sc), ptr(gamma), ptr(beta), ptr(states[l]), parts, BN_EPS)
+          keep.append(stats)
+          zs.append(z)
+        else:
+          out = z
+      feats = torch.empty(B, 32, g.H, g.W, dtype=torch.float32, device=dev)
+      rms = [bn_buffers[l][0] for l in range(6)]
+      rvs = [bn_buffers[l][1] for l in range(6)]
+      _rmw_wait(rms[0])
+      call("as_trunk_finish_fwd", ptr(out), g, ptr(feats), ptr(states), 6, groups, _host_ptrs(rms), _host_ptrs(rvs), BN_MOMENTUM,
+           stream())
+      _rmw_done(rms[0])
+      POOL.put(out, g)
       if not need_bwd:
-        POOL.put(xs[-2], g)
-    out = conv32(xs[6], g, pack_weights(tp[24], shape, False), tp[25], g, shape)
-    feats = pcl_interior(out, g)[:, 0].permute(0, 3, 1, 2).contiguous()
-    POOL.put(out, g)
+        for buf in xs[1:] + zs:
+          POOL.put(buf, g)
+    else:
+      xs, zs, sts = [levels[-1]], [], []
+      for l in range(6):
+        wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
+        rm, rv = bn_buffers[l]
+        z, a, st = block_forward(xs[-1], g, shape, wl, bl, gamma, beta, rm, rv, train, True, need_bwd)
+        zs.append(z); sts.append(st); xs.append(a)
+        if not need_bwd:
+          POOL.put(xs[-2], g)
+      out = conv32(xs[6], g, pack_weights(tp[24], shape, False), tp[25], g, shape)
+      feats = pcl_interior(out, g)[:, 0].permute(0, 3, 1, 2).contiguous()
+      POOL.put(out, g)
     if need_bwd:
-      ctx.k, ctx.g4, ctx.geoms, ctx.train = k, g4, geoms, bool(train)
+      ctx.k, ctx.g4, ctx.geoms, ctx.train, ctx.groups = k, g4, geoms, bool(train), groups
       ctx.sinks = sinks
       ctx.in4, ctx.levels = in4, levels
-      ctx.xs, ctx.zs, ctx.sts = xs, zs, sts
+      ctx.xs, ctx.zs, ctx.sts, ctx.states = xs, zs, sts, states
       ctx.save_for_backward(*params)
     else:
-      POOL.put(xs[-1], g); POOL.put(in4, g4, channels=4)
-      for buf, gi in zip(levels[:-1], geoms[:-1]):
+      if not trunk:
+        POOL.put(xs[-1], g)
+      POOL.put(in4, g4, channels=4)
+      for buf, gi in zip(levels[:-1] if not trunk else levels, geoms[:-1] if not trunk else geoms):
         POOL.put(buf, gi)
     return feats
 
@@ -1023,18 +1101,21 @@ class FeatureExtractorFn(torch.autograd.Function):
     sinks = ctx.sinks
     g_out = POOL.get(g, dev)
     pcl_interior(g_out, g).copy_(f32c(g_feats).permute(0, 2, 3, 1).unsqueeze(1))
-    dW, db = conv32_wgrad(xs[6], g, g_out, g, shape, True, _sink(sinks, 2 * k + 24), _sink(sinks, 2 * k + 25))
-    grads[2 * k + 24], grads[2 * k + 25] = dW, db
-    g_a = conv32(g_out, g, pack_weights(tp[24], shape, True), None, g, shape)
-    POOL.put(g_out, g)
-    for l in range(5, -1, -1):
-      wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
-      g_x, dW, db, g_gamma, g_beta, _ = block_backward(
-          g_a, xs[l], zs[l], sts[l], wl, gamma, g, shape, ctx.train, True, True,
-          sinks[2 * k + 4 * l:2 * k + 4 * l + 4] if sinks is not None else None)
-      grads[2 * k + 4 * l:2 * k + 4 * l + 4] = [dW, db, g_gamma, g_beta]
-      POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
-      g_a = g_x
+    if ctx.states is not None:
+      g_a = FeatureExtractorFn._trunk_backward(ctx, g_out, tp, grads, sinks, dev)
+    else:
+      dW, db = conv32_wgrad(xs[6], g, g_out, g, shape, True, _sink(sinks, 2 * k + 24), _sink(sinks, 2 * k + 25))
+      grads[2 * k + 24], grads[2 * k + 25] = dW, db
+      g_a = conv32(g_out, g, pack_weights(tp[24], shape, True), None, g, shape)
+      POOL.put(g_out, g)
+      for l in range(5, -1, -1):
+        wl, bl, gamma, beta = tp[4 * l:4 * l + 4]
+        g_x, dW, db, g_gamma, g_beta, _ = block_backward(
+            g_a, xs[l], zs[l], sts[l], wl, gamma, g, shape, ctx.train, True, True,
+            sinks[2 * k + 4 * l:2 * k + 4 * l + 4] if sinks is not None else None)
+        grads[2 * k + 4 * l:2 * k + 4 * l + 4] = [dW, db, g_gamma, g_beta]
+        POOL.put(g_a, g); POOL.put(zs[l], g); POOL.put(xs[l + 1], g)
+        g_a = g_x
 
     # head, last strided convolution first.  g_a is the gradient w.r.t. levels[k-1] (geometry geoms[k-1]).
     for i in range(k - 1, -1, -1):
@@ -1064,8 +1145,76 @@ class FeatureExtractorFn(torch.autograd.Function):
     POOL.put(ctx.in4, g4, channels=4)
     for buf, gi in zip(levels, geoms):
       POOL.put(buf, gi)
-    ctx.xs = ctx.zs = ctx.sts = ctx.levels = ctx.in4 = None
-    return (None, None, None, None, None, None) + tuple(grads)
+    ctx.xs = ctx.zs = ctx.sts = ctx.levels = ctx.in4 = ctx.states = None
+    return (None, None, None, None, None, None, None) + tuple(grads)
+
+  @staticmethod
+  def _trunk_backward(ctx, g_out, tp, grads, sinks, dev):
+    """The trunk's backward on csrc/trunk.hip: conv_alone, then blocks 6..1, one launch each for all groups; returns the
+    gradient w.r.t. the head's output.  Parameter gradients go straight to their sinks, or come back through ``grads``."""
+    lib = nat.load()
+    k, groups, g = ctx.k, ctx.groups, ctx.geoms[-1]
+    xs, zs, states = ctx.xs, ctx.zs, ctx.states
+    shape = conv_shape_2d(1)
+    parts = lib.as_trunk_parts(g, groups)
+    base = 2 * k
+
+    def dest(i, like):
+      s_ = _sink(sinks, base + i)
+      if s_ is not None:
+        return s_, True
+      return torch.empty_like(like), False
+
+    bn_grads = torch.empty(6, groups, 2, 32, dtype=torch.float32, device=dev)
+    sums = [torch.empty(groups * parts * 64, dtype=torch.float64, device=dev) for _ in range(6)]
+    g_a = g_out
+    for l in range(6, -1, -1):
+      wl, bl = tp[4 * l], tp[4 * l + 1]
+      dW, sunk_w = dest(4 * l, wl)
+      db, sunk_b = dest(4 * l + 1, bl)
+      if sunk_w != sunk_b:                       # one flag for both: fall back to fresh tensors
+        dW, db, sunk_w = torch.empty_like(wl), torch.empty_like(bl), False
+      ws = _empty(lib.as_trunk_bwd_workspace(g, groups), dev)
+      if sunk_w:
+        _keep_for_deferred_reduce(ws)
+        _rmw_wait(dW)
+      g_x = POOL.get(g, dev)
+      zn, stn, sn = (zs[l - 1], states[l - 1], sums[l - 1]) if l >= 1 else (None, None, None)
+      if l == 6:
+        call("as_trunk_bwd", ptr(g_a), None, None, None, 0, None, None, ptr(xs[6]), ptr(pack_weights(wl, shape, True)), ptr(g_x),
+             ptr(zn), ptr(stn), ptr(sn), g, groups, LEAKY_SLOPE, ptr(dW), ptr(db), int(sunk_w), ptr(ws), stream())
+      else:
+        call("as_trunk_bwd", ptr(g_a), ptr(zs[l]), ptr(states[l]), ptr(sums[l]), parts, ptr(tp[4 * l + 2]), ptr(bn_grads[l]),
+             ptr(xs[l]), ptr(pack_weights(wl, shape, True)), ptr(g_x), ptr(zn), ptr(stn), ptr(sn), g, groups, LEAKY_SLOPE,
+             ptr(dW), ptr(db), int(sunk_w), ptr(ws), stream())
+      if sunk_w:
+        _rmw_done(dW)
+      else:
+        grads[base + 4 * l], grads[base + 4 * l + 1] = dW, db
+      POOL.put(g_a, g)
+      if l < 6:
+        POOL.put(zs[l], g)
+      POOL.put(xs[l + 1] if l < 6 else None, g)
+      g_a = g_x
+    gg, gb, all_sunk = [], [], True
+    for l in range(6):
+      d1, s1 = dest(4 * l + 2, tp[4 * l + 2])
+      d2, s2 = dest(4 * l + 3, tp[4 * l + 3])
+      if not (s1 and s2):
+        all_sunk = False
+      gg.append(d1); gb.append(d2)
+    if not all_sunk:
+      gg = [torch.empty_like(tp[4 * l + 2]) for l in range(6)]
+      gb = [torch.empty_like(tp[4 * l + 3]) for l in range(6)]
+    else:
+      _rmw_wait(gg[0])
+    call("as_trunk_finish_bwd", ptr(bn_grads), 6, groups, _host_ptrs(gg), _host_ptrs(gb), int(all_sunk), stream())
+    if all_sunk:
+      _rmw_done(gg[0])
+    else:
+      for l in range(6):
+        grads[base + 4 * l + 2], grads[base + 4 * l + 3] = gg[l], gb[l]
+    return g_a
 
 
 # ----------------------------------------------------------------------------------------

@@ -81,6 +81,23 @@ class FeatureExtractorNetwork(nn.Module):
     self.conv_alone = nn.Conv2d(32, 32, kernel_size=3, stride=1, padding=1)
 
   def forward(self, rgb_img):
+    return self._run(rgb_img, 1)
+
+  def forward_pair(self, left_img, right_img):
+    """feature_net(left), feature_net(right) of the reference (adapt.py:72) as ONE pass over [left; right] with two
+    statistics groups: in train mode BatchNorm moments, running-statistics updates (left first, then right) and
+    gradients are taken per image batch, exactly as two calls take them; half the launches of a latency-bound chain.
+    Returns (left_features, right_features)."""
+    if left_img.shape != right_img.shape:
+      raise RuntimeError("FeatureExtractorNetwork.forward_pair: left %s and right %s differ in shape" % (
+          tuple(left_img.shape), tuple(right_img.shape)))
+    n = left_img.shape[0]
+    if self.training and (not hip_ops.trunk_enabled()):
+      return self._run(left_img, 1), self._run(right_img, 1)
+    both = self._run(hip_ops.adjacent_or_cat(left_img, right_img), 2 if self.training else 1)
+    return both[:n], both[n:]
+
+  def _run(self, rgb_img, groups):
     nat.require_gpu(rgb_img)
     params = []
     for conv in self.downsample:          # no activation between the strided convs (:81-82)
@@ -88,10 +105,11 @@ class FeatureExtractorNetwork(nn.Module):
     live = [b.live() for b in self.residual_blocks]
     block_params, buffers = _block_params(live)
     params += block_params + [self.conv_alone.weight, self.conv_alone.bias]
-    out = hip_ops.FeatureExtractorFn.apply(rgb_img, self.k, self.training, torch.is_grad_enabled(), buffers,
+    out = hip_ops.FeatureExtractorFn.apply(rgb_img, self.k, groups, self.training, torch.is_grad_enabled(), buffers,
                                            hip_ops.grad_sinks(params), *params)
     if self.training:
-      _count_batches(live)
+      for _ in range(groups):
+        _count_batches(live)
     return out
 
 

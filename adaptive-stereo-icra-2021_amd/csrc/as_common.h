@@ -12,6 +12,10 @@
 #define AS_ERR_LAUNCH (-2)
 
 void as_set_error(const char* fmt, ...);
+// slab reduction behind every 32->32 weight-gradient kernel (conv32_mfma.hip): dW[o][i][t] (+)= sum_chunks partial[chunk][t][i][o],
+// db[o] (+)= sum_chunks partial_db[chunk][o]; recorded instead of launched while a deferral region is open (as_wgrad_defer)
+void as_wgrad_reduce_enqueue(hipStream_t st, const float* partial, const float* partial_db, int nchunks, int T, float* dW,
+                             float* db, int accumulate);
 // measurement hook (optim.hip): event pair around a kernel launch; no-ops unless enabled
 void as_prof_mark(int kernel_id, hipStream_t st, int begin, double flops);
 // kernel ids of the measurement hook (bench.py reads them back with as_prof_read); the `flops` argument carries FLOPs for

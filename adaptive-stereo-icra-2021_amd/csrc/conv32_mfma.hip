@@ -447,6 +447,13 @@ struct PendingReduce { const float* partial; const float* partial_db; int nchunk
 static std::mutex g_defer_mutex;
 static bool g_defer_on = false;
 static std::vector<PendingReduce> g_defer_jobs;
+static void wgrad_reduce(hipStream_t st, const float* partial, const float* partial_db, int nchunks, int T, float* dW, float* db,
+                         int accumulate);
+// (for the other translation units: trunk.hip)
+void as_wgrad_reduce_enqueue(hipStream_t st, const float* partial, const float* partial_db, int nchunks, int T, float* dW,
+                             float* db, int accumulate) {
+  wgrad_reduce(st, partial, partial_db, nchunks, T, dW, db, accumulate);
+}
 
 // every weight-gradient entry point ends in this
 static void wgrad_reduce(hipStream_t st, const float* partial, const float* partial_db, int nchunks, int T, float* dW, float* db,

@@ -194,6 +194,56 @@ int as_agg_tail_fwd(const float* x, const as_pcl* g, const float* in_scale, cons
                     const float* w, const float* bias, float slope, float* logits, float* pred,
                     int32_t* argmax, float* fcs, void* stream);
 
+/* ---- a1, the 1/2^k-resolution trunk of FeatureExtractorNetwork in train mode (csrc/trunk.hip): six BasicBlocks
+ * a_l = lrelu(BN_l(conv3x3_l(a_{l-1}))) + a_{l-1} (stereo_net.py:33-51, only conv1 is executed) and conv_alone (:85), called
+ * once per image of a pair (adapt.py:72) — here ONE launch per layer and direction for both images: the batch dimension of
+ * every PCL tensor holds `ngroups` statistics groups of B/ngroups images each (left images, then right images), BatchNorm
+ * moments and gradients are taken per group, as the two separate calls of the reference take them.
+ * Replaces, per BasicBlock and image: as_conv32_fwd + as_bn_finalize + as_bn_act_fwd forward and as_bn_act_bwd (three kernels) +
+ * as_conv32_wgrad + as_conv32_fwd(dgrad) backward.
+ *   geometry g       2-D PCL (D = 1, halo >= 1 in h and w), any H, W
+ *   as_trunk_parts   workgroups per group of a launch = BatchNorm partials per group = weight-gradient slabs / ngroups
+ * as_trunk_fwd: z = conv3x3(operand) + bias and, if stat_* are given, per-workgroup (count, mean, M2) moments of z
+ *   [ngroups * parts] (+[32]).  bn_prev == NULL: the operand is `src`.  bn_prev != NULL: the operand is
+ *   a_prev = lrelu(BN_prev(src)) + skip with BN_prev still in the partials its own launch wrote; every workgroup merges its
+ *   group's partials (as_bn_finalize's arithmetic, fp64), the first workgroup of a group writes
+ *   state[group] = {mean, invstd, scale, shift, unbiased variance}[32], and a_prev is written to a_out.
+ * as_trunk_finish_fwd: features PCL -> NCHW, and running_mean/var of `nlayers` BatchNorm layers updated from `states`
+ *   ([nlayers][ngroups][5][32]) group after group (feature_net(left), then feature_net(right)); running_mean / running_var are
+ *   HOST arrays of nlayers device pointers.
+ * as_trunk_bwd: backward of one layer.  z != NULL (a BasicBlock): g_a = dL/da_l; g_z = BatchNorm-backward(lrelu'(.) g_a) with
+ *   the per-group sums merged from `sums` ([ngroups][nparts][64] doubles: what the launch above it left in sums_next);
+ *   bn_grads [ngroups][2][32] receives the group's (g_gamma, g_beta); g_x = g_a + dgrad(g_z).  z == NULL (conv_alone): g_a is
+ *   the gradient of the convolution's output itself, g_x = dgrad(g_a).  Both: dW [32,32,3,3] / db [32] set or accumulated
+ *   (workspace: as_trunk_bwd_workspace floats, kept alive until as_wgrad_defer_flush inside a deferral region), and, if z_next is
+ *   given, the stage-1 sums of the layer below (its pre-activation z_next, its state) into sums_next
+ *   ([ngroups * parts][64] doubles).
+ * as_trunk_finish_bwd: g_gamma[l] / g_beta[l] (HOST arrays of device pointers) set or accumulated from bn_grads
+ *   ([nlayers][ngroups][2][32]), groups in call order. */
+typedef struct as_trunk_bn {
+  const float* stat_mean;   /* [ngroups][nparts][32] */
+  const float* stat_m2;     /* [ngroups][nparts][32] */
+  const float* stat_cnt;    /* [ngroups][nparts] */
+  const float* gamma;
+  const float* beta;
+  float* state;             /* out: [ngroups][5][32] */
+  int32_t nparts;           /* partials per group */
+  float eps;
+} as_trunk_bn;
+int as_trunk_parts(const as_pcl* g, int ngroups);
+int as_trunk_fwd(const float* src, const float* skip, const as_trunk_bn* bn_prev, float* a_out, const as_pcl* g, int ngroups,
+                 const float* packed_w, const float* bias, float slope, float* z, float* stat_mean, float* stat_m2,
+                 float* stat_cnt, void* stream);
+int as_trunk_finish_fwd(const float* feats_pcl, const as_pcl* g, float* feats_nchw, const float* states, int nlayers,
+                        int ngroups, float* const* running_mean, float* const* running_var, float momentum, void* stream);
+int64_t as_trunk_bwd_workspace(const as_pcl* g, int ngroups);
+int as_trunk_bwd(const float* g_a, const float* z, const float* state, const double* sums, int nparts, const float* gamma,
+                 float* bn_grads, const float* x, const float* packed_wt, float* g_x, const float* z_next,
+                 const float* state_next, double* sums_next, const as_pcl* g, int ngroups, float slope, float* dW, float* db,
+                 int accumulate, float* workspace, void* stream);
+int as_trunk_finish_bwd(const float* bn_grads, int nlayers, int ngroups, float* const* g_gamma, float* const* g_beta,
+                        int accumulate, void* stream);
+
 /* Data gradient of nn.Conv2d(32,32,5,stride=2,padding=2) (FeatureExtractorNetwork.downsample[1..k-1],
  * stereo_net.py:61-69): four parity phases of a transposed convolution, each a gather over gz.
  * gz: PCL of the convolution's output extent (halo >= 1); gx: PCL of its input extent; w: PyTorch
