@@ -134,7 +134,7 @@ class OnlineAdapter(object):
 
   def __init__(self, feature_net, stereo_net, height, width, lr=5e-5, clip_grad_norm=True,
                smoothness_weight=1e-3, fcs_ema_weight=0.999, process_group=None, sync_bn=False,
-               overlap_features=True, force_data_parallel=False, pair_features=True):
+               overlap_features=True, force_data_parallel=False, pair_features=True, native_collectives=True):
     self.feature_net, self.stereo_net = feature_net, stereo_net
     self.scale = stereo_net.input_scale
     self.coarse_scale = stereo_net.input_scale + stereo_net.k
@@ -155,7 +155,14 @@ class OnlineAdapter(object):
       raise RuntimeError("OnlineAdapter(force_data_parallel=True) needs an initialised torch.distributed process group")
     # sync_bn: train-mode BatchNorm over the batches of all ranks (= the reference's single-process batch); default is
     # per-replica statistics, as DistributedDataParallel without SyncBatchNorm.  Eager stepping only.
-    self.bn_sync = hip_ops.BnSync(process_group) if (sync_bn and self.world > 1) else None
+    # comm: this library's own RCCL communicator (rccl.py) — its collectives can be captured into a hipGraph, c10d's cannot
+    # on this build; None (gloo groups, a failed creation, native_collectives=False) keeps torch.distributed collectives
+    # outside any capture (two graphs per step)
+    self.comm = None
+    if self.dp and native_collectives:
+      from . import rccl
+      self.comm = rccl.try_create(process_group)
+    self.bn_sync = hip_ops.BnSync(process_group, self.comm) if (sync_bn and (self.world > 1 or force_data_parallel)) else None
     dev = self.arena.params.device
     self.scalars = self.arena.step_scalars       # [valid count, loss sum, FCS sum, FCS count], behind the gradients
     self._graph = None
@@ -360,7 +367,7 @@ class OnlineAdapter(object):
         # (its local khamis term is 0 as well: KhamisLossFn returns 0 for an empty mask)
         n_gt = (replay[2] > 0).sum().to(torch.float32)
         six[4] = n_gt; six[5] = replay_loss.detach() * n_gt
-      dist.all_reduce(six, op=dist.ReduceOp.SUM, group=self.pg)
+      self._all_reduce_small(six)
       loss = six[1] / six[0]
       fcs = six[2] / six[3]
       if replay_loss is not None:
@@ -403,7 +410,7 @@ class OnlineAdapter(object):
       hip_ops.set_bn_sync(prev_sync)
       self.plan.end()
     if self.dp:
-      allreduce_gradients_and_scalars(self.arena, self.pg)     # the same single message step() sends
+      self._all_reduce_gradients()                             # the same single message step() sends
       self.arena.grads.div_(n_total)
     self.optimizer.step(clip=self.clip)
 
@@ -426,12 +433,25 @@ class OnlineAdapter(object):
       two = torch.empty(2, dtype=torch.float32, device=total.device)
       tc = total.contiguous()
       nat.call("as_masked_sum", nat.ptr(tc), nat.ptr(m8), n, nat.ptr(two), nat.ptr(ws), nat.stream())
-      dist.all_reduce(two, op=dist.ReduceOp.SUM, group=self.pg)
+      self._all_reduce_small(two)
       loss = two[0] / two[1]
     else:
       loss = masked_mean(total, mask)
     self.feature_net.train(was_f); self.stereo_net.train(was_s)
     return float(loss)
+
+  def _all_reduce_small(self, t):
+    if self.comm is not None:
+      self.comm.all_reduce(t)
+    else:
+      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+  def _all_reduce_gradients(self):
+    """THE collective of a data-parallel step: [gradient arena | 4 step scalars] summed over the ranks, one message."""
+    if self.comm is not None:
+      self.comm.all_reduce(self.arena.grads_and_scalars)       # on the current stream: a graph node under capture
+    else:
+      allreduce_gradients_and_scalars(self.arena, self.pg)
 
   # -- hipGraph capture of the whole step ------------------------------------------------------------
   def capture(self, left, right, warmup=3):
@@ -440,12 +460,14 @@ class OnlineAdapter(object):
     queries events while a capture is open; only this thread's calls have to be capture-safe.)  Every entry point of the C ABI only enqueues work on the current
     stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the device.  Inputs
     are copied into static buffers before each replay.
-    One GPU: a single graph.  Data parallel: two graphs (forward + backward of the local loss sum | 1/N_total scaling
-    + clip + Adam + EMA) with the step's single RCCL all-reduce issued between them on the same stream, outside any
-    capture."""
-    if self.bn_sync is not None:
+    One GPU: a single graph.  Data parallel with this library's own RCCL communicator (self.comm): a single graph as
+    well — the all-reduce (and, with sync_bn, the BatchNorm collectives) are graph nodes.  Data parallel over
+    torch.distributed collectives (gloo, or no native communicator): two graphs (forward + backward of the local loss
+    sum | 1/N_total scaling + clip + Adam + EMA) with the step's single all-reduce issued between them, outside any
+    capture; cross-replica BatchNorm cannot be captured then."""
+    if self.bn_sync is not None and self.comm is None:
       raise RuntimeError("OnlineAdapter.capture: cross-replica BatchNorm puts collectives inside forward and backward; "
-                         "a step cannot be captured with sync_bn=True (step() runs eagerly)")
+                         "over torch.distributed collectives a step cannot be captured with sync_bn=True (step() runs eagerly)")
     self._refuse_nested_capture("capture")
     self._static_left, self._static_right = left.clone(), right.clone()
     side = torch.cuda.Stream()
@@ -474,7 +496,9 @@ class OnlineAdapter(object):
 
   def _capture_graphs(self, side):
     left, right = self._static_left, self._static_right
-    if not self.dp:
+    if not self.dp or self.comm is not None:
+      if self.dp:
+        dist.barrier(group=self.pg)
       graph = torch.cuda.CUDAGraph()
       with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):   # the warm-up's stream: its
         self._static_result = self._step_eager(self._static_left, self._static_right)   # pooled buffers are reused
@@ -508,6 +532,12 @@ class OnlineAdapter(object):
         self._static_result = {"loss": loss.detach(), "fcs": fcs, "fcs_smoothed": self.fcs_smoothed, "outputs": out}
       self._graph = (g1, g2)
 
+  def graph_count(self):
+    """hipGraphs a captured step replays (0: eager stepping)."""
+    if self._graph is None:
+      return 0
+    return len(self._graph) if isinstance(self._graph, tuple) else 1
+
   def graph_inputs(self):
     """The captured step's own input buffers (after capture()): a producer that decodes or copies the next pair
     straight into them — and then passes them to step() — saves the two device copies a replay otherwise starts with."""
@@ -522,7 +552,7 @@ class OnlineAdapter(object):
       self._static_left.copy_(left)
     if right.data_ptr() != self._static_right.data_ptr():
       self._static_right.copy_(right)
-    if not self.dp:
+    if not isinstance(self._graph, tuple):
       self._graph.replay()
     else:
       g1, g2 = self._graph
@@ -561,7 +591,7 @@ class OnlineAdapter(object):
   def _distributed_backward(self, total, mask, fcs_map, pairs):
     m8 = self._dp_local_sums(total, mask, fcs_map)
     self._dp_backward(total, m8)
-    allreduce_gradients_and_scalars(self.arena, self.pg)
+    self._all_reduce_gradients()
     return self._dp_results()
 
 

@@ -451,11 +451,13 @@ class BnSync(object):
   """Cross-replica BatchNorm for data-parallel adaptation: train-mode statistics and the backward's
   per-channel sums span the batches of ALL ranks of ``group``, as the reference's single-process BatchNorm over the
   whole batch does (stereo_net.py:17,29).  Every rank merges the same partials in the same (rank-major) order, so
-  the replicas stay bit-identical.  Collectives cannot be captured: stepping is eager while this is on."""
+  the replicas stay bit-identical.  ``comm`` = this library's own RCCL communicator (rccl.RcclComm): its collectives are
+  enqueued on the current stream and can be captured into a hipGraph; without it the collectives go through
+  torch.distributed and stepping is eager while this is on."""
 
-  def __init__(self, group=None):
+  def __init__(self, group=None, comm=None):
     import torch.distributed as dist
-    self.dist, self.group = dist, group
+    self.dist, self.group, self.comm = dist, group, comm
     self.world = dist.get_world_size(group)
 
 
@@ -473,7 +475,10 @@ def _gathered_stats(stats: StatParts, sync: BnSync):
   """The (count, mean, M2) partials of all ranks, rank-major, in one StatParts."""
   n, w = stats.nparts, sync.world
   every = torch.empty(w, n * 65, dtype=torch.float32, device=stats.buf.device)
-  sync.dist.all_gather(list(every.unbind(0)), stats.buf, group=sync.group)
+  if sync.comm is not None:
+    sync.comm.all_gather(every, stats.buf)
+  else:
+    sync.dist.all_gather(list(every.unbind(0)), stats.buf, group=sync.group)
   out = StatParts(n * w, stats.buf.device)
   out.mean.view(w, n * 32).copy_(every[:, :n * 32])
   out.m2.view(w, n * 32).copy_(every[:, n * 32:n * 64])
@@ -544,7 +549,10 @@ def _bn_bwd_coefs(g_a, z, st, gamma, g, train, g_gamma, g_beta, accumulate, ws, 
   call("as_bn_bwd_sums", ptr(g_a), ptr(z), ptr(st.scale), ptr(st.shift), ptr(st.mean), LEAKY_SLOPE, ptr(ws), g,
        sums.nparts if sums is not None else 0, ptr(local), stream())
   everyone = local.clone()
-  sync.dist.all_reduce(everyone, op=sync.dist.ReduceOp.SUM, group=sync.group)
+  if sync.comm is not None:
+    sync.comm.all_reduce(everyone)
+  else:
+    sync.dist.all_reduce(everyone, op=sync.dist.ReduceOp.SUM, group=sync.group)
   call("as_bn_bwd_finalize_synced", ptr(local), ptr(everyone), ptr(st.invstd), ptr(gamma), ptr(g_gamma), ptr(g_beta),
        int(accumulate), ptr(ws), stream())
 
@@ -880,6 +888,7 @@ class CostAggregationFn(torch.autograd.Function):
       for buf in xs:
         POOL.put(buf, g)
     ctx.mark_non_differentiable(argmax, fcs)
+    ctx.set_materialize_grads(False)       # an output nobody differentiates arrives as None, not as a zero-filled tensor
     return logits, pred, argmax, fcs
 
   @staticmethod
@@ -892,7 +901,7 @@ class CostAggregationFn(torch.autograd.Function):
     xs, zs, sts = ctx.xs, ctx.zs, ctx.sts
 
     g_logits = torch.empty_like(logits)
-    g_pred, g_logits_in = f32c(g_pred), f32c(g_logits_in)      # keep any contiguous copies alive past the launch
+    g_pred, g_logits_in = f32c(g_pred), f32c(g_logits_in)      # keep any contiguous copies alive past the launch (None = zero)
     call("as_softargmax_bwd", ptr(logits), ptr(g_pred), ptr(g_logits_in), B, D, H, W, ptr(g_logits), stream())
 
     grads = [None] * 18
@@ -1463,6 +1472,7 @@ class LinearWarpFn(torch.autograd.Function):
     ctx.r2l = int(bool(right_to_left))
     mask = mask.bool()
     ctx.mark_non_differentiable(mask)
+    ctx.set_materialize_grads(False)
     return warped, mask
 
   @staticmethod
@@ -1471,6 +1481,8 @@ class LinearWarpFn(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       raise NotImplementedError("LinearWarpFn: gradient w.r.t. the image is not part of the adaptation path")
     B, C, H, W = img.shape
+    if g_warped is None:
+      return None, None, None
     g_disp = torch.empty_like(disp)
     g_warped = f32c(g_warped)
     call("as_warp_bwd", ptr(g_warped), ptr(img), ptr(disp), B, C, H, W, ctx.r2l, ptr(g_disp), stream())
@@ -1494,7 +1506,8 @@ class MonodepthLossFn(torch.autograd.Function):
          ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(ws), stream())
     ctx.save_for_backward(pred, img, warped)
     ctx.sw = float(smoothness_weight)
-    return tuple(outs)
+    ctx.set_materialize_grads(False)       # adapt.py:81 uses the first map only: the other three gradients stay None (the
+    return tuple(outs)                     # kernels take NULL for them) instead of three zero-filled planes per step
 
   @staticmethod
   def backward(ctx, g_total, g_l1, g_ssim, g_smooth):
@@ -1506,6 +1519,8 @@ class MonodepthLossFn(torch.autograd.Function):
     g_pred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
     g_warped = torch.empty_like(warped) if ctx.needs_input_grad[2] else None
     ws = _empty(nat.load().as_monodepth_workspace(B, H, W), dev)
+    if g_total is None and g_l1 is None and g_ssim is None and g_smooth is None:
+      return None, None, None, None
     g_total, g_l1, g_ssim, g_smooth = f32c(g_total), f32c(g_l1), f32c(g_ssim), f32c(g_smooth)
     call("as_monodepth_loss_bwd", ptr(g_total), ptr(g_l1), ptr(g_ssim), ptr(g_smooth),
          ptr(pred), ptr(img), ptr(warped), B, H, W, ctx.sw, ptr(g_pred), ptr(g_warped), ptr(ws), stream())

@@ -42,10 +42,12 @@ def parse():
   ap.add_argument("--k", type=int, default=4)
   ap.add_argument("--maxdisp", type=int, default=192)
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--online", action="store_true", help="also measure the step at one pair per step (the reference's "
-                  "online setting) -> \"online_batch1\"; off by default so that a kernel trace of the default command "
-                  "holds launches of ONE size")
-  ap.add_argument("--no-online", action="store_true", help=argparse.SUPPRESS)     # accepted for older scripts
+  ap.add_argument("--online", action="store_true", help=argparse.SUPPRESS)        # (the default now; accepted for older scripts)
+  ap.add_argument("--no-online", action="store_true", help="skip \"online_batch1\" (the same step and forward at ONE pair per "
+                  "step, the reference's own online setting: adapt_*.sh --batch_size 1), measured by default AFTER the "
+                  "profiled region; tracing scripts pass this so that a kernel trace holds launches of one size")
+  ap.add_argument("--no-dp-overhead", action="store_true", help="skip \"dp_path_overhead_ms\" (N=1 only: the data-parallel "
+                  "step in a one-rank RCCL group minus the plain step, the one scaling-loss term one GPU can measure)")
   ap.add_argument("--one-stream", action="store_true", help="the two feature extractions of a pair back to back on one "
                   "stream instead of side by side on two (for per-kernel profiles: rocprofv3 serialises queues)")
   ap.add_argument("--sync-bn", action="store_true", help="N>1: train-mode BatchNorm over the batches of all ranks (the "
@@ -62,6 +64,23 @@ def log(msg):
 
 
 T0 = time.perf_counter()
+
+
+def model_flops(H, W, k, maxdisp):
+  """Algorithmic forward FLOPs per stereo pair (SURVEY 8 size table: 2 x output voxels x Cin x Cout x taps per
+  convolution; both feature towers, the four 3-D layers + conv3d_alone, the refinement): 63.4 G at KITTI k=4."""
+  def down(n):
+    return (n - 1) // 2 + 1
+  feat, h, w, cin = 0.0, H, W, 3
+  for _ in range(k):
+    h, w = down(h), down(w)
+    feat += 2.0 * h * w * 25 * cin * 32
+    cin = 32
+  feat += 7 * 2.0 * h * w * 9 * 32 * 32
+  D = (maxdisp + 1) // 2 ** k
+  agg = 4 * 2.0 * D * h * w * 27 * 32 * 32 + 2.0 * D * h * w * 27 * 32
+  refine = 2.0 * H * W * 9 * 4 * 32 + 6 * 2.0 * H * W * 9 * 32 * 32 + 2.0 * H * W * 9 * 32
+  return {"feature_towers": 2 * feat, "aggregation": agg, "refinement": refine, "forward": 2 * feat + agg + refine}
 
 
 def timed(fn, steps, world):
@@ -83,13 +102,30 @@ def timed(fn, steps, world):
   return dt
 
 
-def host_threads():
-  """Threads to use for the CPU baseline: the box's CPU share (16 per GPU), not the host's core count."""
+def cpu_share():
+  """(threads for the CPU baseline, how that number was arrived at).  BASELINE.md 4 says "all host cores"; what a one-GPU
+  box may use is bounded by, in this order: the scheduler affinity of this process, the cgroup CPU quota (cpu.max), and the
+  pool's stated CPU share of 16 threads per GPU (the host is shared by the boxes of its 8 GPUs; its 256 hardware threads
+  are visible to every one of them).  AS_CPU_THREADS overrides the last of the three."""
   try:
-    n = len(os.sched_getaffinity(0))
+    aff = len(os.sched_getaffinity(0))
   except AttributeError:
-    n = os.cpu_count() or 1
-  return max(1, min(n, int(os.environ.get("AS_CPU_THREADS", "16"))))
+    aff = os.cpu_count() or 1
+  quota = None
+  try:
+    q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+    if q != "max":
+      quota = max(1, int(float(q) / float(per) + 0.5))
+  except (OSError, ValueError):
+    pass
+  share = int(os.environ.get("AS_CPU_THREADS", "16"))
+  n = max(1, min(aff, quota if quota is not None else aff, share))
+  why = "min(affinity %d, cgroup cpu.max %s, pool share per GPU %d)" % (aff, quota if quota is not None else "unlimited", share)
+  return n, why
+
+
+def host_threads():
+  return cpu_share()[0]
 
 
 def cpu_model_string():
@@ -161,11 +197,55 @@ def cpu_baseline(args, fsd, ssd, budget_s=10.0):
   return {"value": round(1.0 / t_adapt, 4), "unit": "stereo pairs/s (fwd+adapt-step)", "cores": many,
           "kind": "port", "fwd_value": round(1.0 / t_fwd, 4),
           "one_thread": {"value": round(1.0 / t1_adapt, 4), "fwd_value": round(1.0 / t1_fwd, 4), "cores": 1},
+          "cores_source": cpu_share()[1],
           "cpu_model": cpu_model_string(), "host_cores_visible": os.cpu_count(), "torch": torch.__version__,
           "parity": parity,
           "sample": "oracle/stereo_oracle.py (PyTorch CPU fp32), batch 1 at %dx%d, medians: %d threads: %d warm-ups + %d "
                     "adapt steps, %d warm-ups + %d forwards; 1 thread: %d warm-up + %d adapt step(s), %d warm-up + %d "
                     "forward(s)" % (args.width, args.height, many, wu, n_adapt, wu, n_fwd, wu1, n1_adapt, wu1, n1_fwd)}
+
+
+def dp_path_overhead(args, fsd, ssd, left, right, dev, use_graph, plain_ms):
+  """N = 1 only: the data-parallel step (local loss sums, flush, ONE RCCL all-reduce of [gradients | 4 scalars] on its own
+  stream, 1/N_total, clip + Adam; two hipGraphs with the collective between them) in a ONE-rank "nccl" process group, minus
+  the plain single-GPU step of the same batch measured in this run.  It is the scaling-loss term one GPU can measure:
+  everything the data-parallel path adds except the wire time of the collective itself."""
+  import socket
+  from adaptive_stereo.adaptation import OnlineAdapter
+  from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+  try:
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+      def leg(native):
+        f1, s1 = FeatureExtractorNetwork(args.k), StereoNet(args.k, 1, 0, maxdisp=args.maxdisp)
+        f1.load_state_dict(fsd); s1.load_state_dict(ssd)
+        a1 = OnlineAdapter(f1.to(dev), s1.to(dev), args.height, args.width, lr=5e-5, clip_grad_norm=True,
+                           overlap_features=not args.one_stream, force_data_parallel=True, native_collectives=native)
+        for _ in range(max(2, args.warmup // 2)):
+          a1.step(left, right)
+        l1, r1 = left, right
+        if use_graph:
+          a1.capture(left, right, warmup=1)
+          l1, r1 = a1.graph_inputs(); l1.copy_(left); r1.copy_(right)
+          a1.step(l1, r1)
+        torch.cuda.synchronize()
+        t = timed(lambda: a1.step(l1, r1), args.steps, 1)
+        return 1e3 * t / args.steps, a1.graph_count(), a1.comm is not None, a1.arena.grads_and_scalars.numel()
+      dp_ms, graphs, native, floats = leg(True)
+      c10d_ms, c10d_graphs, _, _ = leg(False)
+      log("data-parallel path in a one-rank RCCL group: %.3f ms/step in %d graph(s) (torch.distributed collectives: %.3f in %d; "
+          "plain %.3f)" % (dp_ms, graphs, c10d_ms, c10d_graphs, plain_ms))
+      return {"value": round(dp_ms - plain_ms, 3), "dp_one_rank_ms_per_step": round(dp_ms, 3), "plain_ms_per_step": round(plain_ms, 3),
+              "graphs": graphs, "native_rccl_communicator": native,
+              "torch_distributed_collectives": {"value": round(c10d_ms - plain_ms, 3), "ms_per_step": round(c10d_ms, 3), "graphs": c10d_graphs},
+              "note": "one-rank RCCL group on this GPU: all-reduce of %d floats per step; everything the data-parallel path adds "
+                      "except the wire time of the collective" % floats}
+    finally:
+      dist.destroy_process_group()
+  except Exception as e:                      # a measurement leg must never take the headline line down with it
+    log("dp_path_overhead failed: %r" % (e,))
+    return {"value": None, "error": repr(e)[:300]}
 
 
 def main():
@@ -202,7 +282,8 @@ def main():
                           overlap_features=not args.one_stream)
 
   lib = nat.load()
-  use_graph = not args.no_graph and adapter.bn_sync is None     # collectives inside forward/backward: not capturable
+  # cross-replica BatchNorm puts collectives inside forward/backward: capturable only with the library's own communicator
+  use_graph = not args.no_graph and (adapter.bn_sync is None or adapter.comm is not None)
   log("setup done: %d pairs/GPU at %dx%d, world %d, %s" % (B, args.width, args.height, world,
                                                            "hipGraph replay" if use_graph else "eager launches"))
   # ---- forward + adaptation step ---------------------------------------------------------
@@ -289,16 +370,22 @@ def main():
     # HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_by_pairs.json, keyed by pairs per launch;
     # FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes).  `traffic` is the dominant kernel's; the
     # forward / data-gradient flavours of conv32_lds_kernel and the 3-D kernels are in traffic_detail.
-    traffic, traffic_detail = None, None
+    traffic, traffic_detail, traffic_source = None, None, None
     rec = None
-    by_pairs = os.path.join(REPO, "profiles", "r02_pmc_by_pairs.json")     # PMC passes at 1, 2 and 4 pairs per launch
-    if os.path.exists(by_pairs):
-      rec = json.load(open(by_pairs)).get(str(B))
-    if rec is None:
-      pmc = os.path.join(REPO, "profiles", "pmc_conv32_lds.json")
-      if os.path.exists(pmc):
-        rec = json.load(open(pmc))
-        rec = rec if rec.get("pairs_per_launch") == B else None
+    # the newest committed PMC file wins (rocprofv3 --pmc passes cannot run inside this timed process: the counters come
+    # from tests/tools/pmc_run.sh runs of the same kernels at 1, 2 and 4 pairs per launch, committed under profiles/)
+    for name in ("r03_pmc_by_pairs.json", "r02_pmc_by_pairs.json"):
+      by_pairs = os.path.join(REPO, "profiles", name)
+      if os.path.exists(by_pairs):
+        table = json.load(open(by_pairs))
+        keys = sorted(int(k_) for k_ in table if k_.isdigit())
+        if keys:
+          near = min(keys, key=lambda k_: (abs(k_ - B), -k_))
+          rec = table[str(near)]
+          traffic_source = {"file": "profiles/" + name, "pairs_per_launch_measured": near, "exact": near == B,
+                            "how": "separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE), "
+                                   "tests/tools/pmc_run.sh; per launch; scaled by pairs when not exact"}
+          break
     if rec is not None:
       ks = rec.get("kernels", {})
       def pmc_row(k):
@@ -306,10 +393,11 @@ def main():
         return None if v is None else {"hbm_bytes": v["hbm_bytes_per_launch"], "algorithmic_bytes": v["algorithmic_bytes_per_launch"],
                                        "traffic_over_algorithmic": v["traffic_over_algorithmic"],
                                        "mfma_busy": v["mfma_busy_fraction_of_simd_cycles"]}
+      scale = 1.0 if traffic_source is None or traffic_source["exact"] else B / float(traffic_source["pairs_per_launch_measured"])
       if fused_is_dom and "conv32_bwd_fused_kernel" in ks:
-        traffic = int(ks["conv32_bwd_fused_kernel"]["hbm_bytes_per_launch"])
+        traffic = int(ks["conv32_bwd_fused_kernel"]["hbm_bytes_per_launch"] * scale)
       elif not fused_is_dom and "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
-        traffic = int((ks["conv32_lds_kernel<0, false>"]["hbm_bytes_per_launch"] + ks["conv32_lds_kernel<3, true>"]["hbm_bytes_per_launch"]) / 2)
+        traffic = int((ks["conv32_lds_kernel<0, false>"]["hbm_bytes_per_launch"] + ks["conv32_lds_kernel<3, true>"]["hbm_bytes_per_launch"]) / 2 * scale)
       traffic_detail = {"pairs_per_launch": rec.get("pairs_per_launch"),
                         "backward_fused": pmc_row("conv32_bwd_fused_kernel"),
                         "forward_with_activation_on_the_way_in": pmc_row("conv32_act_kernel<true>"),
@@ -318,6 +406,7 @@ def main():
                         "cost_aggregation_3d": {k: pmc_row(k) for k in ks if k.startswith(("agg3d", "agg_tail", "conv3d"))}}
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_source": traffic_source,
                 "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
                 "flops_per_launch": dom["flops_per_launch"], "traffic_detail": traffic_detail,
                 "flavours": [e for e in (entry(22, "conv32_bwd_fused_kernel (full-resolution layer backward in one launch: BatchNorm-backward apply, data gradient + skip, weight gradient, next BatchNorm's sums)"),
@@ -353,6 +442,17 @@ def main():
             (18, "a10 monodepth loss fwd (image mean + SSIM/L1/smoothness)"), (19, "a10 monodepth loss bwd (two passes)")]
     roofline["hbm_rows"] = [dict(e, row=nm.split(" ")[0]) for e, nm in ((hbm_entry(i, nm_), nm_) for i, nm_ in star) if e is not None]
 
+  mf = model_flops(args.height, args.width, args.k, args.maxdisp)
+  if roofline is not None:
+    # the whole step / the whole forward against the fp32 matrix peak: algorithmic FLOPs of the model (forward as in SURVEY
+    # 8's table; a training step = forward + data gradient + weight gradient = 3 x forward) / measured time / peak
+    step_tf = 3.0 * mf["forward"] * B * world / (t_adapt / args.steps) / 1e12
+    fwd_tf = mf["forward"] * B * world / (t_fwd / args.steps) / 1e12
+    roofline["whole_step"] = {"flops_per_pair": 3.0 * mf["forward"], "achieved": round(step_tf / world, 2), "unit": "TFLOP/s per GPU",
+                              "frac": round(step_tf / world / FP32_MFMA_PEAK_TFLOPS, 4)}
+    roofline["whole_forward"] = {"flops_per_pair": mf["forward"], "achieved": round(fwd_tf / world, 2), "unit": "TFLOP/s per GPU",
+                                 "frac": round(fwd_tf / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                                 "breakdown_gflop_per_pair": {k_: round(v / 1e9, 3) for k_, v in mf.items()}}
   out = {
     "metric": "stereo pairs/sec (fwd+adapt-step), KITTI 1242x375 D=192",
     "value": round(pairs / t_adapt, 3),
@@ -374,13 +474,16 @@ def main():
                "parallelism": "dp%d (%s BatchNorm statistics, one flat RCCL gradient all-reduce)" % (
                    world, "cross-replica" if adapter.bn_sync is not None else "per-replica"),
                "kernels": "all hand-written HIP (no MIOpen/rocBLAS on the path)"},
-    "launch_mode": "hipGraph replay of the captured step" if use_graph else "eager",
+    "launch_mode": ("hipGraph replay of the captured step (%d graph%s)" % (adapter.graph_count(), "" if adapter.graph_count() == 1 else "s"))
+                   if use_graph else "eager",
+    "collectives": None if world == 1 else ("RCCL through the library's own communicator, captured in the step's graph"
+                                            if adapter.comm is not None else "torch.distributed, between two graphs"),
     "eager_ms_per_step": round(1e3 * t_adapt_eager / args.steps, 3),
     "fwd_pairs_per_s": round(pairs / t_fwd, 3),
     "fwd_ms_per_step": round(1e3 * t_fwd / args.steps, 3),
     "roofline": roofline,
   }
-  if world == 1 and B != 1 and args.online and not args.no_online:
+  if world == 1 and B != 1 and not args.no_online:
     # The reference adapts online, one pair per step (experiments/adaptation/adapt_*.sh: --batch_size 1): the same
     # step at batch 1 next to the headline configuration (fresh networks, its own captured graphs).
     f1, s1 = FeatureExtractorNetwork(args.k), StereoNet(args.k, 1, 0, maxdisp=args.maxdisp)
@@ -409,6 +512,8 @@ def main():
                             "note": "one pair per step (the reference's online setting), same kernels and graphs"}
     log("online (batch 1): %.2f ms/step, forward %.2f ms" % (1e3 * t1 / args.steps, 1e3 * t1f / args.steps))
     del a1, f1, s1
+  if world == 1 and not args.no_dp_overhead:
+    out["dp_path_overhead_ms"] = dp_path_overhead(args, fsd, ssd, left, right, dev, use_graph, 1e3 * t_adapt / args.steps)
   if world == 1 and not args.no_cpu_baseline:
     out["cpu_baseline"] = cpu_baseline(args, fsd, ssd)
     log("cpu baseline done")

@@ -366,12 +366,35 @@ def _rccl_worker(rank, world, port, out_path):
   torch.cuda.synchronize()
   identity = bool(torch.equal(before, probe.arena.grads_and_scalars))
 
+  # this library's own communicator (adaptive_stereo/rccl.py): same identity, and through the gather
+  native_identity = None
+  if probe.comm is not None:
+    probe.comm.all_reduce(probe.arena.grads_and_scalars)
+    gathered = torch.empty_like(before)
+    probe.comm.all_gather(gathered, before)
+    torch.cuda.synchronize()
+    native_identity = bool(torch.equal(before, probe.arena.grads_and_scalars)) and bool(torch.equal(before, gathered))
+
   results = {}
-  for mode in ("single", "dp_eager", "dp_graph"):
-    adapter = fresh(force_data_parallel=(mode != "single"))
+  # dp_graph: the native communicator's all-reduce is a node of ONE graph; dp_graph_c10d: torch.distributed's all-reduce
+  # between TWO graphs; syncbn_*: cross-replica BatchNorm (its 34 collectives per step) eager and captured
+  for mode in ("single", "dp_eager", "dp_graph", "dp_graph_c10d", "syncbn_eager", "syncbn_graph"):
+    kw = {}
+    if mode != "single":
+      kw["force_data_parallel"] = True
+    if mode == "dp_graph_c10d":
+      kw["native_collectives"] = False
+    if mode.startswith("syncbn"):
+      kw["sync_bn"] = True
+    adapter = fresh(**kw)
     assert adapter.dp == (mode != "single") and adapter.world == 1
-    first_loss = float(adapter.step(*batches[0])["loss"])                         # identical weights in all three modes
-    if mode == "dp_graph":
+    assert (adapter.comm is not None) == (mode not in ("single", "dp_graph_c10d")), mode
+    assert (adapter.bn_sync is not None) == mode.startswith("syncbn")
+    first_loss = float(adapter.step(*batches[0])["loss"])                         # identical weights in all modes
+    if mode in ("dp_graph", "syncbn_graph"):
+      adapter.capture(*batches[0], warmup=1)
+      assert adapter.graph_count() == 1                                          # collectives are graph nodes
+    elif mode == "dp_graph_c10d":
       adapter.capture(*batches[0], warmup=1)
       assert isinstance(adapter._graph, tuple) and len(adapter._graph) == 2      # two graphs, the all-reduce between
     else:
@@ -382,14 +405,15 @@ def _rccl_worker(rank, world, port, out_path):
                      float(adapter.optimizer.step_dev))
     results[mode + "_first_loss"] = first_loss
     entries = [(mi, name, off, n) for (mi, name, _p, off, n) in adapter.arena.entries]
-  torch.save({"identity": identity, "results": results, "entries": entries}, out_path)
+  torch.save({"identity": identity, "native_identity": native_identity, "results": results, "entries": entries}, out_path)
   dist.barrier()
   dist.destroy_process_group()
 
 
 def test_rccl_single_rank_allreduce_and_two_graph_replay(tmp_path):
-  """RCCL on the one GPU this box has: a one-rank "nccl" process group drives the data-parallel step — eagerly and as two
-  replayed hipGraphs with the all-reduce between them.  Graph replay must equal eager data-parallel stepping bit for
+  """RCCL on the one GPU this box has: a one-rank "nccl" process group drives the data-parallel step — eagerly, as ONE
+  replayed hipGraph with the library's own communicator (the all-reduce a graph node) and as two replayed hipGraphs with
+  torch.distributed's all-reduce between them; cross-replica BatchNorm eager and captured.  Graph replay must equal eager data-parallel stepping bit for
   bit; both must agree with the ordinary single-GPU step to rounding (the data-parallel step divides the summed
   gradient by the valid-pixel count after the all-reduce, the single-GPU step scales the incoming gradient before
   backward: the same real number, rounded at a different place)."""
@@ -397,10 +421,19 @@ def test_rccl_single_rank_allreduce_and_two_graph_replay(tmp_path):
   mp.spawn(_rccl_worker, args=(1, _free_port(), out_path), nprocs=1, join=True)
   got = torch.load(out_path)
   assert got["identity"], "a one-rank RCCL all-reduce must leave the buffer unchanged"
+  assert got["native_identity"] is True, "the library's own RCCL communicator: all-reduce / all-gather over one rank"
   (ls, ps, cs, ds), (le, pe, ce, de), (lg, pg_, cg, dg) = (got["results"][m] for m in ("single", "dp_eager", "dp_graph"))
   assert (ce, de) == (cg, dg) == (5, 5.0) and (cs, ds) == (5, 5.0)
   assert le == lg, (le, lg)
   assert torch.equal(pe, pg_), float((pe - pg_).abs().max())
+  # the c10d route (two graphs) gives the same bits as the one-graph route
+  lc, pc, cc, dc = got["results"]["dp_graph_c10d"]
+  assert lc == lg and torch.equal(pc, pg_) and (cc, dc) == (5, 5.0)
+  # cross-replica BatchNorm over one rank: captured (its collectives are graph nodes) == eager, bit for bit; and the
+  # statistics of "all ranks" are this rank's: the losses agree with the per-replica data-parallel step to rounding
+  (lse, pse, _, _), (lsg, psg, csg, dsg) = got["results"]["syncbn_eager"], got["results"]["syncbn_graph"]
+  assert lse == lsg and torch.equal(pse, psg) and (csg, dsg) == (5, 5.0)
+  assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(lse, le)), (lse, le)
   # the very first step runs on identical weights: the data-parallel loss (local sum, all-reduce, divide) and the single-GPU
   # masked mean are the same number up to the order of one division
   f_s, f_e, f_g = (got["results"][m + "_first_loss"] for m in ("single", "dp_eager", "dp_graph"))
