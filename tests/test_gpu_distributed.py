@@ -453,3 +453,58 @@ def test_rccl_single_rank_allreduce_and_two_graph_replay(tmp_path):
               first_loss_rel_dev=abs(ls[0] - le[0]) / max(1.0, abs(ls[0])))
   assert float((ps - pe).abs().mean()) <= 0.1 * 5e-5           # ... and those are rare
   assert flipped <= 0.1
+
+
+def _rccl_kitti_worker(rank, world, port, out_path):
+  """The data-parallel step at the BENCH workload (4 pairs x 375x1242, k=4) in a one-rank RCCL group: eager and as one
+  replayed hipGraph with the all-reduce inside."""
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+  torch.cuda.set_device(0)
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+  from adaptive_stereo.adaptation import OnlineAdapter
+  from adaptive_stereo.models.stereo_net import StereoNet, FeatureExtractorNetwork
+  from adaptive_stereo.utils import synthetic as syn
+  B, Hk, Wk, k = 4, 375, 1242, 4
+  left, right = (t.cuda() for t in syn.stereo_pair(B, Hk, Wk, seed=1))
+  out = {}
+  for mode in ("eager", "graph"):
+    fnet, snet = FeatureExtractorNetwork(k), StereoNet(k, 1, 0, maxdisp=192)
+    fnet.load_state_dict(syn.synthetic_state_dict(fnet.state_dict(), seed=123))
+    snet.load_state_dict(syn.synthetic_state_dict(snet.state_dict(), seed=123, logit_gain=1.0))
+    adapter = OnlineAdapter(fnet.cuda(), snet.cuda(), Hk, Wk, lr=5e-5, force_data_parallel=True)
+    assert adapter.dp and adapter.comm is not None
+    res = adapter.step(left, right)
+    first = (float(res["loss"]), float(res["fcs"]), float(adapter.optimizer.grad_norm()))
+    if mode == "graph":
+      adapter.capture(left, right, warmup=1)
+      assert adapter.graph_count() == 1
+    else:
+      adapter.step(left, right)
+    losses = [float(adapter.step(left, right)["loss"]) for _ in range(2)]
+    torch.cuda.synchronize()
+    out[mode] = (first, losses, adapter.arena.params.detach().cpu().clone())
+  torch.save(out, out_path)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_rccl_data_parallel_step_at_the_bench_workload(tmp_path, golden_loader):
+  """force_data_parallel at KITTI size, 4 pairs per rank (BASELINE configs[3]'s per-GPU share): the first step's loss, FCS and
+  clip norm against the REFERENCE's own fixture for this workload (kitti_375x1242_k4_b4), and graph replay (the RCCL
+  all-reduce a node of the one graph) against eager data-parallel stepping, bit for bit."""
+  out_path = str(tmp_path / "rccl_kitti.pt")
+  mp.spawn(_rccl_kitti_worker, args=(1, _free_port(), out_path), nprocs=1, join=True)
+  got = torch.load(out_path)
+  gold = golden_loader("kitti_375x1242_k4_b4")
+  (loss, fcs, norm), le, pe = got["eager"]
+  (_, _, _), lg, pg_ = got["graph"]
+  assert abs(loss - gold.scalar("train/loss")) < 2e-5, (loss, gold.scalar("train/loss"))
+  assert abs(fcs - gold.scalar("train/fcs_mean")) < 1e-4 * max(1.0, abs(gold.scalar("train/fcs_mean")))
+  ref_norm = gold.scalar("train/stereo_grad_norm")
+  assert abs(norm - ref_norm) <= 1e-3 * ref_norm, (norm, ref_norm)
+  assert le == lg and torch.equal(pe, pg_)
+  from conftest import parity_note
+  parity_note("rccl_dp_kitti_b4", loss=loss, ref_loss=gold.scalar("train/loss"), clip_norm_rel_err=abs(norm - ref_norm) / ref_norm)
