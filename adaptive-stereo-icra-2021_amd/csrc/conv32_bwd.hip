@@ -16,9 +16,14 @@
 //   * the weight gradient is paired the other way round,  dW[kh,kw] = sum_u x[y][u]^T g_z[y-(kh-1)d][u-(kw-1)d]  (the same
 //     sum as sum_v x[v+off]^T g_z[v], re-indexed): the CENTRE x row meets the three g_z rows that are staged anyway, so x
 //     needs one row in LDS, not three;
-//   * g_z is kept in two layouts: swizzled (slot s of voxel v holds chunk s ^ ((v>>1)&7): conflict-free ds_read_b128 of the
-//     data gradient's A operand for any tap offset) and plain (the weight gradient's B operand is a ds_read_b32 of one voxel's
-//     32 channels by 32 lanes, addresses = base + immediates); the element-wise pass writes both;
+//   * g_z is kept ONCE, with a voxel pitch of 144 bytes instead of 128 (round 3; until then two copies, a swizzled and a plain
+//     one): consecutive voxels start 4 banks apart, so the data gradient's ds_read_b128 (lane = voxel) is conflict-free for any
+//     tap offset, the weight gradient's ds_read_b32 (32 lanes = one voxel's 32 channels) is conflict-free as it always was,
+//     and every address of the tile loop is a per-lane constant + a uniform + an immediate — no swizzle arithmetic on the
+//     vector ALU next to the matrix waves (fact 1 of DESIGN 4: it costs matrix-pipe time), half the LDS writes of a conversion;
+//   * the 27 KB this frees hold a ring of three RAW g_a rows: the skip connection of the data gradient (g_x = dgrad + g_a)
+//     reads the row the weight-gradient waves fetched for the conversion two tiles earlier instead of fetching it from HBM a
+//     second time (PMC: 1.38x the algorithmic bytes before);
 //   * waves 0-1 run the data gradient of the segment's two 32-pixel halves (weights resident: 144 registers), waves 2-3 the
 //     weight gradient of the same halves (nine accumulators: 144 registers): 144 MFMAs per wave and tile either way;
 //     77 KB of LDS, two workgroups per CU cover each other's barrier waits and element-wise passes.
@@ -30,12 +35,14 @@
 #include <cstdlib>
 
 #define BW_W 80                         // staged voxels per row: 8 + 64 + 8
-#define BW_ROW_BYTES (BW_W * 128)       // 10,240
-#define BW_SLOT_BYTES (2 * BW_ROW_BYTES)   // plain + swizzled
-#define BW_X_OFF (3 * BW_SLOT_BYTES)    // 61,440: two x rows (double buffer) of the segment's own 64 voxels (the transposed
-#define BW_XROW_BYTES (64 * 128)        //         pairing shifts g_z, not x: no halo)
-#define BW_COEF_OFF (BW_X_OFF + 2 * BW_XROW_BYTES)   // 77,824: k1, k2, k3, scale, shift, mean [6][32]
-#define BW_LDS_BYTES (BW_COEF_OFF + 6 * 128)          // 78,592
+#define BW_PITCH 144                    // bytes per staged g_z voxel (128 + 16: consecutive voxels 4 banks apart)
+#define BW_ROW_BYTES (BW_W * BW_PITCH)  // 11,520
+#define BW_SLOT_BYTES BW_ROW_BYTES
+#define BW_X_OFF (3 * BW_SLOT_BYTES)    // 34,560: two x rows (double buffer) of the segment's own 64 voxels (the transposed
+#define BW_XROW_BYTES (64 * 128)        //         pairing shifts g_z, not x: no halo), plain 128-byte voxels (LDS-DMA)
+#define BW_GA_OFF (BW_X_OFF + 2 * BW_XROW_BYTES)     // 50,944: ring of three raw g_a rows (the segment's own 64 voxels)
+#define BW_COEF_OFF (BW_GA_OFF + 3 * BW_XROW_BYTES)  // 75,520: k1, k2, k3, scale, shift, mean [6][32]
+#define BW_LDS_BYTES (BW_COEF_OFF + 6 * 128)          // 76,288
 #ifndef BW_GRID
 #define BW_GRID 512                     // two resident workgroups per CU (tests/tools/grid_sweep.sh rebuilds with EXTRA=-DBW_GRID=n)
 #endif
@@ -90,7 +97,7 @@ template <int IMM> __device__ inline void bw_load_imm(float& v, const float* sba
 #define BW_FOR_ROWS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
 __device__ inline f32x4 bw_chunk(const char* row, int v, int h, int q) {
-  return *reinterpret_cast<const f32x4*>(row + v * 128 + (((4 * h + q) ^ ((v >> 1) & 7)) << 4));
+  return *reinterpret_cast<const f32x4*>(row + v * BW_PITCH + (4 * h + q) * 16);
 }
 
 // One role per wave, each a separate instantiation of the whole unit / tile loop (written as one body with a run-time
@@ -150,8 +157,8 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
   // group t2 & 7) of an 80-voxel row
   const int t2 = threadIdx.x & 127;
   const int c4 = (t2 & 7) * 4;
-  const int cv_plain = t2 * 16;
-  const int cv_swz = BW_ROW_BYTES + (t2 >> 3) * 128 + (((t2 & 7) ^ ((t2 >> 4) & 7)) << 4);
+  const int cv_gz = (t2 >> 3) * BW_PITCH + (t2 & 7) * 16;        // + 16 voxels (2,304 bytes) per k
+  const int cv_ga = ((t2 >> 3) - 8) * 128 + (t2 & 7) * 16;       // raw g_a row: staged voxel v -> own voxel v - 8 (+ 2,048 per k)
   const unsigned io_off = (unsigned)(512 * h + 4 * li);
 
 #ifdef BW_TIMING_BUILD
@@ -194,19 +201,15 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
         pz[k] = *reinterpret_cast<const f32x4*>(zrow + (t2 + 128 * k) * 4);
       }
     };
-    auto convert_row = [&](int jj) {                       // -> ring slot (jj + 1) % 3, plain + swizzled
+    auto convert_row = [&](int jj) {                       // -> g_z ring slot (jj + 1) % 3, raw g_a ring slot (jj + 3) % 3
       const int y = r0 + jj * d;
-      // both destinations are lane constants + the slot + 2,048 k: voxel (t2 >> 3) + 16 k keeps its swizzle term
-      // ((v >> 1) & 7 = (t2 >> 4) & 7) for every k
-      char* dst_plain = smem + ((jj + 1) % 3) * BW_SLOT_BYTES + cv_plain;
-      char* dst_swz = smem + ((jj + 1) % 3) * BW_SLOT_BYTES + cv_swz;
+      // destinations are lane constants + the slot + a multiple of k
+      char* dst_gz = smem + ((jj + 1) % 3) * BW_SLOT_BYTES + cv_gz;
+      char* dst_ga = smem + BW_GA_OFF + ((jj + 3) % 3) * BW_XROW_BYTES + cv_ga;
       if (y < 0 || y >= H) {                               // (workgroup-uniform; no memory instruction but LDS writes inside)
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          *reinterpret_cast<f32x4*>(dst_plain + k * 2048) = (f32x4){0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(dst_swz + k * 2048) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        return;
+        for (int k = 0; k < 5; ++k) *reinterpret_cast<f32x4*>(dst_gz + k * 16 * BW_PITCH) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;                                            // (no tile of such a row: its raw g_a is never read)
       }
       const float* tab = reinterpret_cast<const float*>(smem + BW_COEF_OFF) + c4;
       const f32x4 k1 = *reinterpret_cast<const f32x4*>(tab), k2 = *reinterpret_cast<const f32x4*>(tab + 32),
@@ -226,8 +229,10 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
           const int xx = x0 - 8 + (t2 >> 3) + 16 * k;
           gzv = (xx >= 0 && xx < W) ? gzv : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        *reinterpret_cast<f32x4*>(dst_plain + k * 2048) = gzv;
-        *reinterpret_cast<f32x4*>(dst_swz + k * 2048) = gzv;
+        *reinterpret_cast<f32x4*>(dst_gz + k * 16 * BW_PITCH) = gzv;
+        // the raw g_a of the segment's own 64 voxels (staged voxels 8..71) for the skip connection two tiles from now
+        if (k >= 1 && k <= 3) *reinterpret_cast<f32x4*>(dst_ga + k * 2048) = ga;
+        else if (k == 0 ? (t2 >> 3) >= 8 : (t2 >> 3) < 8) *reinterpret_cast<f32x4*>(dst_ga + k * 2048) = ga;
       }
     };
     auto issue_x = [&](int jj) {                           // data-gradient waves: x row of comb index jj -> x buffer jj & 1
@@ -260,7 +265,6 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
         // ---- data gradient: out[y][x] = sum_{kh,kw} g_z[y+(kh-1)d][x+(kw-1)d] * Wt[kh][kw]  (+ g_a[y][x]) ----
         const long vox0 = (img + y + p.g.ph) * Wp + xw + p.g.pw;
         float* gx_base = p.gx + vox0 * 32;
-        const float* res_base = p.ga + vox0 * 32;
         const float* nz_base = p.nz + vox0 * 32;
         const int vbase = 8 + 32 * half + li;
         float res[16], zt[16];
@@ -268,7 +272,7 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         f32x4 a[4];
-        const char* rows[3] = {slot_prev + BW_ROW_BYTES, slot_cur + BW_ROW_BYTES, slot_next + BW_ROW_BYTES};
+        const char* rows[3] = {slot_prev, slot_cur, slot_next};
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) a[cc] = bw_chunk(rows[0], vbase - d, h, cc);
 #pragma unroll
@@ -278,11 +282,6 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
             a[(cc + 3) & 3] = bw_chunk(rows[tp / 3], vbase + (tp % 3 - 1) * d, h, (cc + 3) & 3);
           }
 #ifndef BW_EXP_NOEPI
-          if (cc == 4) {
-#define BW_LD(r) bw_load_imm<BW_ROW_IMM(r)>(res[r], res_base, io_off);
-            BW_FOR_ROWS(BW_LD)
-#undef BW_LD
-          }
           if (cc == 8) {
 #define BW_LD(r) bw_load_imm<BW_ROW_IMM(r)>(zt[r], nz_base, io_off);
             BW_FOR_ROWS(BW_LD)
@@ -307,11 +306,13 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bn_dy += acc[r];
 #else
-        // the x row of the next tile, the skip-connection row and the next layer's pre-activation row are home
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]),
-                       "+v"(res[7]), "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]),
-                       "+v"(res[13]), "+v"(res[14]), "+v"(res[15]) :: "memory");
+        // the skip connection: raw g_a of row j, left in LDS by the conversion two tiles ago (ring slot (j + 3) % 3)
+        {
+          const char* garow = smem + BW_GA_OFF + ((j + 3) % 3) * BW_XROW_BYTES + (32 * half + 4 * h) * 128 + li * 4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) res[r] = *reinterpret_cast<const float*>(garow + ((r & 3) + 8 * (r >> 2)) * 128);
+        }
+        // the x row of the next tile and the next layer's pre-activation row are home
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(zt[0]), "+v"(zt[1]), "+v"(zt[2]), "+v"(zt[3]), "+v"(zt[4]), "+v"(zt[5]), "+v"(zt[6]),
                        "+v"(zt[7]), "+v"(zt[8]), "+v"(zt[9]), "+v"(zt[10]), "+v"(zt[11]), "+v"(zt[12]),
@@ -337,7 +338,7 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
           const char* row = (tp / 3 == 0) ? slot_next : ((tp / 3 == 1) ? slot_cur : slot_prev);
-          gaddr[tp] = row + (u0 - (tp % 3 - 1) * d) * 128 + li * 4;
+          gaddr[tp] = row + (u0 - (tp % 3 - 1) * d) * BW_PITCH + li * 4;
         }
         const int dup = x_new - xw;            // pixels below `dup` were counted by the neighbouring segment
         float av[2], bv[2][9];
@@ -349,7 +350,7 @@ __device__ __forceinline__ void conv32_bwd_role(const BwdArgs& p, char* smem) {
           if (s + 1 < 16) {
             av[(s + 1) & 1] = *reinterpret_cast<const float*>(xaddr + (s + 1) * 256);
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) bv[(s + 1) & 1][tp] = *reinterpret_cast<const float*>(gaddr[tp] + (s + 1) * 256);
+            for (int tp = 0; tp < 9; ++tp) bv[(s + 1) & 1][tp] = *reinterpret_cast<const float*>(gaddr[tp] + (s + 1) * 2 * BW_PITCH);
           }
           __builtin_amdgcn_sched_barrier(0);
           const bool counted = 2 * s + h >= dup;

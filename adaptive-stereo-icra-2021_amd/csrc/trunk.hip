@@ -179,32 +179,40 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
   }
   const float bias_v = wave == 0 ? p.bias[li] : 0.f;
 
-  if (MODE == 1) trunk_bn_merge(p.bn, group, mred, tab, wi == 0);
-
-  TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
-  for (int t = wi; t < p.tg.tiles_per_group; t += p.tg.gper) {
+  // The staging loads of a tile (16-byte chunks; 816 jobs over 256 threads) are requested one tile ahead: those of the first
+  // tile before the BatchNorm merge (they depend on nothing — the merge's round trips and theirs overlap), those of tile
+  // t + gper behind the barrier that publishes tile t's operand, in flight during its matrix phase and epilogue.
+  f32x4 q[4], r[4];
+  long off[4];
+  auto request = [&](int t) {
     const TileId id = trunk_tile(p.tg, group, t);
-    // ---- stage 3 x 34 voxels (16-byte chunks; 816 jobs over 256 threads) -------------------------------------------
-    f32x4 q[4], r[4];
-    long off[4];
-    bool inside[4], own[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int job = threadIdx.x + 256 * k;
       const int sv = min(job, TR_JOBS - 1) >> 3, c = job & 7;
       const int row = sv / TR_COLS, col = sv - row * TR_COLS;
-      const int yy = id.y + row - 1, xx = id.x0 + col - 1;
-      inside[k] = job < TR_JOBS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      own[k] = inside[k] && row == 1 && col >= 1 && col <= 32;
-      const int yc = min(max(yy, 0), g.H - 1), xc = min(max(xx, 0), g.W - 1);
+      const int yc = min(max(id.y + row - 1, 0), g.H - 1), xc = min(max(id.x0 + col - 1, 0), g.W - 1);
       off[k] = g.vox(id.b, 0, yc, xc) * 32 + c * 4;
       q[k] = *reinterpret_cast<const f32x4*>(p.src + off[k]);
       if (MODE == 1) r[k] = *reinterpret_cast<const f32x4*>(p.skip + off[k]);
     }
+  };
+  request(wi);
+  if (MODE == 1) trunk_bn_merge(p.bn, group, mred, tab, wi == 0);
+
+  TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
+  for (int t = wi; t < p.tg.tiles_per_group; t += p.tg.gper) {
+    const TileId id = trunk_tile(p.tg, group, t);
+    // ---- stage 3 x 34 voxels ------------------------------------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int job = threadIdx.x + 256 * k;
       const int sv = job >> 3, c = job & 7;
+      const int svc = min(job, TR_JOBS - 1) >> 3;
+      const int row = svc / TR_COLS, col = svc - row * TR_COLS;
+      const int yy = id.y + row - 1, xx = id.x0 + col - 1;
+      const bool inside = job < TR_JOBS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+      const bool own = inside && row == 1 && col >= 1 && col <= 32;
       f32x4 v = q[k];
       if (MODE == 1) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + c * 4);
@@ -212,12 +220,13 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
         f32x4 y = q[k] * sc + sh;
         y = lrelu_sel(y, y, p.slope);
         v = y + r[k];
-        if (own[k]) *reinterpret_cast<f32x4*>(p.a_out + off[k]) = v;
+        if (own) *reinterpret_cast<f32x4*>(p.a_out + off[k]) = v;
       }
-      if (!inside[k]) v = f32x4{0.f, 0.f, 0.f, 0.f};           // zero padding (a BatchNorm'd halo would be lrelu(shift))
+      if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};              // zero padding (a BatchNorm'd halo would be lrelu(shift))
       if (job < TR_JOBS) *reinterpret_cast<f32x4*>(op + op_addr(sv, c)) = v;
     }
     __syncthreads();
+    if (t + p.tg.gper < p.tg.tiles_per_group) request(t + p.tg.gper);
 
     // ---- split-K matrix phase: wave w multiplies taps w, w+4, w+8 ------------------------------------------------------
     f32x16 acc;
@@ -312,6 +321,29 @@ __global__ __launch_bounds__(256) void trunk_bwd_kernel(TrunkBwdArgs p) {
     }
   }
 
+  // loads one tile ahead, as in the forward kernel: the first tile's before the merge of the stage-1 sums (their round
+  // trips overlap), those of tile t + gper in flight during tile t's matrix phase and epilogue
+  float xr[16];
+  f32x4 q[4], r[4];
+  auto request = [&](int t) {
+    const TileId id = trunk_tile(p.tg, group, t);
+    // the weight gradient's A operand: the tile's own voxels of x, 16 voxel pairs (lane half h = voxel parity), channel li
+    const float* xrow = p.x + g.vox(id.b, 0, id.y, 0) * 32 + li;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xr[s] = xrow[(long)min(id.x0 + 2 * s + h, g.W - 1) * 32];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int job = threadIdx.x + 256 * k;
+      const int sv = min(job, TR_JOBS - 1) >> 3, c = job & 7;
+      const int row = sv / TR_COLS, col = sv - row * TR_COLS;
+      const int yc = min(max(id.y + row - 1, 0), g.H - 1), xc = min(max(id.x0 + col - 1, 0), g.W - 1);
+      const long off = g.vox(id.b, 0, yc, xc) * 32 + c * 4;
+      q[k] = *reinterpret_cast<const f32x4*>(p.g_a + off);
+      if (MODE == 1) r[k] = *reinterpret_cast<const f32x4*>(p.z + off);
+    }
+  };
+  request(wi);
+
   if (MODE == 1) {
     // stage 2 of the BatchNorm backward by the consumer: fixed-order fp64 sum of the group's partials
     const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -356,38 +388,23 @@ __global__ __launch_bounds__(256) void trunk_bwd_kernel(TrunkBwdArgs p) {
   float db_run = 0.f;
   double run_dy = 0.0, run_dx = 0.0;
 
+
   for (int t = wi; t < p.tg.tiles_per_group; t += p.tg.gper) {
     const TileId id = trunk_tile(p.tg, group, t);
-    // the weight gradient's A operand: the tile's own voxels of x, 16 voxel pairs (lane half h = voxel parity), channel li
-    float xr[16];
-    {
-      const float* xrow = p.x + g.vox(id.b, 0, id.y, 0) * 32 + li;
+    float xa[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int u = 2 * s + h, xx = id.x0 + u;
-        const bool ok = u >= id.dup && xx < g.W;
-        const float v = xrow[(long)min(xx, g.W - 1) * 32];
-        xr[s] = ok ? v : 0.f;
-      }
-    }
-    f32x4 q[4], r[4];
-    bool inside[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int job = threadIdx.x + 256 * k;
-      const int sv = min(job, TR_JOBS - 1) >> 3, c = job & 7;
-      const int row = sv / TR_COLS, col = sv - row * TR_COLS;
-      const int yy = id.y + row - 1, xx = id.x0 + col - 1;
-      inside[k] = job < TR_JOBS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      const int yc = min(max(yy, 0), g.H - 1), xc = min(max(xx, 0), g.W - 1);
-      const long off = g.vox(id.b, 0, yc, xc) * 32 + c * 4;
-      q[k] = *reinterpret_cast<const f32x4*>(p.g_a + off);
-      if (MODE == 1) r[k] = *reinterpret_cast<const f32x4*>(p.z + off);
+    for (int s = 0; s < 16; ++s) {
+      const int u = 2 * s + h;
+      xa[s] = (u >= id.dup && id.x0 + u < g.W) ? xr[s] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int job = threadIdx.x + 256 * k;
       const int sv = job >> 3, c = job & 7;
+      const int svc = min(job, TR_JOBS - 1) >> 3;
+      const int row = svc / TR_COLS, col = svc - row * TR_COLS;
+      const int yy = id.y + row - 1, xx = id.x0 + col - 1;
+      const bool inside = job < TR_JOBS && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
       f32x4 v = q[k];
       if (MODE == 1) {
         const f32x4 k1 = *reinterpret_cast<const f32x4*>(tab + c * 4);
@@ -400,10 +417,11 @@ __global__ __launch_bounds__(256) void trunk_bwd_kernel(TrunkBwdArgs p) {
         const f32x4 dx = (r[k] - mu) * k2;
         v = (gg - k1 - dx) * k3;
       }
-      if (!inside[k]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!inside) v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (job < TR_JOBS) *reinterpret_cast<f32x4*>(op + op_addr(sv, c)) = v;
     }
     __syncthreads();
+    if (t + p.tg.gper < p.tg.tiles_per_group) request(t + p.tg.gper);
 
     // ---- data gradient (split-K over the taps of the mirrored kernel) and weight gradient ------------------------------
     f32x16 acc;
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(256) void trunk_bwd_kernel(TrunkBwdArgs p) {
         for (int s = 0; s < 16; ++s) {
           const int sv = base + 2 * s;
           const float bv = op[op_addr(sv, li >> 2) + (li & 3)];
-          wacc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[s], bv, wacc[k], 0, 0, 0);
+          wacc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], bv, wacc[k], 0, 0, 0);
         }
       }
     }
