@@ -144,6 +144,9 @@ _SIGNATURES = {
   "as_upsample_bilinear_bwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),
   "as_warp_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
   "as_warp_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+  "as_warp_bwd_add": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+  "as_monodepth_loss_bwd_masked": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp,
+                                           c_vp]),
   "as_monodepth_workspace": (c_i64, [c_int, c_int, c_int]),
   "as_monodepth_loss_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp]),

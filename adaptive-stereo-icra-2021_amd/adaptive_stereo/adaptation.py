@@ -275,10 +275,13 @@ class OnlineAdapter(object):
       fl, fr = self.feature_net(left), self.feature_net(right)   # collectives inside: one stream, one order
     out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     pred = out["pred_disp_l/{}".format(self.scale)]
-    warped, mask = self.warper(right, pred, right_to_left=True)
-    total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+    if pred.shape[-2:] != (self.warper._height, self.warper._width):
+      raise AssertionError("OnlineAdapter: images of %s, built for %dx%d" % (tuple(pred.shape[-2:]), self.warper._height,
+                                                                                self.warper._width))
+    # warp + monodepth loss + masked mean (adapt.py:78-86) as one autograd node: (mean, sum, valid count, warped, mask)
+    mean, lsum, count, warped, _mask = hip_ops.MaskedPhotometricFn.apply(pred, left, right, self.sw)
     fcs_map = feature_contrast_mean(out["cost_volume_l/{}".format(self.coarse_scale)])
-    return total, mask, fcs_map, out, warped
+    return (mean, lsum, count), fcs_map, out, warped
 
   def _step_eager(self, left, right):
     self.feature_net.train(); self.stereo_net.train()
@@ -288,14 +291,13 @@ class OnlineAdapter(object):
     prev_sync = hip_ops.set_bn_sync(self.bn_sync)
     hip_ops.rmw_order_reset(True)        # two streams update the same gradient sinks / running statistics: keep order
     try:
-      total, mask, fcs_map, out, warped = self._forward_maps(left, right)
+      (loss, lsum, count), fcs_map, out, warped = self._forward_maps(left, right)
 
       if not self.dp:
-        loss = masked_mean(total, mask)
         fcs = fcs_map.mean()
         loss.backward()
       else:
-        loss, fcs = self._distributed_backward(total, mask, fcs_map, left.shape[0])
+        loss, fcs = self._distributed_backward(lsum, count, fcs_map)
     finally:
       hip_ops.rmw_order_reset(False)
       hip_ops.set_bn_sync(prev_sync)
@@ -338,9 +340,7 @@ class OnlineAdapter(object):
           fl, fr = self._features_train(left, right) if two_streams else (self.feature_net(left), self.feature_net(right))
         out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
         pred = out["pred_disp_l/{}".format(self.scale)]
-        warped, mask = self.warper(right, pred, right_to_left=True)
-        total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
-        loss = masked_mean(total, mask)
+        loss, lsum, count, warped, _mask = hip_ops.MaskedPhotometricFn.apply(pred, left, right, self.sw)
         backprop = loss
         replay_loss = None
         if replay is not None:
@@ -358,8 +358,8 @@ class OnlineAdapter(object):
     fcs = fcs_map.mean()
     dp_terms = None
     if self.dp:
-      m8 = self._dp_local_sums(total, mask, fcs_map)        # this rank's [count, loss sum, FCS sum, FCS count]
-      six = torch.zeros(6, dtype=torch.float32, device=total.device)
+      self._dp_local_sums(lsum, count, fcs_map)             # this rank's [count, loss sum, FCS sum, FCS count]
+      six = torch.zeros(6, dtype=torch.float32, device=lsum.device)
       six[:4] = self.scalars
       if replay_loss is not None:
         # the UNCLAMPED local count travels: the reference's whole-batch denominator is max(sum_r n_r, 1)
@@ -375,10 +375,10 @@ class OnlineAdapter(object):
         # divided by the valid-pixel count N after its all-reduce, so this rank back-propagates
         # sum_r(monodepth) + w * (N / M) * sum_r(khamis) = ... + w * (N / M) * n_r * khamis_r
         replay_coef, replay_whole = replay_whole_batch_terms(six, n_gt, er_loss_weight)
-        dp_terms = (total, m8, replay_loss, replay_coef, six[0])
+        dp_terms = (lsum, replay_loss, replay_coef, six[0])
         replay_loss = replay_whole
       else:
-        dp_terms = (total, m8, None, None, six[0])
+        dp_terms = (lsum, None, None, six[0])
     if self.fcs_smoothed is None:
       self.fcs_smoothed = fcs.detach().clone()
     else:
@@ -398,11 +398,11 @@ class OnlineAdapter(object):
     hip_ops.rmw_order_reset(self.bn_sync is None)
     try:
       if self.dp:
-        total, m8, replay_loss, replay_coef, n_total = result["dp_terms"]
+        lsum, replay_loss, replay_coef, n_total = result["dp_terms"]
         if replay_loss is None:
-          total.backward(m8.to(torch.float32))
+          lsum.backward()
         else:
-          torch.autograd.backward([total, replay_loss], [m8.to(torch.float32), replay_coef.reshape(replay_loss.shape)])
+          torch.autograd.backward([lsum, replay_loss], [torch.ones_like(lsum), replay_coef.reshape(replay_loss.shape)])
       else:
         result["backprop_loss"].backward()
     finally:
@@ -422,21 +422,13 @@ class OnlineAdapter(object):
     fl, fr = self._features_eval(left, right)
     out = self.stereo_net(left, fl, fr, "l", output_cost_volume=True)
     pred = out["pred_disp_l/{}".format(self.scale)]
-    warped, mask = self.warper(right, pred, right_to_left=True)
-    total = monodepth_loss(pred, left, warped, smoothness_weight=self.sw)[0]
+    loss, lsum, count, _warped, _mask = hip_ops.MaskedPhotometricFn.apply(pred, left, right, self.sw)
     if self.dp:
       # every rank scores its own buffered pair; the state machine must see ONE number on all ranks: the masked mean
       # over the pairs of all ranks (buffers fill in lock-step: the OOD gate is decided on all-reduced scalars)
-      m8 = mask.to(torch.uint8).contiguous()
-      n = total.numel()
-      ws = torch.empty(nat.load().as_masked_sum_workspace(n), dtype=torch.float32, device=total.device)
-      two = torch.empty(2, dtype=torch.float32, device=total.device)
-      tc = total.contiguous()
-      nat.call("as_masked_sum", nat.ptr(tc), nat.ptr(m8), n, nat.ptr(two), nat.ptr(ws), nat.stream())
+      two = torch.stack([lsum.detach(), count.detach()])
       self._all_reduce_small(two)
       loss = two[0] / two[1]
-    else:
-      loss = masked_mean(total, mask)
     self.feature_net.train(was_f); self.stereo_net.train(was_s)
     return float(loss)
 
@@ -515,9 +507,9 @@ class OnlineAdapter(object):
         self.plan.begin()
         hip_ops.rmw_order_reset(True)
         try:
-          total, mask, fcs_map, out, warped = self._forward_maps(self._static_left, self._static_right)
-          m8 = self._dp_local_sums(total, mask, fcs_map)
-          self._dp_backward(total, m8)
+          (_, lsum, count), fcs_map, out, warped = self._forward_maps(self._static_left, self._static_right)
+          self._dp_local_sums(lsum, count, fcs_map)
+          self._dp_backward(lsum)
         finally:
           hip_ops.rmw_order_reset(False)
           self.plan.end()
@@ -563,23 +555,15 @@ class OnlineAdapter(object):
     return self._static_result
 
   # -- data-parallel step in three device-side phases with the two collectives between them ---------------
-  def _dp_local_sums(self, total, mask, fcs_map):
+  def _dp_local_sums(self, lsum, count, fcs_map):
     """Phase 1 tail: this rank's [valid count, loss sum, FCS sum, FCS count] into self.scalars (no communication)."""
-    m8 = mask.to(torch.uint8)
-    lib = nat.load()
-    n = total.numel()
-    ws = torch.empty(lib.as_masked_sum_workspace(n), dtype=torch.float32, device=total.device)
-    local = torch.empty(2, dtype=torch.float32, device=total.device)
-    td, m8c = total.detach().contiguous(), m8.contiguous()
-    nat.call("as_masked_sum", nat.ptr(td), nat.ptr(m8c), n, nat.ptr(local), nat.ptr(ws), nat.stream())
-    fill_step_scalars(self.scalars, local[0], local[1], fcs_map.sum(), float(fcs_map.numel()))
-    return m8
+    fill_step_scalars(self.scalars, lsum.detach(), count.detach(), fcs_map.sum(), float(fcs_map.numel()))
 
-  def _dp_backward(self, total, m8):
-    """Phase 1 tail: the gradient of this rank's masked loss SUM (d sum / d total = mask).  The whole-batch masked
-    mean of the reference (adapt.py:83) is (sum over ranks of these sums) / N_total, and backward is linear in the
-    incoming gradient: the division by N_total waits until gradients and counts have been all-reduced together."""
-    total.backward(m8.to(torch.float32))
+  def _dp_backward(self, lsum):
+    """Phase 1 tail: the gradient of this rank's masked loss SUM.  The whole-batch masked mean of the reference
+    (adapt.py:83) is (sum over ranks of these sums) / N_total, and backward is linear in the incoming gradient: the
+    division by N_total waits until gradients and counts have been all-reduced together."""
+    lsum.backward()
     hip_ops.flush_deferred_reductions()          # the gradients must be complete before the all-reduce reads them
 
   def _dp_results(self):
@@ -588,9 +572,9 @@ class OnlineAdapter(object):
     self.arena.grads.div_(s[0])
     return s[1] / s[0], s[2] / s[3]
 
-  def _distributed_backward(self, total, mask, fcs_map, pairs):
-    m8 = self._dp_local_sums(total, mask, fcs_map)
-    self._dp_backward(total, m8)
+  def _distributed_backward(self, lsum, count, fcs_map):
+    self._dp_local_sums(lsum, count, fcs_map)
+    self._dp_backward(lsum)
     self._all_reduce_gradients()
     return self._dp_results()
 

@@ -1528,6 +1528,63 @@ class MonodepthLossFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------
+# The adaptation step's whole loss tail in one Function (adapt.py:78-86: monodepth_single_loss): warp the right image with the
+# predicted disparity, photometric + smoothness loss map, mean over the valid pixels.  Same kernels as LinearWarpFn,
+# MonodepthLossFn and MaskedMeanFn; what disappears is the glue between them — three loss maps nobody reads, the dense
+# gradient map mask * (g / N) and the element-wise launches that build it, the autograd add of the disparity's two gradients.
+# ----------------------------------------------------------------------------------------
+class MaskedPhotometricFn(torch.autograd.Function):
+  """pred [B,1,H,W], left, right [B,3,H,W] -> (mean, sum, count, warped, valid mask uint8 [B,1,H,W]).
+  mean = total[mask].mean(), sum = total[mask].sum() (data-parallel ranks back-propagate the sum); only mean and sum are
+  differentiable, and only w.r.t. pred."""
+
+  @staticmethod
+  def forward(ctx, pred, left, right, smoothness_weight):
+    pred, left, right = f32c(pred), f32c(left), f32c(right)
+    B, C, H, W = left.shape
+    if C != 3 or tuple(pred.shape) != (B, 1, H, W) or right.shape != left.shape:
+      raise RuntimeError("MaskedPhotometricFn: expected pred [B,1,H,W], left/right [B,3,H,W]")
+    dev = left.device
+    lib = nat.load()
+    warped = torch.empty_like(right)
+    mask = torch.empty(B, 1, H, W, dtype=torch.uint8, device=dev)
+    call("as_warp_fwd", ptr(right), ptr(pred), B, C, H, W, 1, ptr(warped), ptr(mask), stream())
+    total = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+    ws = _empty(lib.as_monodepth_workspace(B, H, W), dev)
+    call("as_monodepth_loss_fwd", ptr(pred), ptr(left), ptr(warped), B, H, W, float(smoothness_weight), ptr(total), None, None,
+         None, ptr(ws), stream())
+    out3 = _empty(3, dev)
+    ws2 = _empty(lib.as_masked_sum_workspace(total.numel()), dev)
+    call("as_masked_sum", ptr(total), ptr(mask), total.numel(), ptr(out3), ptr(ws2), stream())
+    torch.div(out3[0], out3[1], out=out3[2])
+    ctx.save_for_backward(pred, left, right, warped, mask, out3)
+    ctx.sw = float(smoothness_weight)
+    count = out3[1].clone()
+    ctx.mark_non_differentiable(count, warped, mask)
+    ctx.set_materialize_grads(False)
+    return out3[2], out3[0], count, warped, mask
+
+  @staticmethod
+  def backward(ctx, g_mean, g_sum, _g_count, _g_warped, _g_mask):
+    pred, left, right, warped, mask, out3 = ctx.saved_tensors
+    if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+      raise NotImplementedError("MaskedPhotometricFn: gradients w.r.t. the images are not part of the adaptation path")
+    if g_mean is None and g_sum is None:
+      return None, None, None, None
+    B, C, H, W = left.shape
+    dev = left.device
+    g_mean = f32c(g_mean).reshape(1) if g_mean is not None else None
+    g_sum = f32c(g_sum).reshape(1) if g_sum is not None else None
+    g_direct, g_warped = torch.empty_like(pred), torch.empty_like(warped)
+    ws = _empty(nat.load().as_monodepth_workspace(B, H, W), dev)
+    call("as_monodepth_loss_bwd_masked", ptr(mask), ptr(g_sum), ptr(g_mean), ptr(out3), ptr(pred), ptr(left), ptr(warped), B, H, W,
+         ctx.sw, ptr(g_direct), ptr(g_warped), ptr(ws), stream())
+    g_pred = torch.empty_like(pred)
+    call("as_warp_bwd_add", ptr(g_warped), ptr(right), ptr(pred), ptr(g_direct), B, C, H, W, 1, ptr(g_pred), stream())
+    return g_pred, None, None, None
+
+
+# ----------------------------------------------------------------------------------------
 # loss[mask].mean() without the boolean-index host sync (adapt.py:81-83)
 # ----------------------------------------------------------------------------------------
 class MaskedMeanFn(torch.autograd.Function):

@@ -154,10 +154,32 @@ __global__ __launch_bounds__(256) void monodepth_fwd_kernel(const float* __restr
   if (smooth) smooth[i] = sm;
 }
 
+// Where the gradient of the `total` loss map comes from: a dense map (autograd handed one over), or — the adaptation step's
+// own case, loss = total[mask].mean() (adapt.py:81-83) — the validity mask and two device scalars: every valid pixel carries
+// g_sum + g_mean / count (count = valid pixels, read from the forward's masked-sum result), every other pixel 0.  The second
+// form needs no g_total plane and none of the element-wise launches that would build it.
+struct GtSrc {
+  const float* dense;        // [B][H][W] or null
+  const uint8_t* mask;       // [B][H][W] or null
+  const float* g_sum;        // [1] or null
+  const float* g_mean;       // [1] or null
+  const float* sum_count;    // [2]: masked sum, count (g_mean only)
+};
+__device__ inline float gt_scalar(const GtSrc& s) {
+  if (s.mask == nullptr) return 0.f;
+  float v = s.g_sum ? s.g_sum[0] : 0.f;
+  if (s.g_mean) v += s.g_mean[0] / s.sum_count[1];
+  return v;
+}
+__device__ inline float gt_at(const GtSrc& s, float gs, long i) {
+  if (s.dense) return s.dense[i];
+  return (s.mask && s.mask[i]) ? gs : 0.f;
+}
+
 // ---- backward pass A: per-centre SSIM coefficients, g_nd, and partial sums of g_nd*pred -------------
 // coef layout: [B][10][H][W]: (a,b,c) x 3 channels, then g_nd.
 __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
-    const float* __restrict__ g_total, const float* __restrict__ g_ssim, const float* __restrict__ g_smooth,
+    GtSrc g_total, const float* __restrict__ g_ssim, const float* __restrict__ g_smooth,
     const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ warped,
     const float* __restrict__ mean_disp, int B, int H, int W, float sw,
     float* __restrict__ coef, double* __restrict__ partial) {
@@ -168,11 +190,12 @@ __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
   const float* Wp = warped + (long)b * 3 * plane;
   const float* P = pred + (long)b * plane;
   const float den = mean_disp[b] + 1e-7f;
+  const float gs = gt_scalar(g_total);
   double s_local = 0.0;
   for (int o = blockIdx.x * 256 + threadIdx.x; o < H * W; o += gridDim.x * 256) {
     const int y = o / W, x = o - y * W;
     const long gi = (long)b * plane + o;
-    const float gt = g_total ? g_total[gi] : 0.f;
+    const float gt = gt_at(g_total, gs, gi);
     const float G_ssim = 0.85f * gt + (g_ssim ? g_ssim[gi] : 0.f);
     float* cf = coef + (long)b * 10 * plane + o;
 #pragma unroll
@@ -193,7 +216,7 @@ __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
       g_nd += Gs * edge_wx(I, plane, y, x, W) * sgn(nd - P[o + 1] / den);
     }
     if (x > 0) {
-      const float gtl = g_total ? g_total[gi - 1] : 0.f;
+      const float gtl = gt_at(g_total, gs, gi - 1);
       const float Gs = sw * gtl + (g_smooth ? g_smooth[gi - 1] : 0.f);
       g_nd -= Gs * edge_wx(I, plane, y, x - 1, W) * sgn(P[o - 1] / den - nd);
     }
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
       g_nd += Gs * edge_wy(I, plane, y, x, W) * sgn(nd - P[o + W] / den);
     }
     if (y > 0) {
-      const float gtu = g_total ? g_total[gi - W] : 0.f;
+      const float gtu = gt_at(g_total, gs, gi - W);
       const float Gs = sw * gtu + (g_smooth ? g_smooth[gi - W] : 0.f);
       g_nd -= Gs * edge_wy(I, plane, y - 1, x, W) * sgn(P[o - W] / den - nd);
     }
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
 
 // ---- backward pass B: gather ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void monodepth_bwd_b_kernel(
-    const float* __restrict__ g_total, const float* __restrict__ g_l1,
+    GtSrc g_total, const float* __restrict__ g_l1,
     const float* __restrict__ pred, const float* __restrict__ img, const float* __restrict__ warped,
     const float* __restrict__ mean_disp, const float* __restrict__ coef, const float* __restrict__ sum_gnd_pred,
     int B, int H, int W, float* __restrict__ g_pred, float* __restrict__ g_warped) {
@@ -230,7 +253,7 @@ __global__ __launch_bounds__(256) void monodepth_bwd_b_kernel(
   const float* I = img + (long)b * 3 * plane;
   const float* Wp = warped + (long)b * 3 * plane;
   const float* cf = coef + (long)b * 10 * plane;
-  const float gt = g_total ? g_total[i] : 0.f;
+  const float gt = gt_at(g_total, gt_scalar(g_total), i);
   const float G_l1 = 0.15f * gt + (g_l1 ? g_l1[i] : 0.f);
   if (g_warped) {
 #pragma unroll
@@ -343,10 +366,33 @@ extern "C" int as_monodepth_loss_fwd(const float* pred, const float* img, const 
   return AS_OK;
 }
 
+static int monodepth_bwd(GtSrc g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
+                         const float* pred, const float* img, const float* warped, int B, int H, int W,
+                         float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream);
+
 extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
                                      const float* pred, const float* img, const float* warped, int B, int H, int W,
                                      float smoothness_weight, float* g_pred, float* g_warped,
                                      float* workspace, void* stream) {
+  GtSrc src = {g_total, nullptr, nullptr, nullptr, nullptr};
+  return monodepth_bwd(src, g_l1, g_ssim, g_smooth, pred, img, warped, B, H, W, smoothness_weight, g_pred, g_warped, workspace,
+                       stream);
+}
+
+extern "C" int as_monodepth_loss_bwd_masked(const uint8_t* mask, const float* g_sum, const float* g_mean,
+                                            const float* sum_count, const float* pred, const float* img, const float* warped,
+                                            int B, int H, int W, float smoothness_weight, float* g_pred, float* g_warped,
+                                            float* workspace, void* stream) {
+  AS_CHECK_ARG(mask && (g_sum || g_mean) && (g_mean == nullptr || sum_count != nullptr),
+               "as_monodepth_loss_bwd_masked: mask, at least one of g_sum / g_mean, and sum_count with g_mean");
+  GtSrc src = {nullptr, mask, g_sum, g_mean, sum_count};
+  return monodepth_bwd(src, nullptr, nullptr, nullptr, pred, img, warped, B, H, W, smoothness_weight, g_pred, g_warped, workspace,
+                       stream);
+}
+
+static int monodepth_bwd(GtSrc g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
+                         const float* pred, const float* img, const float* warped, int B, int H, int W,
+                         float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream) {
   AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535 && (long)H * W < (1L << 31),
                "as_monodepth_loss_bwd: bad argument");
   AS_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "as_monodepth_loss_bwd: workspace must be 16-byte aligned");

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ g_warped, const float* __restrict__ img,
-                                                        const float* __restrict__ disp, int B, int C, int H, int W, int r2l,
-                                                        float* __restrict__ g_disp) {
+                                                        const float* __restrict__ disp, const float* __restrict__ add_src,
+                                                        int B, int C, int H, int W, int r2l, float* __restrict__ g_disp) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)B * H * W) return;
   const int x = i % W, y = (i / W) % H, b = i / ((long)W * H);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   // d ix / d nx = W/2 (times the clip multiplier); d nx / d fx = 2/W; d fx / d disp = -/+ 1.
   const float g_nx = gix * (c.mx * ((float)W / 2.f));
   const float g_fx = g_nx * (2.f / (float)W);
-  g_disp[i] = r2l ? -g_fx : g_fx;
+  g_disp[i] = (r2l ? -g_fx : g_fx) + (add_src ? add_src[i] : 0.f);
 }
 
 // ---- host ------------------------------------------------------------------------------------
@@ -182,14 +182,19 @@ extern "C" int as_warp_fwd(const float* img, const float* disp, int B, int C, in
   return AS_OK;
 }
 
-extern "C" int as_warp_bwd(const float* g_warped, const float* img, const float* disp, int B, int C, int H, int W,
-                           int right_to_left, float* g_disp, void* stream) {
+extern "C" int as_warp_bwd_add(const float* g_warped, const float* img, const float* disp, const float* add_src, int B, int C,
+                               int H, int W, int right_to_left, float* g_disp, void* stream) {
   AS_CHECK_ARG(g_warped && img && disp && g_disp && B > 0 && C > 0 && H > 0 && W > 0, "as_warp_bwd: bad argument");
   const long n = (long)B * H * W;
   as_prof_mark(AS_PROF_WARP_BWD, (hipStream_t)stream, 1, 0.0);
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, g_warped, img, disp,
-                     B, C, H, W, right_to_left, g_disp);
-  as_prof_mark(AS_PROF_WARP_BWD, (hipStream_t)stream, 0, (double)B * H * W * 4.0 * (2 * C + 2));
+                     add_src, B, C, H, W, right_to_left, g_disp);
+  as_prof_mark(AS_PROF_WARP_BWD, (hipStream_t)stream, 0, (double)B * H * W * 4.0 * (2 * C + 2 + (add_src ? 1 : 0)));
   AS_CHECK_LAUNCH("as_warp_bwd");
   return AS_OK;
+}
+
+extern "C" int as_warp_bwd(const float* g_warped, const float* img, const float* disp, int B, int C, int H, int W,
+                           int right_to_left, float* g_disp, void* stream) {
+  return as_warp_bwd_add(g_warped, img, disp, nullptr, B, C, H, W, right_to_left, g_disp, stream);
 }

@@ -25,7 +25,7 @@
 #define TR_STAGE_VOX (3 * TR_COLS)          // 102 voxels
 #define TR_OP_FLOATS (TR_STAGE_VOX * 32)    // 3264 floats
 #define TR_JOBS (TR_STAGE_VOX * 8)          // 816 sixteen-byte chunks
-#define TR_GPER_MAX 128
+#define TR_GPER_MAX 128                 // 2 groups x 128 workgroups = one per CU (the backward kernel holds 450 registers: no second workgroup fits a CU; 144 per group ran 50 % slower)
 
 struct TrunkGeom {
   PclDev g;
@@ -91,7 +91,7 @@ __device__ inline void trunk_bn_merge(const TrunkBnIn& m, int group, double* red
   const int per_slice = (m.nparts + 7) >> 3;
   const double K = (double)sm[c];
   double s0 = 0.0, s1 = 0.0, sq = 0.0;
-  constexpr int BATCH = 8;
+  constexpr int BATCH = 12;                              // partials per thread whose loads are in flight together (96 per group per round)
   for (int j0 = 0; j0 < per_slice; j0 += BATCH) {
     float pn[BATCH], pm[BATCH], pq[BATCH];
 #pragma unroll

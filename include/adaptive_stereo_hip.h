@@ -431,6 +431,10 @@ int as_warp_fwd(const float* img, const float* disp, int B, int C, int H, int W,
                 float* warped, uint8_t* mask, void* stream);
 int as_warp_bwd(const float* g_warped, const float* img, const float* disp, int B, int C, int H, int W,
                 int right_to_left, float* g_disp, void* stream);
+/* The same with g_disp = (gradient through the warp) + add_src[i] (add_src may be NULL): the disparity receives its gradient
+ * from the loss map directly and through the warped image (adapt.py:78-86) — the sum autograd would form in a launch of its own. */
+int as_warp_bwd_add(const float* g_warped, const float* img, const float* disp, const float* add_src, int B, int C,
+                    int H, int W, int right_to_left, float* g_disp, void* stream);
 
 /* ---- a10: monodepth photometric loss — utils/loss_functions.py:41-138 ---------
  * total = 0.85*mean_c(SSIM dist) + 0.15*mean_c|I - I~| + sw*smooth(d/(mean d + 1e-7), I).
@@ -445,6 +449,12 @@ int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* 
                           const float* pred, const float* img, const float* warped, int B, int H, int W,
                           float smoothness_weight, float* g_pred, float* g_warped,
                           float* workspace, void* stream);
+/* Backward of loss = total[mask].mean() / total[mask].sum() (adapt.py:81-83) without a dense gradient map: every valid pixel
+ * of `total` carries g_sum[0] + g_mean[0] / sum_count[1] (either pointer may be NULL; sum_count = as_masked_sum's out2 of the
+ * forward pass), every other pixel 0; the l1 / ssim / smooth maps carry no gradient. */
+int as_monodepth_loss_bwd_masked(const uint8_t* mask, const float* g_sum, const float* g_mean, const float* sum_count,
+                                 const float* pred, const float* img, const float* warped, int B, int H, int W,
+                                 float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream);
 
 /* ---- loss[mask].mean() without a host sync — adapt.py:81-83 --------------------
  * out[0] = sum(v*m), out[1] = count(m); value = out[0]/out[1] is formed by the caller

@@ -1168,3 +1168,38 @@ def test_fused_full_resolution_kernels_refuse_unsupported_geometry():
     nat.call("as_conv32_bwd_fused", nat.ptr(buf[0]), g, nat.ptr(buf[1]), nat.ptr(buf[2]), g, s1, nat.ptr(wp), nat.ptr(st.scale),
              nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(buf[2]), nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(buf[3]), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.ptr(fws), nat.stream())
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 41, 67), (2, 96, 256), (1, 375, 1242)])
+def test_masked_photometric_loss_in_one_node_equals_the_separate_functions(B, H, W):
+  """hip_ops.MaskedPhotometricFn (warp + monodepth loss + masked mean as one autograd node, the gradient map mask * g / N
+  never built, the disparity's two gradients added by the warp's backward kernel) against LinearWarpFn -> MonodepthLossFn ->
+  masked_mean stitched by autograd: loss, sum, count, warped image, mask and d loss / d pred bit for bit — for the mean
+  (one-GPU step) and for the sum (what a data-parallel rank back-propagates)."""
+  from adaptive_stereo import hip_ops as ops
+  g = torch.Generator().manual_seed(41)
+  left = torch.rand(B, 3, H, W, generator=g).to(DEV)
+  right = torch.rand(B, 3, H, W, generator=g).to(DEV)
+  pred0 = (torch.rand(B, 1, H, W, generator=g) * 12.0).to(DEV)
+  for use_sum in (False, True):
+    p1 = pred0.clone().requires_grad_(True)
+    warped, mask = ops.LinearWarpFn.apply(right, p1, True)
+    total = ops.MonodepthLossFn.apply(p1, left, warped, 1e-3)[0]
+    if use_sum:
+      m8 = mask.to(torch.uint8)
+      ref = (total * m8).sum()          # (value only: fp32 torch sum; the gradient is what is compared)
+      total.backward(m8.to(torch.float32))
+    else:
+      ref = ops.masked_mean(total, mask)
+      ref.backward()
+    p2 = pred0.clone().requires_grad_(True)
+    mean, lsum, count, warped2, mask2 = ops.MaskedPhotometricFn.apply(p2, left, right, 1e-3)
+    (lsum if use_sum else mean).backward()
+    assert torch.equal(warped2, warped) and torch.equal(mask2.bool(), mask)
+    assert int(count) == int(mask.sum())
+    if not use_sum:
+      assert float(mean) == float(ref)
+    else:
+      assert abs(float(lsum) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert torch.equal(p2.grad, p1.grad), float((p2.grad - p1.grad).abs().max())
+    assert float(p2.grad.abs().max()) > 0.0
