@@ -159,6 +159,8 @@ _SIGNATURES = {
   "as_khamis_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
   "as_eval_metrics_workspace": (c_i64, [c_i64]),
   "as_eval_metrics": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+  "as_relu_bwd": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+  "as_mirror_taps_ch0": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
   "as_sumsq_workspace": (c_i64, [c_i64]),
   "as_clip_coef": (c_int, [c_vp, c_float, c_vp, c_vp]),
   "as_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -461,7 +461,9 @@ class OnlineAdapter(object):
       raise RuntimeError("OnlineAdapter.capture: cross-replica BatchNorm puts collectives inside forward and backward; "
                          "over torch.distributed collectives a step cannot be captured with sync_bn=True (step() runs eagerly)")
     self._refuse_nested_capture("capture")
-    self._static_left, self._static_right = left.clone(), right.clone()
+    # one buffer, the two images its halves: the pair pass of the feature extractor then needs no concatenation copy
+    pair = torch.cat([left, right])
+    self._static_left, self._static_right = pair[:left.shape[0]], pair[left.shape[0]:]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

@@ -1338,7 +1338,9 @@ class EdgeRefineFn(torch.autograd.Function):
     xs, zs, sts = ctx.xs, ctx.zs, ctx.sts
     grads = [None] * 30
 
-    g_pre = (f32c(g_out) * (out > 0)).contiguous()            # through the final ReLU (stereo_net.py:121)
+    g_out = f32c(g_out)
+    g_pre = torch.empty_like(out)                             # through the final ReLU (stereo_net.py:121)
+    call("as_relu_bwd", ptr(g_out), ptr(out), out.numel(), ptr(g_pre), stream())
     w_out = params[28]
     sinks = ctx.sinks
     g_a = POOL.get(g, dev)
@@ -1389,7 +1391,8 @@ class EdgeRefineFn(torch.autograd.Function):
         # g_z0 itself is needed by nobody: only its 3x3 32->1 data gradient towards the disparity channel is.  The weight
         # gradient kernel writes the nine per-tap projections of g_z0 (36 B per pixel instead of 128) and a gather sums
         # the nine shifted planes — no g_z0 write, no 32-channel re-read
-        w_proj = w0[:, 0].flip(-1, -2).reshape(32, 9).t().contiguous()          # [9][32]
+        w_proj = _empty(288, dev)                                               # [9][32]: channel 0 of w0, taps mirrored
+        call("as_mirror_taps_ch0", ptr(w0), 4, ptr(w_proj), None, stream())
         h_proj = _empty(B * 9 * H * W, dev)
         call("as_conv4_wgrad_bnapply_proj", ptr(ctx.in4), g4, ptr(g_a), ptr(ctx.z0), g, s33, 4, ptr(st0.scale), ptr(st0.shift),
              ptr(st0.mean), ptr(coef), LEAKY_SLOPE, ptr(w_proj), ptr(h_proj), ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4),
@@ -1416,11 +1419,12 @@ class EdgeRefineFn(torch.autograd.Function):
     if ctx.needs_input_grad[0]:
       # d/d(up-sampled disparity) = direct path (g_pre) + conv2d_feature's data gradient for input
       # channel 0, which is a 32->1 convolution of g_z0 with mirrored taps; the add is fused.
-      w_ch0 = w0[:, 0].flip(-1, -2).reshape(32, 9).contiguous()
       g_up = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
       if h_proj is not None:
         call("as_tap_gather", ptr(h_proj), ptr(g_pre), ptr(g_up), B, H, W, stream())
       else:
+        w_ch0 = _empty(288, dev)                                                # [32][9]
+        call("as_mirror_taps_ch0", ptr(w0), 4, None, ptr(w_ch0), stream())
         call("as_conv32to1_fwd", ptr(g_z0), g, s33, ptr(w_ch0), None, ptr(g_pre), 0, ptr(g_up), stream())
       g_coarse = torch.empty(B, h, w, dtype=torch.float32, device=dev)
       call("as_upsample_bilinear_bwd", ptr(g_up), B, H, W, ptr(g_coarse), h, w, gain, stream())

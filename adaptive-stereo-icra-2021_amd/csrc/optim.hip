@@ -105,6 +105,47 @@ extern "C" int as_clip_coef(const float* sumsq, float max_norm, float* coef, voi
   return AS_OK;
 }
 
+// ---- small glue of EdgeAwareRefinement's backward (stereo_net.py:116-121), one launch each instead of torch expressions ----
+// g_in = g_out where out > 0, else 0: the final ReLU's backward.
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ out, long n,
+                                                        float* __restrict__ g_in) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(g_out + i), o = *reinterpret_cast<const f32x4*>(out + i);
+    f32x4 r;
+    r.x = o.x > 0.f ? g.x : 0.f; r.y = o.y > 0.f ? g.y : 0.f; r.z = o.z > 0.f ? g.z : 0.f; r.w = o.w > 0.f ? g.w : 0.f;
+    *reinterpret_cast<f32x4*>(g_in + i) = r;
+  } else {
+    for (long k = i; k < n; ++k) g_in[k] = out[k] > 0.f ? g_out[k] : 0.f;
+  }
+}
+
+extern "C" int as_relu_bwd(const float* g_out, const float* out, int64_t n, float* g_in, void* stream) {
+  AS_CHECK_ARG(g_out && out && g_in && n > 0, "as_relu_bwd: bad argument");
+  AS_CHECK_ARG((((uintptr_t)g_out | (uintptr_t)out | (uintptr_t)g_in) & 15) == 0, "as_relu_bwd: 16-byte aligned tensors");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(as_div_up(n, 1024)), dim3(256), 0, (hipStream_t)stream, g_out, out, (long)n, g_in);
+  AS_CHECK_LAUNCH("as_relu_bwd");
+  return AS_OK;
+}
+
+// Input channel 0 of a [32][Cin][3][3] weight with mirrored taps, in the two layouts the 32->1 data-gradient kernels read:
+// by_tap[t][c] = by_channel[c][t] = w[c][0][8 - t].
+__global__ void mirror_ch0_kernel(const float* __restrict__ w, int Cin, float* __restrict__ by_tap, float* __restrict__ by_channel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 288) return;
+  const int c = i / 9, t = i - 9 * c;
+  const float v = w[((long)c * Cin) * 9 + (8 - t)];
+  if (by_tap) by_tap[t * 32 + c] = v;
+  if (by_channel) by_channel[c * 9 + t] = v;
+}
+
+extern "C" int as_mirror_taps_ch0(const float* w, int Cin, float* by_tap, float* by_channel, void* stream) {
+  AS_CHECK_ARG(w && Cin >= 1 && (by_tap || by_channel), "as_mirror_taps_ch0: bad argument");
+  hipLaunchKernelGGL(mirror_ch0_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w, Cin, by_tap, by_channel);
+  AS_CHECK_LAUNCH("as_mirror_taps_ch0");
+  return AS_OK;
+}
+
 extern "C" int64_t as_sumsq_workspace(int64_t n) { return n > 0 ? 2 * SS_BLOCKS : -1; }
 
 extern "C" int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream) {

@@ -487,6 +487,12 @@ int as_eval_metrics(const float* pred, const float* gt, int64_t n, float* out6, 
 int64_t as_sumsq_workspace(int64_t n);
 int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream);
 /* coef[0] = min(max_norm / (sqrt(sumsq[0]) + 1e-6), 1): the scale clip_grad_norm_ applies (adapt.py:391). */
+/* Glue of EdgeAwareRefinement's backward (stereo_net.py:116-121) as single launches:
+ * as_relu_bwd: g_in[i] = out[i] > 0 ? g_out[i] : 0 (the final ReLU; n floats, 16-byte aligned);
+ * as_mirror_taps_ch0: input channel 0 of a [32][Cin][3][3] weight with mirrored taps — by_tap [9][32] and by_channel [32][9]
+ * (either may be NULL): the 32->1 data gradient of conv2d_feature towards the disparity channel. */
+int as_relu_bwd(const float* g_out, const float* out, int64_t n, float* g_in, void* stream);
+int as_mirror_taps_ch0(const float* w, int Cin, float* by_tap, float* by_channel, void* stream);
 int as_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
 int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
