@@ -819,6 +819,10 @@ class CostAggregationFn(torch.autograd.Function):
       # writes the activated tensor back only when a backward pass will need it); each launch finalizes its own BatchNorm
       lib = nat.load()
       nparts = lib.as_agg3d_parts(g)
+      # every workgroup of the consumer merges ALL of the producer's partials: fine for a few hundred (240 at 4 KITTI pairs),
+      # quadratic beyond (k = 3 volumes: 1,632 workgroups x 1,632 partials = 0.7 GB through L2 per layer, measured 2x the
+      # layer's time) — there one finalize launch per layer is the cheaper form
+      merge_in_consumer = nparts <= 512
       x, prev = vol, None
       for l in range(4):
         w, b, gamma, beta = params[4 * l:4 * l + 4]
@@ -827,7 +831,10 @@ class CostAggregationFn(torch.autograd.Function):
         if train:
           a_prev = POOL.get(g, dev) if (prev is not None and need_bwd) else None
           pending = PendingBn(StatParts(nparts, dev), gamma, beta, rm, rv)
-          z = agg3d(x, g, wp, b, in_bn=prev, a_out=a_prev, stats=pending.stats)
+          if prev is not None and not merge_in_consumer:
+            z = agg3d(x, g, wp, b, in_state=prev.finalize(), a_out=a_prev, stats=pending.stats)
+          else:
+            z = agg3d(x, g, wp, b, in_bn=prev, a_out=a_prev, stats=pending.stats)
           if prev is not None:
             xs.append(a_prev)                   # a_l (None when nothing will read it)
             if not need_bwd:
@@ -860,10 +867,15 @@ class CostAggregationFn(torch.autograd.Function):
         # one launch: layer 4's BatchNorm (merged from its partials) + LeakyReLU on the way in, 32->1 convolution,
         # soft-argmax, arg-max, FCS
         a4 = POOL.get(g, dev) if need_bwd else None
-        _rmw_wait(bn4.rm)
-        call("as_agg_tail_fwd", ptr(z4), g, None, None, bn4.block, ptr(a4), ptr(w_out), ptr(b_out), LEAKY_SLOPE,
-             ptr(logits), ptr(pred), ptr(argmax), ptr(fcs), stream())
-        _rmw_done(bn4.rm)
+        if bn4.stats.nparts <= 512:
+          _rmw_wait(bn4.rm)
+          call("as_agg_tail_fwd", ptr(z4), g, None, None, bn4.block, ptr(a4), ptr(w_out), ptr(b_out), LEAKY_SLOPE,
+               ptr(logits), ptr(pred), ptr(argmax), ptr(fcs), stream())
+          _rmw_done(bn4.rm)
+        else:
+          st4 = bn4.finalize()
+          call("as_agg_tail_fwd", ptr(z4), g, ptr(st4.scale), ptr(st4.shift), None, ptr(a4), ptr(w_out), ptr(b_out), LEAKY_SLOPE,
+               ptr(logits), ptr(pred), ptr(argmax), ptr(fcs), stream())
         keep_alive = bn4                        # (its tensors are referenced by the launch just issued)
       else:
         a4 = bn_act(z4, bn4.finalize(), g)

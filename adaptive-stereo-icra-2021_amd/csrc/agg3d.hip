@@ -50,7 +50,13 @@ struct Agg3dArgs {
   PclDev g;
   int tiles_per_plane, npos, run, groups, slot_bytes;
   int seg_len, nseg, units, per_xcd;
-  unsigned wp_magic;         // ceil(2^32 / Wp): pos / Wp == __umulhi(pos, wp_magic) for pos < 2^16
+  unsigned wp_magic;         // ceil(2^32 / Ws): pos / Ws == __umulhi(pos, wp_magic) for pos < 2^16
+  // Column strips (planes wider than four LDS runs allow — k = 3: 156 and 120 columns): a plane is cut into `strips`
+  // sub-planes of Ws = Cw + 2 columns (Ws a multiple of 8: every 8-voxel DMA group then lies inside one row), each staged
+  // and walked exactly like a narrow plane of its own — "position" = y * Ws + x', taps are constant offsets — while global
+  // addresses use the full row pitch.  The last strip is right-aligned (it may overlap its neighbour: recomputed, identical
+  // values, left out of the moments).  strips == 1: Ws == Wp, the sub-plane IS the plane (the original, contiguous form).
+  int strips, Ws, tiles_per_strip;
 };
 
 typedef __attribute__((address_space(3))) void* lds_as3_t;
@@ -92,24 +98,45 @@ __device__ inline void agg_issue_plane(const Agg3dArgs& p, int b, int q, int pos
     agg_dma_1kb(src + (long)tail_v0 * 32, off_tail, slot + tail_v0 * 128u);
 }
 
-template <int IN, int EPI>
+// Strip form: the run [rs_al, rs_al + 8 ng) in strip coordinates, group by group (a group = 8 positions of one row).
+__device__ inline void agg_issue_plane_strip(const Agg3dArgs& p, int b, int q, int rs_al, int ng, int xs, unsigned lds0, int wave,
+                                             unsigned off_reg) {
+  const float* plane = p.x + ((long)b * p.g.Dp + q) * ((long)p.g.Wp * p.g.Hp) * 32;
+  const unsigned slot = lds0 + (unsigned)((q & 3) * p.slot_bytes);
+  for (int i = wave; i < ng; i += 4) {
+    const int pos = rs_al + 8 * i;
+    const int y = (int)__umulhi((unsigned)pos, p.wp_magic), xq = pos - y * p.Ws;
+    agg_dma_1kb(plane + ((long)y * p.g.Wp + xs + xq) * 32, off_reg, slot + (unsigned)(i * 1024));
+  }
+}
+
+template <int IN, int EPI, bool STRIP>
 __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_as3_t)ring));
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, li = lane & 31;
-  const int Wp = p.g.Wp;
+  const int Wp = STRIP ? p.Ws : p.g.Wp;          // row pitch of the staged (sub-)plane: every tap offset is in these units
 
   // unit = (pair b, tile t of the plane, segment of output planes); the segments of one column sit on one XCD
   const int unit = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
   const bool active = unit < p.units;                                   // workgroup-uniform
   const int col = active ? unit / p.nseg : 0, seg = active ? unit - col * p.nseg : 0;
-  const int b = col / p.tiles_per_plane, t = col - b * p.tiles_per_plane;
+  const int b = col / p.tiles_per_plane;
+  int t = col - b * p.tiles_per_plane;
+  const int strip = STRIP ? t / p.tiles_per_strip : 0;
+  if (STRIP) t -= strip * p.tiles_per_strip;
+  const int xs = STRIP ? min(strip * (p.Ws - 2), p.g.Wp - p.Ws) : 0;    // padded global column of strip column 0
+  const int dupc = STRIP ? strip * (p.Ws - 2) - xs : 0;                 // interior strip columns <= dupc belong to the strip before
   const int d0 = seg * p.seg_len, d1 = active ? min(d0 + p.seg_len, p.g.D) : d0;
   const int first = p.g.ph * Wp + p.g.pw;
   const int pos_new = first + 128 * t;
   const int pos0 = min(pos_new, first + p.npos - 128);
-  const long plane_vox = (long)Wp * p.g.Hp;
+  const long plane_vox = (long)p.g.Wp * p.g.Hp;
+  // strip form: the run starts at a multiple of 8 (lead = what that adds in front) and is ng groups long
+  const int lead = STRIP ? ((pos0 - Wp - 1) & 7) : 0;
+  const int rs_al = pos0 - Wp - 1 - lead;
+  const int ng = STRIP ? (lead + 130 + 2 * Wp + 7) >> 3 : p.groups;
 
   // DMA lane constants (conv3d_lds.hip): source-side swizzle, the last group placed to END at the run's end
   const unsigned vl = (unsigned)(lane >> 3), sl = (unsigned)(lane & 7);
@@ -118,20 +145,34 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
   const unsigned off_tail = vl * 128u + ((sl ^ ((((tail_v0 + vl) >> 1)) & 7u)) << 4);
 
   // (the prologue's DMA is in flight while the lane masks below are computed)
+  auto issue = [&](int q) {
+    if (STRIP) agg_issue_plane_strip(p, b, q, rs_al, ng, xs, lds0, wave, off_reg);
+    else agg_issue_plane(p, b, q, pos0, plane_vox, lds0, wave, off_reg, off_tail, tail_v0);
+  };
   if (active)
-    for (int q = d0; q < d0 + 3; ++q) agg_issue_plane(p, b, q, pos0, plane_vox, lds0, wave, off_reg, off_tail, tail_v0);
+    for (int q = d0; q < d0 + 3; ++q) issue(q);
 
   // this lane's 16 output rows: position pos0 + 32*wave + row(r, h); halo columns are stored as zeros (they must stay
   // zero), duplicates of the previous tile (shifted last tile) are stored again with identical values, both are left out
   // of the moments.
   unsigned keep = 0u, fresh = 0u;                                        // bit r: interior column / first written here
+  unsigned so[STRIP ? 16 : 1];                                           // strip form: byte offset of row r's voxel in its plane
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int pos = pos0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int xp = pos - agg_div_wp(pos, p.wp_magic) * Wp;
-    const bool in = xp >= p.g.pw && xp < p.g.pw + p.g.W;
+    const int yp = agg_div_wp(pos, p.wp_magic);
+    const int xp = pos - yp * Wp;
+    bool in = xp >= p.g.pw && xp < p.g.pw + p.g.W;
+    bool fr = in && pos >= pos_new;
+    if (STRIP) {
+      const int gx = xs + xp;                                            // padded global column
+      in = xp >= 1 && xp <= Wp - 2 && gx < p.g.pw + p.g.W;
+      fr = in && pos >= pos_new && xp > dupc;
+      // rows that are not kept are stored (as zeros) onto voxel 0 of the plane — a halo voxel, zero for life
+      so[r] = (in ? (unsigned)(yp * p.g.Wp + gx) * 128u : 0u) + 4u * (unsigned)li;
+    }
     keep |= (in ? 1u : 0u) << r;
-    fresh |= ((in && pos >= pos_new) ? 1u : 0u) << r;
+    fresh |= (fr ? 1u : 0u) << r;
   }
   const unsigned io_off = (unsigned)(512 * h + 4 * li);
 
@@ -151,15 +192,24 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
     in_sh = *reinterpret_cast<const f32x4*>(tab + 32 + 4 * cg);
     __syncthreads();        // every thread has its affine before plane d0+3 is requested into the scratch's slot
   }
+  unsigned ao[STRIP ? 12 : 1];                       // strip form: byte offset of chunk k's voxel in its plane (by-product)
   if (IN != 0) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
       const int v = vrow + 32 * k;
-      const int pos = pos0 - Wp - 1 + v;
-      const int yp = agg_div_wp(pos, p.wp_magic), xp = pos - yp * Wp;
-      const bool in = v < p.run && xp >= p.g.pw && xp < p.g.pw + p.g.W && yp >= p.g.ph && yp < p.g.ph + p.g.H;
+      const int pos = rs_al + v;
+      const int yp = agg_div_wp(max(pos, 0), p.wp_magic), xp = pos - yp * Wp;
+      bool in = v < p.run && xp >= p.g.pw && xp < p.g.pw + p.g.W && yp >= p.g.ph && yp < p.g.ph + p.g.H;
+      bool own = in && v >= Wp + 1 && v < Wp + 129;
+      if (STRIP) {
+        const int gx = xs + xp;
+        // a strip's halo columns are real voxels of its neighbours: activated like any other (they feed this strip's taps)
+        in = v < 8 * ng && gx >= p.g.pw && gx < p.g.pw + p.g.W && yp >= p.g.ph && yp < p.g.ph + p.g.H;
+        own = in && v >= lead + Wp + 1 && v < lead + Wp + 129 && xp >= 1 && xp <= Wp - 2;
+        ao[k] = (unsigned)(yp * p.g.Wp + gx) * 128u;
+      }
       tmask |= (in ? 1u : 0u) << k;
-      omask |= ((in && v >= Wp + 1 && v < Wp + 129) ? 1u : 0u) << k;
+      omask |= (own ? 1u : 0u) << k;
     }
   }
   // Branch-free: all 12 chunk reads of a thread are issued together (a per-k branch would expose one LDS round trip per
@@ -170,7 +220,8 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
     if (q < p.g.pd || q >= p.g.pd + p.g.D) return;   // a halo plane: zeros stay zeros
     char* slot = ring + (q & 3) * p.slot_bytes;
     const bool own = p.a_out != nullptr && q - p.g.pd >= d0 && q - p.g.pd < d1;
-    float* outp = p.a_out + (((long)b * p.g.Dp + q) * plane_vox + (pos0 - Wp - 1)) * 32 + 4 * cg;
+    float* outp = STRIP ? p.a_out + (((long)b * p.g.Dp + q) * plane_vox) * 32 + 4 * cg
+                        : p.a_out + (((long)b * p.g.Dp + q) * plane_vox + (pos0 - Wp - 1)) * 32 + 4 * cg;
     f32x4* cp[12];
     f32x4 y[12];
 #pragma unroll
@@ -192,7 +243,10 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
     if (own) {
 #pragma unroll
       for (int k = 0; k < 12; ++k)
-        if ((omask >> k) & 1u) *reinterpret_cast<f32x4*>(outp + (long)(vrow + 32 * k) * 32) = y[k];
+        if ((omask >> k) & 1u) {
+          if (STRIP) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(outp) + ao[k]) = y[k];
+          else *reinterpret_cast<f32x4*>(outp + (long)(vrow + 32 * k) * 32) = y[k];
+        }
     }
   };
 
@@ -212,12 +266,12 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the by-product stores precede the next DMA in the queue
       __syncthreads();
     }
-    if (d0 + 1 < d1) agg_issue_plane(p, b, d0 + 3, pos0, plane_vox, lds0, wave, off_reg, off_tail, tail_v0);
+    if (d0 + 1 < d1) issue(d0 + 3);
 
     f32x4 bw[AGG_WRING][4], a[2][4];
 #pragma unroll
     for (int tp = 0; tp < AGG_WRING - 1; ++tp) agg_load_w(bw[tp], wrsrc, wlane, tp);
-    const int vbase = 32 * wave + li;
+    const int vbase = lead + 32 * wave + li;
 
     for (int d = d0; d < d1; ++d) {
       f32x16 acc;
@@ -260,16 +314,18 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
           activate(d + 3);
           __syncthreads();
         }
-        if (d + 2 < d1) agg_issue_plane(p, b, d + 4, pos0, plane_vox, lds0, wave, off_reg, off_tail, tail_v0);
+        if (d + 2 < d1) issue(d + 4);
       }
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- epilogue of plane d: 16 stores per lane, scalar base + lane offset + immediate ----
-      float* z_base = p.ep.z + ((((long)b * p.g.Dp + d + p.g.pd) * plane_vox) + pos0 + 32 * wave) * 32;
+      float* z_base = STRIP ? p.ep.z + (((long)b * p.g.Dp + d + p.g.pd) * plane_vox) * 32
+                            : p.ep.z + ((((long)b * p.g.Dp + d + p.g.pd) * plane_vox) + pos0 + 32 * wave) * 32;
 #define AGG_ST(r) { float v = acc[r];                                                       \
                     if (EPI == 1) { v = fmaf(v, ep_sc, ep_sh); v = v > 0.f ? v : v * p.ep.slope; } \
                     v = ((keep >> r) & 1u) ? v : 0.f;                                        \
-                    agg_store_imm<AGG_ROW_IMM(r)>(z_base, io_off, v); }
+                    if (STRIP) agg_store_imm<0>(z_base, so[STRIP ? r : 0], v);               \
+                    else agg_store_imm<AGG_ROW_IMM(r)>(z_base, io_off, v); }
       AGG_FOR_ROWS(AGG_ST)
 #undef AGG_ST
       if (EPI == 0 && p.ep.stat_mean != nullptr) {
@@ -307,17 +363,26 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------
-static int agg_run(const as_pcl* g) { return 130 + 2 * (g->W + 2 * g->pw); }
-static int agg_tiles_per_plane(const as_pcl* g) {
-  const int Wp = g->W + 2 * g->pw;
-  return as_div_up((int64_t)(g->H - 1) * Wp + g->W, 128);
+#define AGG_MAX_WP 83                  // widest (sub-)plane whose four runs fit in LDS: (130 + 2 * 83 + 7) / 8 = 37 groups
+static int agg_strips(const as_pcl* g) { return g->W + 2 <= AGG_MAX_WP ? 1 : as_div_up(g->W, 78); }
+static int agg_ws(const as_pcl* g) {       // row pitch of the staged (sub-)plane
+  const int n = agg_strips(g);
+  if (n == 1) return g->W + 2;
+  return (as_div_up(g->W, n) + 2 + 7) / 8 * 8;
 }
+static int agg_run(const as_pcl* g) { return 130 + 2 * agg_ws(g) + (agg_strips(g) > 1 ? 7 : 0); }   // (strips: + alignment lead)
+static int agg_tiles_per_strip(const as_pcl* g) {
+  const int Ws = agg_ws(g), cw = agg_strips(g) == 1 ? g->W : Ws - 2;
+  return as_div_up((int64_t)(g->H - 1) * Ws + cw, 128);
+}
+static int agg_tiles_per_plane(const as_pcl* g) { return agg_strips(g) * agg_tiles_per_strip(g); }
 
 bool agg3d_applicable(const as_pcl* g) {
   if (!as_pcl_ok(g) || g->pd != 1 || g->ph != 1 || g->pw != 1) return false;
-  const int Wp = g->W + 2;
-  if (Wp < 34) return false;                                      // a wave tile (32 positions) spans at most two rows
-  if ((long)(g->H - 1) * Wp + g->W < 128) return false;           // at least one full tile per plane
+  const int Ws = agg_ws(g), cw = agg_strips(g) == 1 ? g->W : Ws - 2;
+  if (Ws < 34 || Ws > AGG_MAX_WP || Ws > g->W + 2) return false;  // a wave tile (32 positions) spans at most two rows
+  if ((long)(g->H - 1) * Ws + cw < 128) return false;             // at least one full tile per (sub-)plane
+  if ((long)(g->H + 2) * Ws >= 65536) return false;               // positions are divided by Ws through a 16-bit magic multiply
   if (agg_run(g) > 32 * 12) return false;                         // the element-wise pass covers 12 x 32 voxels per plane
   return (long)((agg_run(g) + 7) / 8) * 1024 * 4 + 4096 <= 156 * 1024;   // four plane runs + the element-wise pass's dump slots
 }
@@ -343,17 +408,21 @@ int agg3d_units(const as_pcl* g) {
   return as_div_up(units, 8) * 8;                                  // = the grid = the number of BatchNorm partials
 }
 
-template <int IN, int EPI>
-static int agg_launch_t(const Agg3dArgs& a, int lds_bytes, hipStream_t st) {
+template <int IN, int EPI, bool STRIP>
+static int agg_launch_s(const Agg3dArgs& a, int lds_bytes, hipStream_t st) {
   static AsPerDevice attr_set;
   if (!attr_set.get()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(agg3d_kernel<IN, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(agg3d_kernel<IN, EPI, STRIP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { as_set_error("as_agg3d_fwd: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
     attr_set.set();
   }
-  hipLaunchKernelGGL((agg3d_kernel<IN, EPI>), dim3(8 * a.per_xcd), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((agg3d_kernel<IN, EPI, STRIP>), dim3(8 * a.per_xcd), dim3(256), lds_bytes, st, a);
   return AS_OK;
+}
+template <int IN, int EPI>
+static int agg_launch_t(const Agg3dArgs& a, int lds_bytes, hipStream_t st) {
+  return a.strips > 1 ? agg_launch_s<IN, EPI, true>(a, lds_bytes, st) : agg_launch_s<IN, EPI, false>(a, lds_bytes, st);
 }
 
 extern "C" int as_agg3d_ok(const as_pcl* g) { return agg3d_applicable(g) ? 1 : 0; }
@@ -383,8 +452,9 @@ extern "C" int as_agg3d_fwd(const float* x, const as_pcl* g, const float* packed
   a.ep.stat_cnt = moments ? stat_cnt : nullptr;
   a.ep.epilogue = epilogue; a.ep.slope = slope;
   a.g = as_make_dev(g);
+  a.strips = agg_strips(g); a.Ws = agg_ws(g); a.tiles_per_strip = agg_tiles_per_strip(g);
   a.tiles_per_plane = agg_tiles_per_plane(g);
-  a.npos = (g->H - 1) * a.g.Wp + g->W;
+  a.npos = (g->H - 1) * a.Ws + (a.strips == 1 ? g->W : a.Ws - 2);
   a.run = agg_run(g);
   a.groups = (a.run + 7) / 8;
   a.slot_bytes = a.groups * 1024;
@@ -392,7 +462,7 @@ extern "C" int as_agg3d_fwd(const float* x, const as_pcl* g, const float* packed
   a.nseg = as_div_up(g->D, a.seg_len);
   a.units = g->B * a.tiles_per_plane * a.nseg;
   a.per_xcd = as_div_up(a.units, 8);
-  a.wp_magic = (unsigned)((((uint64_t)1 << 32) + a.g.Wp - 1) / a.g.Wp);
+  a.wp_magic = (unsigned)((((uint64_t)1 << 32) + a.Ws - 1) / a.Ws);
   const int lds_bytes = 4 * a.slot_bytes + 4096;
   hipStream_t st = (hipStream_t)stream;
   const double flops = 2.0 * (double)g->B * g->D * g->H * g->W * 1024.0 * 27.0;

@@ -793,7 +793,11 @@ AGG_CASES = [  # B, D, H, W
   (2, 12, 34, 60),      # SceneFlow k=4
   (3, 5, 9, 40),        # ragged: D not a multiple of the segment length, last tile shifted back
   (1, 1, 4, 33),        # a single plane, the smallest supported width (Wp = 35 >= 34)
-  (2, 7, 6, 85),        # the widest plane whose four runs fit in LDS
+  (2, 7, 6, 81),        # the widest plane whose four runs fit in LDS as they are
+  (1, 6, 11, 156),      # KITTI k=3 width: two column strips of 78 (+2) columns
+  (2, 5, 9, 120),       # SceneFlow k=3 width: two strips of 62 (+2), the second right-aligned and overlapping the first
+  (1, 4, 7, 200),       # three strips
+  (1, 3, 47, 156),      # KITTI k=3 plane, full height
   (6, 7, 24, 78),       # segments of four planes, the last one ragged (planes 4..6)
 ]
 
@@ -904,10 +908,12 @@ def test_agg3d_layer_against_torch_and_first_generation(B, D, H, W):
 def test_agg3d_refuses_unsupported_geometry():
   lib = nat.load()
   assert lib.as_agg3d_ok(Pcl(1, 12, 24, 31, 1, 1, 1)) == 0      # Wp = 33 < 34
-  assert lib.as_agg3d_ok(Pcl(1, 12, 24, 90, 1, 1, 1)) == 0      # four runs of 130 + 2*92 voxels do not fit in LDS
-  assert lib.as_agg3d_ok(Pcl(1, 24, 47, 156, 1, 1, 1)) == 0     # KITTI k=3: stays on the first-generation kernels
+  assert lib.as_agg3d_ok(Pcl(1, 12, 24, 90, 1, 1, 1)) == 1      # wider than four LDS runs: two column strips (round 3)
+  assert lib.as_agg3d_ok(Pcl(1, 24, 47, 156, 1, 1, 1)) == 1     # KITTI k=3: two strips of 78 columns
+  assert lib.as_agg3d_ok(Pcl(1, 24, 68, 120, 1, 1, 1)) == 1     # SceneFlow k=3
   assert lib.as_agg3d_ok(Pcl(1, 12, 24, 78, 1, 2, 2)) == 0      # halo must be exactly 1
-  g = Pcl(1, 12, 24, 90, 1, 1, 1)
+  assert lib.as_agg3d_ok(Pcl(1, 12, 900, 78, 1, 1, 1)) == 0     # positions of a (sub-)plane must stay below 2^16
+  g = Pcl(1, 12, 24, 31, 1, 1, 1)
   x = ops.pcl_zeros(g, DEV)
   with pytest.raises(RuntimeError, match="not supported"):
     ops.agg3d(x, g, torch.zeros(27 * 1024, device=DEV), None, z=ops.pcl_zeros(g, DEV), epilogue=2)
