@@ -305,6 +305,7 @@ def main():
   # Roofline leg: per-launch durations of the dominant kernels from HIP events on the launch stream.
   # Events cannot bracket nodes inside a graph replay, so with --graph the same K steps are run once
   # more eagerly, right after the timed region, with the events armed (same kernels, same shapes).
+  n_graphs = adapter.graph_count()
   if use_graph:
     adapter._graph = None
   lib.as_prof_reset(); lib.as_prof_enable(1)
@@ -474,7 +475,7 @@ def main():
                "parallelism": "dp%d (%s BatchNorm statistics, one flat RCCL gradient all-reduce)" % (
                    world, "cross-replica" if adapter.bn_sync is not None else "per-replica"),
                "kernels": "all hand-written HIP (no MIOpen/rocBLAS on the path)"},
-    "launch_mode": ("hipGraph replay of the captured step (%d graph%s)" % (adapter.graph_count(), "" if adapter.graph_count() == 1 else "s"))
+    "launch_mode": ("hipGraph replay of the captured step (%d graph%s)" % (n_graphs, "" if n_graphs == 1 else "s"))
                    if use_graph else "eager",
     "collectives": None if world == 1 else ("RCCL through the library's own communicator, captured in the step's graph"
                                             if adapter.comm is not None else "torch.distributed, between two graphs"),
