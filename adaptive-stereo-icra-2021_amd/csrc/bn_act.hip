@@ -233,9 +233,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
                                                                int accumulate) {
   __shared__ double red[16][64];
   const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;      // 16 slices x 64 sums: a slice adds <= 64 slabs
+  // every load of a round of 32 slabs in flight together, then added in slab order (the order of the plain loop: the same
+  // bits): this kernel is one workgroup on the critical path of a layer's backward, its time is its round trips — with 8
+  // loads per round a 512-slab merge was four dependent rounds (7 us), now one
   double s = 0.0;
-#pragma unroll 8
-  for (int i = sl; i < nblocks; i += 16) s += partial[(long)i * 64 + j];
+  for (int i0 = sl; i0 < nblocks; i0 += 16 * 32) {
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) { const int i = i0 + 16 * u; v[u] = i < nblocks ? partial[(long)i * 64 + j] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += v[u];
+  }
   red[sl][j] = s;
   __syncthreads();
   if (threadIdx.x < 32) {
