@@ -20,6 +20,7 @@
 #include "as_common.h"
 #include "conv_epilogue.h"
 #include "trunk.h"
+#include <cstdlib>
 
 #define TR_COLS 34
 #define TR_STAGE_VOX (3 * TR_COLS)          // 102 voxels
@@ -137,6 +138,15 @@ __device__ inline void trunk_bn_merge(const TrunkBnIn& m, int group, double* red
 // Forward layer.  MODE 0: the operand is `src` as it is (first block: the head's output).  MODE 1: the operand is
 // a_{l-1} = lrelu(BN_{l-1}(src = z_{l-1})) + skip (= a_{l-2}), formed while staging; the tile's own voxels of a_{l-1} are
 // written to a_out (the next skip connection and the backward pass read it).
+// Diagnostic build (make EXTRA=-DTR_TIMING_BUILD): wave 0 of every workgroup stamps the shader clock at the phase boundaries
+// of its FIRST tile; tests/tools/trunk_timing.py prints the averages.  Never for production.
+#ifdef TR_TIMING_BUILD
+__device__ long long* g_tr_timing = nullptr;
+#define TR_T(slot) do { if (threadIdx.x == 0 && tstamp) tstamp[slot] = wall_clock64(); } while (0)
+#else
+#define TR_T(slot) do { } while (0)
+#endif
+
 struct TrunkFwdArgs {
   const float* src;
   const float* skip;
@@ -150,6 +160,9 @@ struct TrunkFwdArgs {
   float* stat_cnt;
   TrunkGeom tg;
   float slope;
+#ifdef TR_TIMING_BUILD
+  long long* timing;
+#endif
 };
 
 template <int MODE>
@@ -164,6 +177,10 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
   const int h = lane >> 5, li = lane & 31;
   const int group = blockIdx.x / p.tg.gper, wi = blockIdx.x - group * p.tg.gper;
   const PclDev g = p.tg.g;
+#ifdef TR_TIMING_BUILD
+  long long* tstamp = p.timing ? p.timing + (long)blockIdx.x * 8 : nullptr;
+#endif
+  TR_T(0);
 
   // this wave's taps (wave, wave + 4, wave + 8): B fragments resident for the whole launch; requested first — they depend on
   // nothing, the merge and the staging loads below overlap their latency
@@ -198,7 +215,9 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
     }
   };
   request(wi);
+  TR_T(1);
   if (MODE == 1) trunk_bn_merge(p.bn, group, mred, tab, wi == 0);
+  TR_T(2);
 
   TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
   for (int t = wi; t < p.tg.tiles_per_group; t += p.tg.gper) {
@@ -226,6 +245,7 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
       if (job < TR_JOBS) *reinterpret_cast<f32x4*>(op + op_addr(sv, c)) = v;
     }
     __syncthreads();
+    if (t == wi) TR_T(3);
     if (t + p.tg.gper < p.tg.tiles_per_group) request(t + p.tg.gper);
 
     // ---- split-K matrix phase: wave w multiplies taps w, w+4, w+8 ------------------------------------------------------
@@ -244,6 +264,7 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
         mfma16t(acc, a, bw[k]);
       }
     }
+    if (t == wi) TR_T(4);
     if (wave > 0) {
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) part[wave - 1][rr][lane] = acc[rr];
@@ -253,6 +274,7 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) acc[rr] = ((acc[rr] + part[0][rr][lane]) + part[1][rr][lane]) + part[2][rr][lane];
     }
+    if (t == wi) TR_T(5);
     const int x = id.x0 + li;
     const bool valid = wave == 0 && li >= id.dup && x < g.W;
     const int out_vox = (int)g.vox(id.b, 0, id.y, min(x, g.W - 1));
@@ -263,7 +285,9 @@ __global__ __launch_bounds__(256) void trunk_fwd_kernel(TrunkFwdArgs p) {
     conv_epilogue(acc, ep, out_vox, valid, id.nvalid, red, bmean, &ts);
     if (p.stat_mean != nullptr && threadIdx.x < 32) stats_merge(run, ts);
     __syncthreads();                                            // op / part / red are rewritten by the next tile
+    if (t == wi) TR_T(6);
   }
+  TR_T(7);
   if (p.stat_mean != nullptr && threadIdx.x < 32) {
     const int idx = group * p.tg.gper + wi;
     p.stat_mean[idx * 32 + threadIdx.x] = run.mean;
@@ -638,6 +662,11 @@ extern "C" int as_trunk_fwd(const float* src, const float* skip, const as_trunk_
   a.stat_mean = stat_mean; a.stat_m2 = stat_m2; a.stat_cnt = stat_cnt; a.slope = slope;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(a.tg.gper * ngroups);
+#ifdef TR_TIMING_BUILD
+  static long long* tbuf = nullptr;
+  if (!tbuf) hipMalloc(&tbuf, 1024 * 8 * 8);
+  a.timing = tbuf;
+#endif
   if (bn_prev != nullptr) {
     AS_CHECK_ARG(skip && a_out && bn_prev->stat_mean && bn_prev->stat_m2 && bn_prev->stat_cnt && bn_prev->gamma && bn_prev->beta &&
                  bn_prev->state && bn_prev->nparts >= 1, "as_trunk_fwd: incomplete as_trunk_bn / skip / a_out");
@@ -650,6 +679,15 @@ extern "C" int as_trunk_fwd(const float* src, const float* skip, const as_trunk_
     hipLaunchKernelGGL(trunk_fwd_kernel<0>, grid, dim3(256), 0, st, a);
   }
   AS_CHECK_LAUNCH("as_trunk_fwd");
+#ifdef TR_TIMING_BUILD
+  if (getenv("AS_TR_TIMING")) {                            // dump THIS launch (synchronises: diagnostic build only)
+    hipStreamSynchronize(st);
+    static long long hbuf[1024 * 8];
+    hipMemcpy(hbuf, tbuf, sizeof(hbuf), hipMemcpyDeviceToHost);
+    FILE* f = fopen("gpurun_out/trunk_timing.bin", "wb");
+    if (f) { int n = a.tg.gper * ngroups; fwrite(&n, 4, 1, f); fwrite(hbuf, 8, (size_t)n * 8, f); fclose(f); }
+  }
+#endif
   return AS_OK;
 }
 
