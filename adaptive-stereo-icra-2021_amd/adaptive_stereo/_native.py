@@ -112,6 +112,7 @@ _SIGNATURES = {
   "as_trunk_parts": (c_int, [_P(Pcl), c_int]),
   "as_trunk_fwd": (c_int, [c_vp, c_vp, _P(TrunkBn), c_vp, _P(Pcl), c_int, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_trunk_finish_fwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, c_int, c_int, _P(c_vp), _P(c_vp), c_float, c_vp]),
+  "as_trunk_begin_bwd": (c_int, [c_vp, c_vp, c_int, _P(Pcl), c_vp, c_vp]),
   "as_trunk_bwd_workspace": (c_i64, [_P(Pcl), c_int]),
   "as_trunk_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _P(Pcl), c_int, c_float,
                            c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -154,6 +155,7 @@ _SIGNATURES = {
                                     c_vp, c_vp, c_vp]),
   "as_masked_sum_workspace": (c_i64, [c_i64]),
   "as_masked_sum": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+  "as_masked_sum_mean": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_khamis_workspace": (c_i64, [c_i64]),
   "as_khamis_fwd": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_khamis_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),

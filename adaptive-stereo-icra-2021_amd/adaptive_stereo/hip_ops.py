@@ -1091,6 +1091,7 @@ class FeatureExtractorFn(torch.autograd.Function):
       out = conv32(xs[6], g, pack_weights(tp[24], shape, False), tp[25], g, shape)
       feats = pcl_interior(out, g)[:, 0].permute(0, 3, 1, 2).contiguous()
       POOL.put(out, g)
+    ctx.pair_out = groups == 2
     if need_bwd:
       ctx.k, ctx.g4, ctx.geoms, ctx.train, ctx.groups = k, g4, geoms, bool(train), groups
       ctx.sinks = sinks
@@ -1103,17 +1104,21 @@ class FeatureExtractorFn(torch.autograd.Function):
       POOL.put(in4, g4, channels=4)
       for buf, gi in zip(levels[:-1] if not trunk else levels, geoms[:-1] if not trunk else geoms):
         POOL.put(buf, gi)
+    if ctx.pair_out:
+      # the two groups as two outputs: autograd hands their gradients over separately (slicing one output afterwards costs a
+      # zero-fill and a copy per slice and an add in backward)
+      return feats[:B // 2], feats[B // 2:]
     return feats
 
   @staticmethod
-  def backward(ctx, g_feats):
+  def backward(ctx, *g_outs):
     if ctx.needs_input_grad[0]:
       raise NotImplementedError("FeatureExtractorFn: gradient w.r.t. the image is not part of the adaptation path")
     params = ctx.saved_tensors
     k, g4, geoms = ctx.k, ctx.g4, ctx.geoms
     g = geoms[-1]
     xs, zs, sts, levels = ctx.xs, ctx.zs, ctx.sts, ctx.levels
-    dev = g_feats.device
+    dev = g_outs[0].device
     lib = nat.load()
     shape = conv_shape_2d(1)
     tp = params[2 * k:]
@@ -1121,7 +1126,9 @@ class FeatureExtractorFn(torch.autograd.Function):
 
     sinks = ctx.sinks
     g_out = POOL.get(g, dev)
-    pcl_interior(g_out, g).copy_(f32c(g_feats).permute(0, 2, 3, 1).unsqueeze(1))
+    g_outs = [f32c(t) for t in g_outs]
+    call("as_trunk_begin_bwd", ptr(g_outs[0]), ptr(g_outs[1]) if len(g_outs) > 1 else None, g_outs[0].shape[0], g, ptr(g_out),
+         stream())
     if ctx.states is not None:
       g_a = FeatureExtractorFn._trunk_backward(ctx, g_out, tp, grads, sinks, dev)
     else:
@@ -1569,13 +1576,12 @@ class MaskedPhotometricFn(torch.autograd.Function):
     ws = _empty(lib.as_monodepth_workspace(B, H, W), dev)
     call("as_monodepth_loss_fwd", ptr(pred), ptr(left), ptr(warped), B, H, W, float(smoothness_weight), ptr(total), None, None,
          None, ptr(ws), stream())
-    out3 = _empty(3, dev)
+    out3 = _empty(4, dev)                          # sum, count, mean, count (a second copy: the non-differentiable output)
     ws2 = _empty(lib.as_masked_sum_workspace(total.numel()), dev)
-    call("as_masked_sum", ptr(total), ptr(mask), total.numel(), ptr(out3), ptr(ws2), stream())
-    torch.div(out3[0], out3[1], out=out3[2])
+    call("as_masked_sum_mean", ptr(total), ptr(mask), total.numel(), ptr(out3), ptr(ws2), stream())
     ctx.save_for_backward(pred, left, right, warped, mask, out3)
     ctx.sw = float(smoothness_weight)
-    count = out3[1].clone()
+    count = out3[3]
     ctx.mark_non_differentiable(count, warped, mask)
     ctx.set_materialize_grads(False)
     return out3[2], out3[0], count, warped, mask

@@ -94,7 +94,9 @@ class FeatureExtractorNetwork(nn.Module):
     n = left_img.shape[0]
     if self.training and (not hip_ops.trunk_enabled()):
       return self._run(left_img, 1), self._run(right_img, 1)
-    both = self._run(hip_ops.adjacent_or_cat(left_img, right_img), 2 if self.training else 1)
+    if self.training:
+      return self._run(hip_ops.adjacent_or_cat(left_img, right_img), 2)       # two outputs
+    both = self._run(hip_ops.adjacent_or_cat(left_img, right_img), 1)
     return both[:n], both[n:]
 
   def _run(self, rgb_img, groups):

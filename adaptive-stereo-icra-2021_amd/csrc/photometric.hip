@@ -315,11 +315,14 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const float* __restrict
     partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
 }
-__global__ void masked_sum_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out2) {
+__global__ void masked_sum_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out2, int with_mean) {
   double s = 0.0, c = 0.0;                       // one wave; lane-strided, then a shuffle tree: fixed order
   for (int i = threadIdx.x; i < nblk; i += 64) { s += partial[2 * i]; c += partial[2 * i + 1]; }
   s = wave_sum_d(s); c = wave_sum_d(c);
-  if (threadIdx.x == 0) { out2[0] = (float)s; out2[1] = (float)c; }
+  if (threadIdx.x == 0) {
+    out2[0] = (float)s; out2[1] = (float)c;
+    if (with_mean) { out2[2] = (float)s / (float)c; out2[3] = (float)c; }     // fp32 sum / fp32 count, as the caller's division was
+  }
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------
@@ -471,7 +474,14 @@ extern "C" int as_eval_metrics(const float* pred, const float* gt, int64_t n, fl
 #define MS_BLOCKS 512
 extern "C" int64_t as_masked_sum_workspace(int64_t n) { return n > 0 ? 4 * MS_BLOCKS : -1; }
 
+static int masked_sum_impl(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream, int with_mean);
 extern "C" int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream) {
+  return masked_sum_impl(v, mask, n, out2, workspace, stream, 0);
+}
+extern "C" int as_masked_sum_mean(const float* v, const uint8_t* mask, int64_t n, float* out4, float* workspace, void* stream) {
+  return masked_sum_impl(v, mask, n, out4, workspace, stream, 1);
+}
+static int masked_sum_impl(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream, int with_mean) {
   AS_CHECK_ARG(v && mask && out2 && workspace && n > 0, "as_masked_sum: bad argument");
   AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_masked_sum: workspace must be 8-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -480,7 +490,7 @@ extern "C" int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, flo
   double* partial = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(masked_sum_kernel, dim3((int)nb), dim3(256), 0, st, v, mask, (long)n, partial);
   AS_CHECK_LAUNCH("as_masked_sum");
-  hipLaunchKernelGGL(masked_sum_finalize_kernel, dim3(1), dim3(64), 0, st, partial, (int)nb, out2);
+  hipLaunchKernelGGL(masked_sum_finalize_kernel, dim3(1), dim3(64), 0, st, partial, (int)nb, out2, with_mean);
   AS_CHECK_LAUNCH("as_masked_sum(finalize)");
   return AS_OK;
 }

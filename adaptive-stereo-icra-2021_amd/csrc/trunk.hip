@@ -605,6 +605,38 @@ __global__ __launch_bounds__(256) void trunk_finish_fwd_kernel(TrunkFinishArgs p
   }
 }
 
+// Start of the backward pass: the gradient(s) of the features, NCHW as autograd hands them over — one tensor, or the left
+// and the right images' separately (the two outputs of a pair pass) — into the interior of one PCL buffer.
+struct TrunkBeginArgs {
+  const float* ga;           // NCHW [nA][32][H][W]
+  const float* gb;           // NCHW [B - nA][32][H][W] or null
+  int nA;
+  float* out;                // PCL, geometry g (batch B)
+  PclDev g;
+};
+
+__global__ __launch_bounds__(256) void trunk_begin_bwd_kernel(TrunkBeginArgs p) {
+  __shared__ float tile[32][33];
+  const PclDev g = p.g;
+  const int segs = (g.W + 31) / 32;
+  const int row = blockIdx.x / segs, seg = blockIdx.x - row * segs;
+  const int b = row / g.H, y = row - b * g.H, x0 = seg * 32;
+  const float* src = b < p.nA ? p.ga + (long)b * 32 * g.H * g.W : p.gb + (long)(b - p.nA) * 32 * g.H * g.W;
+  const int u = threadIdx.x & 31, c0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = c0 + 8 * k, x = x0 + u;
+    tile[u][cc] = x < g.W ? src[((long)cc * g.H + y) * g.W + x] : 0.f;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 31, v0 = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int uu = v0 + 8 * k, x = x0 + uu;
+    if (x < g.W) p.out[g.vox(b, 0, y, x) * 32 + c] = tile[uu][c];
+  }
+}
+
 // End of the backward pass: the per-group BatchNorm parameter gradients of every layer into their destinations, groups in
 // call order.
 struct TrunkBnGradArgs {
@@ -709,6 +741,16 @@ extern "C" int as_trunk_finish_fwd(const float* feats_pcl, const as_pcl* g, floa
   const int blocks = g->B * g->H * ((g->W + 31) / 32) + (nlayers > 0 ? 1 : 0);
   hipLaunchKernelGGL(trunk_finish_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   AS_CHECK_LAUNCH("as_trunk_finish_fwd");
+  return AS_OK;
+}
+
+extern "C" int as_trunk_begin_bwd(const float* g_a, const float* g_b, int nA, const as_pcl* g, float* out_pcl, void* stream) {
+  AS_CHECK_ARG(as_pcl_ok(g) && g->D == 1 && g->pd == 0, "as_trunk_begin_bwd: needs a 2-D PCL geometry");
+  AS_CHECK_ARG(g_a && out_pcl && nA >= 1 && nA <= g->B && (nA == g->B || g_b != nullptr), "as_trunk_begin_bwd: bad argument");
+  TrunkBeginArgs a;
+  a.ga = g_a; a.gb = g_b; a.nA = nA; a.out = out_pcl; a.g = as_make_dev(g);
+  hipLaunchKernelGGL(trunk_begin_bwd_kernel, dim3(g->B * g->H * ((g->W + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
+  AS_CHECK_LAUNCH("as_trunk_begin_bwd");
   return AS_OK;
 }
 

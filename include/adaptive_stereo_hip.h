@@ -236,6 +236,9 @@ int as_trunk_fwd(const float* src, const float* skip, const as_trunk_bn* bn_prev
                  float* stat_cnt, void* stream);
 int as_trunk_finish_fwd(const float* feats_pcl, const as_pcl* g, float* feats_nchw, const float* states, int nlayers,
                         int ngroups, float* const* running_mean, float* const* running_var, float momentum, void* stream);
+ /* as_trunk_begin_bwd: the features' gradient(s), NCHW — one tensor [B,32,H,W] (g_b NULL, nA = B) or the left and right
+ * halves of a pair pass separately ([nA,...] and [B-nA,...]) — into the interior of one PCL buffer of geometry g. */
+int as_trunk_begin_bwd(const float* g_a, const float* g_b, int nA, const as_pcl* g, float* out_pcl, void* stream);
 int64_t as_trunk_bwd_workspace(const as_pcl* g, int ngroups);
 int as_trunk_bwd(const float* g_a, const float* z, const float* state, const double* sums, int nparts, const float* gamma,
                  float* bn_grads, const float* x, const float* packed_wt, float* g_x, const float* z_next,
@@ -461,6 +464,9 @@ int as_monodepth_loss_bwd_masked(const uint8_t* mask, const float* g_sum, const 
  * on device.  workspace: as_masked_sum_workspace(n) floats. */
 int64_t as_masked_sum_workspace(int64_t n);
 int as_masked_sum(const float* v, const uint8_t* mask, int64_t n, float* out2, float* workspace, void* stream);
+/* The same with out4 = [sum, count, sum / count, count]: the mean and a second copy of the count come out of the finalize
+ * launch instead of two element-wise launches of the caller. */
+int as_masked_sum_mean(const float* v, const uint8_t* mask, int64_t n, float* out4, float* workspace, void* stream);
 
 /* ---- a13: khamis_robust_loss — utils/loss_functions.py:6-15 (ER modes, adapt.py:339-349) -------
  * out2[0] = sum_{gt>0}(sqrt((gt-pred)^2+4)/2 - 1) / max(count(gt>0),1), out2[1] = max(count,1).

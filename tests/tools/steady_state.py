@@ -18,5 +18,6 @@ if len(sys.argv) > 3:
 print("steady-state window = the %d timed adaptation steps" % steps)
 print("window wall %.2f ms; kernel busy %.2f ms (%.0f%%); %.0f kernels per step; %.2f ms per step" % (
     (t1 - t0) / 1e6, tot / 1e6, 100 * tot / (t1 - t0), len(win) / steps, (t1 - t0) / 1e6 / steps))
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+import os
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:(1000 if os.environ.get('SS_ALL') else 45)]:
   print("%6.2f%% %8.1f us/step  x%-4d avg %7.1fus  %s" % (100 * v[0] / tot, v[0] / steps / 1e3, v[1] // steps, v[0] / v[1] / 1e3, k[:100]))
