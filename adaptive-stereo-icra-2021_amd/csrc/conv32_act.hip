@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
     // cannot see asm stores and would turn a wait for an older load into a wait for them (vmcnt retires in order)
     f32x4 pz[5], pa[5];
     const unsigned t16 = (unsigned)t * 16u;
-    auto fetch_row = [&](int jj) {                         // rows outside the image: any valid row (converted to zeros)
+    auto fetch_into = [&](int jj, f32x4 (&pz)[5], f32x4 (&pa)[5]) {     // rows outside the image: any valid row (-> zeros)
       const int y = min(max(r0 + jj * d, 0), H - 1);
       const long off = ((img + y + p.g.ph) * Wp + px0) * 32;
 #pragma unroll
@@ -135,11 +135,12 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
         if (SKIP) ca_load4(pa[k], p.ain + off + k * 1024, t16);
       }
     };
+    auto fetch_row = [&](int jj) { fetch_into(jj, pz, pa); };
     auto wait_row = [&]() {
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
       if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
     };
-    auto convert_row = [&](int jj) {                       // -> ring slot (jj + 1) % 3, swizzled; by-product for own rows
+    auto convert_from = [&](int jj, f32x4 (&pz)[5], f32x4 (&pa)[5]) {   // -> ring slot (jj + 1) % 3, swizzled; by-product for own rows
       const int y = r0 + jj * d;
       char* dst = smem + ((jj + 1) % 3) * CA_ROW_BYTES + cv_swz;
       if (y < 0 || y >= H) {                               // (workgroup-uniform)
@@ -169,11 +170,36 @@ __global__ __launch_bounds__(256, 2) void conv32_act_kernel(ActArgs p) {
         if (own && mine) ca_store4(aout + k * 1024, t16, yv);
       }
     };
+    auto convert_row = [&](int jj) { convert_from(jj, pz, pa); };
 
-    // ---- run-in: activated rows j0-1, j0, j0+1 ----
+#ifdef CA_RUNIN_SERIAL
+    // (A/B builds only, EXTRA=-DCA_RUNIN_SERIAL: round 2's run-in — three dependent fetch -> wait -> convert rounds)
     fetch_row(j0 - 1); wait_row(); convert_row(j0 - 1);
     fetch_row(j0); wait_row(); convert_row(j0);
     fetch_row(j0 + 1); wait_row(); convert_row(j0 + 1);
+#else
+    // ---- run-in: activated rows j0-1, j0, j0+1 ----  two rows in flight at a time (two register sets: the accumulator and
+    // the operand ring of the tile loop are not live yet; three sets spilled), retired by counted waits — vector-memory
+    // instructions retire in order — two exposed round trips per piece instead of three
+    {
+      f32x4 qz[5], qa[5];
+      fetch_into(j0 - 1, pz, pa); fetch_into(j0, qz, qa);
+      if (SKIP) asm volatile("s_waitcnt vmcnt(10)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+      convert_from(j0 - 1, pz, pa);                        // never one of the piece's own rows: no by-product stores
+      fetch_into(j0 + 1, pz, pa);
+      if (SKIP) asm volatile("s_waitcnt vmcnt(10)" : "+v"(qz[0]), "+v"(qz[1]), "+v"(qz[2]), "+v"(qz[3]), "+v"(qz[4]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" : "+v"(qz[0]), "+v"(qz[1]), "+v"(qz[2]), "+v"(qz[3]), "+v"(qz[4]) :: "memory");
+      if (SKIP) asm volatile("" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(qa[4]) :: "memory");
+      convert_from(j0, qz, qa);
+      // row j0 is always an own row: exactly four by-product stores per wave (k = 1..3 everybody, k = 0 waves 1-3, k = 4
+      // wave 0) queue up behind row j0+1's loads — that row is home when at most those four are outstanding
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+      convert_from(j0 + 1, pz, pa);
+    }
+#endif
     __syncthreads();
 
     for (int j = j0; j < j1; ++j) {
