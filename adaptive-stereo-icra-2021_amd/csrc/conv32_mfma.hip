@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
 #define CONV32_SPLITK_MAX_M 32768
 #endif
 static inline bool conv32_splitk_applies(int ntaps, long M) {
-  return ntaps == 9 && M <= CONV32_SPLITK_MAX_M;
+  // 25 taps (the strided head's 5x5 convolutions, round 3): a one-wave chain is 400 dependent MFMAs = 12 us; on the two
+  // smallest levels (<= 16 K output voxels: fewer wave tiles than the chip has SIMDs) the split chain of 112 wins
+  return (ntaps == 9 && M <= CONV32_SPLITK_MAX_M) || (ntaps == 25 && M <= CONV32_SPLITK_MAX_M / 2);
 }
 
 template <int NT>
@@ -569,7 +571,8 @@ static int launch_conv32(const ConvArgs& args, hipStream_t st, const char* who) 
   }
   const dim3 grid(as_div_up(a.M, 128)), block(256);
   if (conv32_splitk_applies(a.ntaps, a.M)) {
-    hipLaunchKernelGGL(conv32_fwd_splitk_kernel<9>, dim3(as_div_up(a.M, 32)), block, 0, st, a);
+    if (a.ntaps == 9) hipLaunchKernelGGL(conv32_fwd_splitk_kernel<9>, dim3(as_div_up(a.M, 32)), block, 0, st, a);
+    else hipLaunchKernelGGL(conv32_fwd_splitk_kernel<25>, dim3(as_div_up(a.M, 32)), block, 0, st, a);
     return AS_OK;
   }
   switch (a.ntaps) {
