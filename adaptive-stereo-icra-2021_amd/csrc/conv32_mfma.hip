@@ -77,12 +77,10 @@ __device__ inline void mfma16(f32x16& acc, const f32x4 (&a)[4], const f32x4 (&b)
 #define AS_CONV32_PREFETCH 1
 #endif
 template <int NT>
-__global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
-  __shared__ float red[4][32];
-  __shared__ float bmean[32];
+__device__ __forceinline__ void conv32_fwd_body(const ConvArgs& p, const int block, float (*red)[32], float* bmean) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, li = lane & 31;
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = block * 4 + wave;
   const int v = tile * 32 + li;
   const bool valid = v < p.M;
   int in_vox, out_vox;
@@ -123,8 +121,33 @@ __global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   TileStats ts;
-  conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.M - (int)blockIdx.x * 128), red, bmean, &ts);
-  stats_write(p.ep, blockIdx.x, ts);
+  conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.M - block * 128), red, bmean, &ts);
+  stats_write(p.ep, block, ts);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv32_fwd_kernel(ConvArgs p) {
+  __shared__ float red[4][32];
+  __shared__ float bmean[32];
+  conv32_fwd_body<NT>(p, (int)blockIdx.x, red, bmean);
+}
+
+// The four parity phases of a stride-2 5x5 data gradient (9 / 6 / 6 / 4 taps, see as_conv32_dgrad_s2) in ONE launch: a
+// workgroup finds its phase from its block index and runs that phase's fully unrolled body.  Four launches per layer were
+// 12 launches per step on the three small levels of the feature head, each a few hundred workgroups at most.
+struct DgradS2Args { ConvArgs ph[4]; int nblk[4]; };
+
+__global__ __launch_bounds__(256) void conv32_dgrad_s2_kernel(DgradS2Args p) {
+  __shared__ float red[4][32];
+  __shared__ float bmean[32];
+  int b = (int)blockIdx.x;
+  if (b < p.nblk[0]) { conv32_fwd_body<9>(p.ph[0], b, red, bmean); return; }
+  b -= p.nblk[0];
+  if (b < p.nblk[1]) { conv32_fwd_body<6>(p.ph[1], b, red, bmean); return; }
+  b -= p.nblk[1];
+  if (b < p.nblk[2]) { conv32_fwd_body<6>(p.ph[2], b, red, bmean); return; }
+  b -= p.nblk[2];
+  conv32_fwd_body<4>(p.ph[3], b, red, bmean);
 }
 
 // Split-K flavour for small maps.  On a 24x78 map (1/16 resolution: 59 workgroups of 128 voxels at 4 pairs, 15 at one) the
@@ -559,13 +582,22 @@ static int check_conv(const as_pcl* gin, const as_pcl* gout, const as_conv_shape
 
 __device__ float g_zero_bias[32];          // zero-initialised: the bias of a convolution that has none
 
+// 32 zeros in device memory (the convolution bodies read their bias unconditionally), per HIP device
+static const float* zero_bias_ptr(void) {
+  static const float* zeros[32] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return nullptr;
+  if (zeros[d] == nullptr) {
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_zero_bias)) == hipSuccess) zeros[d] = static_cast<const float*>(sym);
+  }
+  return zeros[d];
+}
+
 static int launch_conv32(const ConvArgs& args, hipStream_t st, const char* who) {
   ConvArgs a = args;
   if (a.ep.bias == nullptr) {
-    static const float* zeros = [] {
-      void* sym = nullptr;
-      return hipGetSymbolAddress(&sym, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? static_cast<const float*>(sym) : nullptr;
-    }();
+    const float* zeros = zero_bias_ptr();
     if (zeros == nullptr) { as_set_error("%s: no address for the zero bias", who); return AS_ERR_LAUNCH; }
     a.ep.bias = zeros;
   }
@@ -623,10 +655,12 @@ extern "C" int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const floa
         for (int l = px; l < 5; l += 2) all.idx[all.n++] = j * 5 + l;
   hipLaunchKernelGGL(pack_weights_subset_kernel, dim3(as_div_up(all.n * 1024, 256)), dim3(256), 0, st, w, wp, 25, all);
   AS_CHECK_LAUNCH("as_conv32_dgrad_s2(pack)");
+  DgradS2Args args;
+  int total = 0, ph = 0;
   for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
+    for (int px = 0; px < 2; ++px, ++ph) {
       const int Hl = (ggx->H - py + 1) / 2, Wl = (ggx->W - px + 1) / 2;
-      ConvArgs a;
+      ConvArgs& a = args.ph[ph];
       int n = 0;
       for (int j = py; j < 5; j += 2)
         for (int l = px; l < 5; l += 2) {
@@ -634,18 +668,23 @@ extern "C" int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const floa
           a.tap_off[n] = ((py + 2 - j) / 2) * Wp + (px + 2 - l) / 2;
           ++n;
         }
-      if (Hl > 0 && Wl > 0) {
-        a.x = gz; a.wp = wp;
-        a.ep.bias = nullptr; a.ep.z = gx; a.ep.ep_scale = nullptr; a.ep.ep_shift = nullptr; a.ep.residual = nullptr;
-        a.ep.stat_mean = nullptr; a.ep.stat_m2 = nullptr; a.ep.stat_cnt = nullptr; a.ep.epilogue = 0; a.ep.slope = 0.f;
-        a.gin = as_make_dev(ggz); a.gout = as_make_dev(ggx);
-        a.map.Hl = Hl; a.map.Wl = Wl; a.map.in_stride = 1; a.map.out_stride = 2; a.map.out_oy = py; a.map.out_ox = px;
-        a.M = ggx->B * Hl * Wl; a.ntaps = n;
-        if (int e = launch_conv32(a, st, "as_conv32_dgrad_s2")) return e;
-        AS_CHECK_LAUNCH("as_conv32_dgrad_s2");
-      }
+      a.x = gz; a.wp = wp;
+      a.ep.bias = nullptr; a.ep.z = gx; a.ep.ep_scale = nullptr; a.ep.ep_shift = nullptr; a.ep.residual = nullptr;
+      a.ep.stat_mean = nullptr; a.ep.stat_m2 = nullptr; a.ep.stat_cnt = nullptr; a.ep.epilogue = 0; a.ep.slope = 0.f;
+      a.gin = as_make_dev(ggz); a.gout = as_make_dev(ggx);
+      a.map.Hl = Hl > 0 ? Hl : 1; a.map.Wl = Wl > 0 ? Wl : 1; a.map.in_stride = 1; a.map.out_stride = 2; a.map.out_oy = py; a.map.out_ox = px;
+      a.M = (Hl > 0 && Wl > 0) ? ggx->B * Hl * Wl : 0; a.ntaps = n;
+      args.nblk[ph] = as_div_up(a.M, 128);
+      total += args.nblk[ph];
       wp += n * 1024;
     }
+  const float* zero_bias = zero_bias_ptr();                // (the bias of conv32_fwd_body is read unconditionally)
+  if (zero_bias == nullptr) { as_set_error("as_conv32_dgrad_s2: no address for the zero bias"); return AS_ERR_LAUNCH; }
+  for (int i = 0; i < 4; ++i) args.ph[i].ep.bias = zero_bias;
+  as_prof_mark(AS_PROF_CONV32, st, 1, 0.0);
+  if (total > 0) hipLaunchKernelGGL(conv32_dgrad_s2_kernel, dim3(total), dim3(256), 0, st, args);
+  as_prof_mark(AS_PROF_CONV32, st, 0, 2.0 * (double)ggx->B * ggz->H * ggz->W * 1024.0 * 25.0);
+  AS_CHECK_LAUNCH("as_conv32_dgrad_s2");
   return AS_OK;
 }
 
