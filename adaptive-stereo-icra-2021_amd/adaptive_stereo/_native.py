@@ -147,7 +147,7 @@ _SIGNATURES = {
   "as_warp_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
   "as_warp_bwd_add": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
   "as_monodepth_loss_bwd_masked": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp,
-                                           c_vp]),
+                                           c_vp, c_vp]),
   "as_monodepth_workspace": (c_i64, [c_int, c_int, c_int]),
   "as_monodepth_loss_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
                                     c_vp]),
@@ -165,6 +165,7 @@ _SIGNATURES = {
   "as_mirror_taps_ch0": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp]),
   "as_sumsq_workspace": (c_i64, [c_i64]),
   "as_clip_coef": (c_int, [c_vp, c_float, c_vp, c_vp]),
+  "as_sumsq_clip": (c_int, [c_vp, c_i64, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_float, c_float, c_float, c_float, c_int, c_vp,
                            c_vp]),

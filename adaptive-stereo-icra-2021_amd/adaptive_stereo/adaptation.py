@@ -93,13 +93,18 @@ class FusedClipAdam(object):
   def step(self, clip=True):
     a = self.arena
     self.step_count += 1
-    self.step_dev += 1.0
+    # the device-side step counter must move before the first Adam launch reads it: it rides on the clip's finalize launch
+    # when the clipped group is the first one (the reference's: stereo_net), else it is an add of its own
+    ride = bool(clip) and self.clip_group == 0
+    if not ride:
+      self.step_dev += 1.0
     for gi, (s, e) in enumerate(a.group_bounds):
       scale = None
       if clip and gi == self.clip_group:
-        nat.call("as_sumsq", nat.ptr(a.grads[s:e]), e - s, nat.ptr(self.sumsq), nat.ptr(self.ws), nat.stream())
-        # torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
-        nat.call("as_clip_coef", nat.ptr(self.sumsq), float(self.max_norm), nat.ptr(self.coef), nat.stream())
+        # torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1 — sum of squares, coefficient and
+        # the step counter in two launches
+        nat.call("as_sumsq_clip", nat.ptr(a.grads[s:e]), e - s, float(self.max_norm), nat.ptr(self.sumsq), nat.ptr(self.coef),
+                 nat.ptr(self.step_dev) if (ride and gi == 0) else None, nat.ptr(self.ws), nat.stream())
         scale = self.coef
       nat.call("as_adam_step", nat.ptr(a.params[s:e]), nat.ptr(a.grads[s:e]), nat.ptr(self.exp_avg[s:e]),
                nat.ptr(self.exp_avg_sq[s:e]), e - s, nat.ptr(scale), self.lr, self.betas[0], self.betas[1],

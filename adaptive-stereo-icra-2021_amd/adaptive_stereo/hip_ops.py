@@ -1581,6 +1581,7 @@ class MaskedPhotometricFn(torch.autograd.Function):
     call("as_masked_sum_mean", ptr(total), ptr(mask), total.numel(), ptr(out3), ptr(ws2), stream())
     ctx.save_for_backward(pred, left, right, warped, mask, out3)
     ctx.sw = float(smoothness_weight)
+    ctx.fwd_ws = ws                          # the forward workspace: its per-image mean disparity is reused by backward
     count = out3[3]
     ctx.mark_non_differentiable(count, warped, mask)
     ctx.set_materialize_grads(False)
@@ -1600,7 +1601,8 @@ class MaskedPhotometricFn(torch.autograd.Function):
     g_direct, g_warped = torch.empty_like(pred), torch.empty_like(warped)
     ws = _empty(nat.load().as_monodepth_workspace(B, H, W), dev)
     call("as_monodepth_loss_bwd_masked", ptr(mask), ptr(g_sum), ptr(g_mean), ptr(out3), ptr(pred), ptr(left), ptr(warped), B, H, W,
-         ctx.sw, ptr(g_direct), ptr(g_warped), ptr(ws), stream())
+         ctx.sw, ptr(g_direct), ptr(g_warped), ptr(ws), ptr(ctx.fwd_ws), stream())
+    ctx.fwd_ws = None
     g_pred = torch.empty_like(pred)
     call("as_warp_bwd_add", ptr(g_warped), ptr(right), ptr(pred), ptr(g_direct), B, C, H, W, 1, ptr(g_pred), stream())
     return g_pred, None, None, None

@@ -86,11 +86,18 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void sumsq_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out) {
+// (optionally also the clip coefficient of torch.nn.utils.clip_grad_norm_ and the optimizer's device-side step counter: three
+// one-thread jobs in the launch that exists anyway)
+__global__ void sumsq_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out, float max_norm,
+                                      float* __restrict__ coef, float* __restrict__ step_counter) {
   double s = 0.0;                                // one wave; lane-strided, then a shuffle tree: fixed order
   for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) out[0] = (float)s;
+  if (threadIdx.x == 0) {
+    out[0] = (float)s;
+    if (coef) coef[0] = fminf(max_norm / (sqrtf((float)s) + 1e-6f), 1.0f);      // as clip_coef_kernel, from the stored fp32 value
+    if (step_counter) step_counter[0] += 1.0f;
+  }
 }
 
 // torch.nn.utils.clip_grad_norm_: coef = min(max_norm / (sqrt(sumsq) + 1e-6), 1), in fp32 like ATen
@@ -156,8 +163,24 @@ extern "C" int as_sumsq(const float* g, int64_t n, float* out, float* workspace,
   double* partial = reinterpret_cast<double*>(workspace);
   hipLaunchKernelGGL(sumsq_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, partial);
   AS_CHECK_LAUNCH("as_sumsq");
-  hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)nb, out);
+  hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)nb, out, 0.f,
+                     (float*)nullptr, (float*)nullptr);
   AS_CHECK_LAUNCH("as_sumsq(finalize)");
+  return AS_OK;
+}
+
+extern "C" int as_sumsq_clip(const float* g, int64_t n, float max_norm, float* out, float* coef, float* step_counter,
+                             float* workspace, void* stream) {
+  AS_CHECK_ARG(g && out && coef && workspace && n > 0 && max_norm > 0.f, "as_sumsq_clip: bad argument");
+  AS_CHECK_ARG(((uintptr_t)workspace & 7) == 0, "as_sumsq_clip: workspace must be 8-byte aligned");
+  long nb = (n + 255) / 256;
+  if (nb > SS_BLOCKS) nb = SS_BLOCKS;
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, partial);
+  AS_CHECK_LAUNCH("as_sumsq_clip");
+  hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)nb, out, max_norm, coef,
+                     step_counter);
+  AS_CHECK_LAUNCH("as_sumsq_clip(finalize)");
   return AS_OK;
 }
 

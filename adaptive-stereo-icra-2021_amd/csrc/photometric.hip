@@ -371,7 +371,8 @@ extern "C" int as_monodepth_loss_fwd(const float* pred, const float* img, const 
 
 static int monodepth_bwd(GtSrc g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
                          const float* pred, const float* img, const float* warped, int B, int H, int W,
-                         float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream);
+                         float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream,
+                         const float* mean_fwd = nullptr);
 
 extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
                                      const float* pred, const float* img, const float* warped, int B, int H, int W,
@@ -385,17 +386,20 @@ extern "C" int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, co
 extern "C" int as_monodepth_loss_bwd_masked(const uint8_t* mask, const float* g_sum, const float* g_mean,
                                             const float* sum_count, const float* pred, const float* img, const float* warped,
                                             int B, int H, int W, float smoothness_weight, float* g_pred, float* g_warped,
-                                            float* workspace, void* stream) {
+                                            float* workspace, const float* fwd_workspace, void* stream) {
   AS_CHECK_ARG(mask && (g_sum || g_mean) && (g_mean == nullptr || sum_count != nullptr),
                "as_monodepth_loss_bwd_masked: mask, at least one of g_sum / g_mean, and sum_count with g_mean");
   GtSrc src = {nullptr, mask, g_sum, g_mean, sum_count};
+  // fwd_workspace (may be NULL): the workspace as_monodepth_loss_fwd ran with on the SAME pred — its per-image mean disparity
+  // (the first B floats) is reused instead of being summed again (two launches)
   return monodepth_bwd(src, nullptr, nullptr, nullptr, pred, img, warped, B, H, W, smoothness_weight, g_pred, g_warped, workspace,
-                       stream);
+                       stream, fwd_workspace);
 }
 
 static int monodepth_bwd(GtSrc g_total, const float* g_l1, const float* g_ssim, const float* g_smooth,
                          const float* pred, const float* img, const float* warped, int B, int H, int W,
-                         float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream) {
+                         float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream,
+                         const float* mean_fwd) {
   AS_CHECK_ARG(pred && img && warped && workspace && B > 0 && H > 1 && W > 1 && B <= 65535 && (long)H * W < (1L << 31),
                "as_monodepth_loss_bwd: bad argument");
   AS_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "as_monodepth_loss_bwd: workspace must be 16-byte aligned");
@@ -403,7 +407,8 @@ static int monodepth_bwd(GtSrc g_total, const float* g_l1, const float* g_ssim, 
   PhWs w = carve(workspace, B);
   const long plane = (long)H * W;
   as_prof_mark(AS_PROF_LOSS_BWD, st, 1, 0.0);
-  if (int e = image_mean(pred, B, plane, w, st)) return e;
+  if (mean_fwd != nullptr) w.mean = const_cast<float*>(mean_fwd);      // read-only from here on
+  else if (int e = image_mean(pred, B, plane, w, st)) return e;
   hipLaunchKernelGGL(monodepth_bwd_a_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, g_total, g_ssim, g_smooth,
                      pred, img, warped, w.mean, B, H, W, smoothness_weight, w.coef, w.partial);
   AS_CHECK_LAUNCH("as_monodepth_loss_bwd(A)");

@@ -454,10 +454,12 @@ int as_monodepth_loss_bwd(const float* g_total, const float* g_l1, const float* 
                           float* workspace, void* stream);
 /* Backward of loss = total[mask].mean() / total[mask].sum() (adapt.py:81-83) without a dense gradient map: every valid pixel
  * of `total` carries g_sum[0] + g_mean[0] / sum_count[1] (either pointer may be NULL; sum_count = as_masked_sum's out2 of the
- * forward pass), every other pixel 0; the l1 / ssim / smooth maps carry no gradient. */
+ * forward pass), every other pixel 0; the l1 / ssim / smooth maps carry no gradient.  fwd_workspace (may be NULL): the workspace
+ * as_monodepth_loss_fwd ran with on the same pred — its per-image mean disparity is reused instead of being summed again. */
 int as_monodepth_loss_bwd_masked(const uint8_t* mask, const float* g_sum, const float* g_mean, const float* sum_count,
                                  const float* pred, const float* img, const float* warped, int B, int H, int W,
-                                 float smoothness_weight, float* g_pred, float* g_warped, float* workspace, void* stream);
+                                 float smoothness_weight, float* g_pred, float* g_warped, float* workspace,
+                                 const float* fwd_workspace, void* stream);
 
 /* ---- loss[mask].mean() without a host sync — adapt.py:81-83 --------------------
  * out[0] = sum(v*m), out[1] = count(m); value = out[0]/out[1] is formed by the caller
@@ -500,6 +502,10 @@ int as_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stre
 int as_relu_bwd(const float* g_out, const float* out, int64_t n, float* g_in, void* stream);
 int as_mirror_taps_ch0(const float* w, int Cin, float* by_tap, float* by_channel, void* stream);
 int as_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
+/* as_sumsq + as_clip_coef in the launches as_sumsq has anyway; step_counter (may be NULL) += 1: the optimizer's device-side
+ * step count, read by as_adam_step under hipGraph replay. */
+int as_sumsq_clip(const float* g, int64_t n, float max_norm, float* out, float* coef, float* step_counter,
+                  float* workspace, void* stream);
 int as_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                  const float* grad_scale_dev, float lr, float beta1, float beta2, float eps,
                  int step, const float* step_dev, void* stream);
