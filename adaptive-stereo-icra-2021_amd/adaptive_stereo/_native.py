@@ -68,6 +68,8 @@ _SIGNATURES = {
                             c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_conv32_dgrad_s2_workspace": (c_i64, []),
   "as_conv32_dgrad_s2": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), c_vp, c_vp]),
+  "as_conv32_dgrad_s2_pack": (c_int, [c_vp, c_vp, c_vp]),
+  "as_conv32_dgrad_s2_packed": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), c_vp]),
   "as_conv32_wgrad_workspace": (c_i64, [_P(Pcl), _P(Pcl), _P(ConvShape)]),
   "as_conv32_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_bn_finalize": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_float, c_float, c_vp, c_vp, c_vp,

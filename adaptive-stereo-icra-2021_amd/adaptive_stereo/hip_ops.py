@@ -243,12 +243,31 @@ def pack_weights(w, shape: ConvShape, transpose_flip: bool):
   w = f32c(w)
   plan = _ACTIVE_PLAN
   if plan is not None:
-    hit = plan.packed(w, shape, transpose_flip)
+    hit = plan.packed(w, shape.taps(), int(bool(transpose_flip)), shape.taps() * 1024)
     if hit is not None:
       return hit
   packed = _empty(shape.taps() * 1024, w.device)
   call("as_conv32_pack_weights", ptr(w), ptr(packed), shape, int(transpose_flip), stream())
   return packed
+
+
+# kinds of include/adaptive_stereo_hip.h (as_pack_job.transpose_flip)
+PACK_S2_DGRAD, PACK_CONV4, PACK_MIRROR_TAP, PACK_MIRROR_CH = 2, 16, 32, 33
+
+
+def pack_special(w, kind, taps, size, direct):
+  """A weight-derived buffer other than the standard packing (the strided data gradient's phase-major taps, the 4-channel
+  layers' packing, the mirrored channel-0 taps): from the StepPlan's one batch launch when a plan is active, else through
+  ``direct(out)`` (the stand-alone entry point)."""
+  w = f32c(w)
+  plan = _ACTIVE_PLAN
+  if plan is not None:
+    hit = plan.packed(w, taps, kind, size)
+    if hit is not None:
+      return hit
+  out = _empty(size, w.device)
+  direct(w, out)
+  return out
 
 
 class StepPlan(object):
@@ -264,7 +283,7 @@ class StepPlan(object):
   def __init__(self, enabled=True):
     self.enabled = enabled     # False: begin()/end() do nothing (every call takes the ordinary path)
     self.ready = False
-    self._rec_pack = {}        # (data_ptr, taps, flip) -> (weight tensor, ConvShape)
+    self._rec_pack = {}        # (data_ptr, taps, kind) -> (weight tensor, floats of the packed buffer)
     self._rec_bn = {}          # id(bn module) -> [bn module, count]
     self._rec_affine = {}      # gamma.data_ptr() -> (gamma, beta, running_mean, running_var)   (eval-mode layers)
     self._affine_states = {}
@@ -275,10 +294,10 @@ class StepPlan(object):
     self._pending = None
 
   # -- weights ---------------------------------------------------------------------------------------
-  def packed(self, w, shape, flip):
-    key = (w.data_ptr(), shape.taps(), bool(flip))
+  def packed(self, w, taps, kind, size):
+    key = (w.data_ptr(), int(taps), int(kind))
     if not self.ready:
-      self._rec_pack[key] = (w, shape)
+      self._rec_pack[key] = (w, int(size))
       return None
     return self._views.get(key)
 
@@ -344,14 +363,14 @@ class StepPlan(object):
     import struct
     if self._rec_pack:
       dev = next(iter(self._rec_pack.values()))[0].device
-      total = sum(k[1] * 1024 for k in self._rec_pack)
+      total = sum((size + 3) // 4 * 4 for _, size in self._rec_pack.values())
       self._buf = torch.empty(total, dtype=torch.float32, device=dev)
       blob, off = b"", 0
-      for key, (w, shape) in self._rec_pack.items():
-        view = self._buf[off:off + key[1] * 1024]
+      for key, (w, size) in self._rec_pack.items():
+        view = self._buf[off:off + size]
         self._views[key] = view
         blob += struct.pack("<QQii", w.data_ptr(), view.data_ptr(), key[1], int(key[2]))
-        off += key[1] * 1024
+        off += (size + 3) // 4 * 4             # every packed buffer 16-byte aligned
       self._weights = [w for w, _ in self._rec_pack.values()]     # keep the storages alive
       self._jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
       self._njobs = len(self._rec_pack)
@@ -1025,8 +1044,8 @@ class FeatureExtractorFn(torch.autograd.Function):
       out = POOL.get(gi, dev)
       wd, bd = params[2 * i], params[2 * i + 1]
       if i == 0:
-        wp = _empty(25 * 128, dev)
-        call("as_conv4_pack_weights", ptr(wd), 3, ptr(wp), CONV5_S2, stream())
+        wp = pack_special(wd, PACK_CONV4 + 3, 25, 25 * 128,
+                          lambda w_, o_: call("as_conv4_pack_weights", ptr(w_), 3, ptr(o_), CONV5_S2, stream()))
         call("as_conv4_fwd", ptr(in4), g4, ptr(wp), ptr(bd), ptr(out), gi, CONV5_S2, 0, None, None, LEAKY_SLOPE,
              None, None, None, stream())
       else:
@@ -1165,8 +1184,9 @@ class FeatureExtractorFn(torch.autograd.Function):
         dW, db = conv32_wgrad(levels[i - 1], gprev, g_a, gi, CONV5_S2, True, _sink(sinks, 2 * i), _sink(sinks, 2 * i + 1))
         grads[2 * i], grads[2 * i + 1] = dW, db
         g_prev = POOL.get(gprev, dev)
-        ws = _empty(lib.as_conv32_dgrad_s2_workspace(), dev)
-        call("as_conv32_dgrad_s2", ptr(g_a), gi, ptr(wd), ptr(g_prev), gprev, ptr(ws), stream())
+        wps = pack_special(wd, PACK_S2_DGRAD, 25, 25 * 1024,
+                           lambda w_, o_: call("as_conv32_dgrad_s2_pack", ptr(w_), ptr(o_), stream()))
+        call("as_conv32_dgrad_s2_packed", ptr(g_a), gi, ptr(wps), ptr(g_prev), gprev, stream())
         POOL.put(g_a, gi)
         g_a = g_prev
     POOL.put(g_a, geoms[0])
@@ -1282,8 +1302,8 @@ class EdgeRefineFn(torch.autograd.Function):
     # conv2d_feature: 4 -> 32, BatchNorm, LeakyReLU
     w0, b0, gamma0, beta0 = params[0:4]
     rm0, rv0 = bn_buffers[0]
-    wp4 = _empty(9 * 128, dev)
-    call("as_conv4_pack_weights", ptr(w0), 4, ptr(wp4), s33, stream())
+    wp4 = pack_special(w0, PACK_CONV4 + 4, 9, 9 * 128,
+                       lambda w_, o_: call("as_conv4_pack_weights", ptr(w_), 4, ptr(o_), s33, stream()))
     if train:
       stats = StatParts(lib.as_conv4_stat_parts(g4, g, s33), dev)
       z0 = POOL.get(g, dev)
@@ -1410,8 +1430,8 @@ class EdgeRefineFn(torch.autograd.Function):
         # g_z0 itself is needed by nobody: only its 3x3 32->1 data gradient towards the disparity channel is.  The weight
         # gradient kernel writes the nine per-tap projections of g_z0 (36 B per pixel instead of 128) and a gather sums
         # the nine shifted planes — no g_z0 write, no 32-channel re-read
-        w_proj = _empty(288, dev)                                               # [9][32]: channel 0 of w0, taps mirrored
-        call("as_mirror_taps_ch0", ptr(w0), 4, ptr(w_proj), None, stream())
+        w_proj = pack_special(w0, PACK_MIRROR_TAP, 9, 288,                      # [9][32]: channel 0 of w0, taps mirrored
+                              lambda w_, o_: call("as_mirror_taps_ch0", ptr(w_), 4, ptr(o_), None, stream()))
         h_proj = _empty(B * 9 * H * W, dev)
         call("as_conv4_wgrad_bnapply_proj", ptr(ctx.in4), g4, ptr(g_a), ptr(ctx.z0), g, s33, 4, ptr(st0.scale), ptr(st0.shift),
              ptr(st0.mean), ptr(coef), LEAKY_SLOPE, ptr(w_proj), ptr(h_proj), ptr(sinks[0]), ptr(sinks[1]), 1, ptr(ws4),
@@ -1442,8 +1462,8 @@ class EdgeRefineFn(torch.autograd.Function):
       if h_proj is not None:
         call("as_tap_gather", ptr(h_proj), ptr(g_pre), ptr(g_up), B, H, W, stream())
       else:
-        w_ch0 = _empty(288, dev)                                                # [32][9]
-        call("as_mirror_taps_ch0", ptr(w0), 4, None, ptr(w_ch0), stream())
+        w_ch0 = pack_special(w0, PACK_MIRROR_CH, 9, 288,                        # [32][9]
+                             lambda w_, o_: call("as_mirror_taps_ch0", ptr(w_), 4, None, ptr(o_), stream()))
         call("as_conv32to1_fwd", ptr(g_z0), g, s33, ptr(w_ch0), None, ptr(g_pre), 0, ptr(g_up), stream())
       g_coarse = torch.empty(B, h, w, dtype=torch.float32, device=dev)
       call("as_upsample_bilinear_bwd", ptr(g_up), B, H, W, ptr(g_coarse), h, w, gain, stream())

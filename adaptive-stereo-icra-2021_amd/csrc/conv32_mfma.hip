@@ -637,8 +637,30 @@ __global__ void pack_weights_subset_kernel(const float* __restrict__ w, float* _
 
 extern "C" int64_t as_conv32_dgrad_s2_workspace(void) { return 25 * 1024; }
 
+extern "C" int as_conv32_dgrad_s2_pack(const float* w, float* packed, void* stream) {
+  AS_CHECK_ARG(w && packed, "as_conv32_dgrad_s2_pack: null pointer");
+  // all four parity phases' weights in one launch: the 25 taps in phase-major order (9 + 6 + 6 + 4)
+  TapSubset all; all.n = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px)
+      for (int j = py; j < 5; j += 2)
+        for (int l = px; l < 5; l += 2) all.idx[all.n++] = j * 5 + l;
+  hipLaunchKernelGGL(pack_weights_subset_kernel, dim3(as_div_up(all.n * 1024, 256)), dim3(256), 0, (hipStream_t)stream, w, packed, 25,
+                     all);
+  AS_CHECK_LAUNCH("as_conv32_dgrad_s2_pack");
+  return AS_OK;
+}
+
 extern "C" int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const float* w, float* gx, const as_pcl* ggx,
                                   float* workspace, void* stream) {
+  AS_CHECK_ARG(w && workspace, "as_conv32_dgrad_s2: null pointer");
+  if (int e = as_conv32_dgrad_s2_pack(w, workspace, stream)) return e;
+  return as_conv32_dgrad_s2_packed(gz, ggz, workspace, gx, ggx, stream);
+}
+
+extern "C" int as_conv32_dgrad_s2_packed(const float* gz, const as_pcl* ggz, const float* packed, float* gx, const as_pcl* ggx,
+                                         void* stream) {
+  const float* w = packed; float* workspace = const_cast<float*>(packed);
   AS_CHECK_ARG(as_pcl_ok(ggz) && as_pcl_ok(ggx) && gz && w && gx && workspace, "as_conv32_dgrad_s2: bad argument");
   AS_CHECK_ARG(ggz->D == 1 && ggx->D == 1 && ggz->B == ggx->B, "as_conv32_dgrad_s2: 2-D tensors of equal batch expected");
   AS_CHECK_ARG(ggz->H == (ggx->H - 1) / 2 + 1 && ggz->W == (ggx->W - 1) / 2 + 1,
@@ -646,15 +668,7 @@ extern "C" int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const floa
   AS_CHECK_ARG(ggz->ph >= 1 && ggz->pw >= 1, "as_conv32_dgrad_s2: gz needs a zero halo of 1");
   hipStream_t st = (hipStream_t)stream;
   const int Wp = ggz->W + 2 * ggz->pw;
-  float* wp = workspace;
-  // all four parity phases' weights in one launch: the 25 taps in phase-major order (9 + 6 + 6 + 4)
-  TapSubset all; all.n = 0;
-  for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px)
-      for (int j = py; j < 5; j += 2)
-        for (int l = px; l < 5; l += 2) all.idx[all.n++] = j * 5 + l;
-  hipLaunchKernelGGL(pack_weights_subset_kernel, dim3(as_div_up(all.n * 1024, 256)), dim3(256), 0, st, w, wp, 25, all);
-  AS_CHECK_LAUNCH("as_conv32_dgrad_s2(pack)");
+  const float* wp = workspace;
   DgradS2Args args;
   int total = 0, ph = 0;
   for (int py = 0; py < 2; ++py)
@@ -701,14 +715,44 @@ extern "C" int as_conv32_pack_weights(const float* w, float* packed, const as_co
 
 // All of a step's weight packings in ONE launch: the job table lives in device memory (the weights sit in a
 // flat arena and the packed buffers are persistent, so the table is built once).
+// transpose_flip doubles as the KIND of a job (round 3: every weight-derived buffer of a step comes out of this one launch):
+//   0 / 1                         as_conv32_pack_weights (forward / data-gradient orientation)
+//   AS_PACK_S2_DGRAD (2)          as_conv32_dgrad_s2_pack: 5x5 stride-2 data gradient, the 25 taps in parity-phase-major order
+//   AS_PACK_CONV4 + Cin (16 + c)  as_conv4_pack_weights for Cin input channels, taps = T
+//   AS_PACK_MIRROR_TAP / _CH      as_mirror_taps_ch0's by_tap / by_channel layouts of a [32][4][3][3] weight
+__device__ inline int s2_phase_major_tap(int t) {          // the t-th tap of the order (py, px, j, l) of as_conv32_dgrad_s2
+  int n = 0;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px)
+      for (int j = py; j < 5; j += 2)
+        for (int l = px; l < 5; l += 2) { if (n == t) return j * 5 + l; ++n; }
+  return 0;
+}
+
 __global__ void pack_weights_batch_kernel(const as_pack_job* __restrict__ jobs) {
   const as_pack_job job = jobs[blockIdx.y];
-  const int T = job.taps;
+  const int T = job.taps, kind = job.transpose_flip;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (kind >= AS_PACK_CONV4 && kind < AS_PACK_CONV4 + 8) {
+    const int Cin = kind - AS_PACK_CONV4;
+    if (idx >= T * 128) return;
+    const int co = idx & 31, h = (idx >> 5) & 1, j = (idx >> 6) & 1, t = idx >> 7;
+    const int c = 2 * j + h;
+    job.packed[idx] = c < Cin ? job.w[((long)co * Cin + c) * T + t] : 0.f;
+    return;
+  }
+  if (kind == AS_PACK_MIRROR_TAP || kind == AS_PACK_MIRROR_CH) {
+    if (idx >= 288) return;
+    const int c = idx / 9, t = idx - 9 * c;
+    const float v = job.w[((long)c * 4) * 9 + (8 - t)];
+    job.packed[kind == AS_PACK_MIRROR_TAP ? t * 32 + c : c * 9 + t] = v;
+    return;
+  }
   if (idx >= T * 1024) return;
   const int e = idx & 3, j = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, t = idx >> 10;
   const int k = 16 * h + 4 * q + e;
-  job.packed[idx] = job.transpose_flip ? job.w[((long)k * 32 + j) * T + (T - 1 - t)] : job.w[((long)j * 32 + k) * T + t];
+  if (kind == AS_PACK_S2_DGRAD) job.packed[idx] = job.w[((long)k * 32 + j) * T + s2_phase_major_tap(t)];
+  else job.packed[idx] = kind ? job.w[((long)k * 32 + j) * T + (T - 1 - t)] : job.w[((long)j * 32 + k) * T + t];
 }
 
 extern "C" int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, int max_taps, void* stream) {

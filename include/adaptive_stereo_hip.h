@@ -91,8 +91,12 @@ typedef struct as_pack_job {
   const float* w;
   float* packed;
   int32_t taps;
-  int32_t transpose_flip;
+  int32_t transpose_flip;   /* 0 / 1, or one of the AS_PACK_* kinds below: every weight-derived buffer of a step from ONE launch */
 } as_pack_job;
+#define AS_PACK_S2_DGRAD 2      /* as_conv32_dgrad_s2_pack (taps = 25) */
+#define AS_PACK_CONV4 16        /* + Cin: as_conv4_pack_weights for Cin input channels (packed: taps * 128 floats) */
+#define AS_PACK_MIRROR_TAP 32   /* as_mirror_taps_ch0's by_tap [9][32] of a [32][4][3][3] weight */
+#define AS_PACK_MIRROR_CH 33    /* ... its by_channel [32][9] */
 int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, int max_taps, void* stream);
 int as_conv32_num_blocks(const as_pcl* gout);
 int as_conv32_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
@@ -254,6 +258,12 @@ int as_trunk_finish_bwd(const float* bn_grads, int nlayers, int ngroups, float* 
 int64_t as_conv32_dgrad_s2_workspace(void);
 int as_conv32_dgrad_s2(const float* gz, const as_pcl* ggz, const float* w, float* gx, const as_pcl* ggx,
                        float* workspace, void* stream);
+/* The same in two halves: the phase-major packing of the weights (25 * 1024 floats; constant while the weights are) and the
+ * convolution on packed weights — a caller that packs once per step (or through as_conv32_pack_weights_batch, AS_PACK_S2_DGRAD)
+ * saves the packing launch of every call. */
+int as_conv32_dgrad_s2_pack(const float* w, float* packed, void* stream);
+int as_conv32_dgrad_s2_packed(const float* gz, const as_pcl* ggz, const float* packed, float* gx, const as_pcl* ggx,
+                              void* stream);
 int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
                     const as_conv_shape* s, float* dW, float* db, int accumulate, float* workspace, void* stream);
