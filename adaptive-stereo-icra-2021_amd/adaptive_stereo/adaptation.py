@@ -437,6 +437,16 @@ class OnlineAdapter(object):
     self.feature_net.train(was_f); self.stereo_net.train(was_s)
     return float(loss)
 
+  def close(self):
+    """Releases the library's own RCCL communicator (collective: every rank calls it, before the process group goes)."""
+    if self.comm is not None:
+      torch.cuda.synchronize()
+      self._graph = None                 # a captured graph holds nodes of this communicator
+      self.comm.destroy()
+      self.comm = None
+      if self.bn_sync is not None:
+        self.bn_sync.comm = None
+
   def _all_reduce_small(self, t):
     if self.comm is not None:
       self.comm.all_reduce(t)

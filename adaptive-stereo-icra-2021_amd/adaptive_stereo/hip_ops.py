@@ -185,6 +185,7 @@ def flush_deferred_reductions():
 _TAIL_BNSUMS = True        # conv2d_out's data gradient also sums for the last block's BatchNorm backward
 _HEAD_PROJ = True          # conv2d_feature backward: per-tap projections instead of g_z
 _FWD_ACT = True            # full-resolution training forward: previous BatchNorm + LeakyReLU applied on the way in
+_WINOGRAD = True           # ... and its 3x3 convolution by the minimal-filtering algorithm F(2x2, 3x3) (csrc/conv32_wino.hip)
 # (module switches, each with a setter: tests/test_gpu_end_to_end.py runs both routes and compares them; timing A/B of a
 # route is a tool's business — tests/tools/ab_switch.py — not the environment's)
 
@@ -204,6 +205,13 @@ def set_head_proj(enabled):
 def set_fwd_act(enabled):
   global _FWD_ACT
   prev, _FWD_ACT = _FWD_ACT, bool(enabled)
+  return prev
+
+
+def set_winograd(enabled):
+  """False: the full-resolution training forward keeps the direct form (as_conv32_act_fwd).  Returns the previous setting."""
+  global _WINOGRAD
+  prev, _WINOGRAD = _WINOGRAD, bool(enabled)
   return prev
 
 
@@ -252,7 +260,7 @@ def pack_weights(w, shape: ConvShape, transpose_flip: bool):
 
 
 # kinds of include/adaptive_stereo_hip.h (as_pack_job.transpose_flip)
-PACK_S2_DGRAD, PACK_CONV4, PACK_MIRROR_TAP, PACK_MIRROR_CH = 2, 16, 32, 33
+PACK_S2_DGRAD, PACK_CONV4, PACK_MIRROR_TAP, PACK_MIRROR_CH, PACK_WINO, PACK_WINO_T = 2, 16, 32, 33, 34, 35
 
 
 def pack_special(w, kind, taps, size, direct):
@@ -656,9 +664,18 @@ def block_forward_act(z_prev, a_prevprev, st_prev: BnState, g: Pcl, shape: ConvS
   previous layer (read z_prev, read a_prevprev, write a_prev) disappears."""
   dev = z_prev.device
   lib = nat.load()
+  a_prev, z = POOL.get(g, dev), POOL.get(g, dev)
+  if _WINOGRAD and lib.as_conv32_wino_ok(g, g, shape) == 1:
+    # F(2x2, 3x3): 4 matrix products per output pixel instead of 9; the transformed filters come out of the step's one
+    # packing launch like every other weight-derived buffer
+    ww = pack_special(w, PACK_WINO, 16, 16 * 1024,
+                      lambda w_, o_: call("as_conv32_wino_pack_weights", ptr(w_), ptr(o_), 0, stream()))
+    stats = StatParts(lib.as_conv32_wino_parts(), dev)
+    call("as_conv32_wino_fwd", ptr(z_prev), ptr(a_prevprev), ptr(st_prev.scale), ptr(st_prev.shift), ptr(a_prev), g, ptr(ww),
+         ptr(b), LEAKY_SLOPE, ptr(z), g, shape, ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stream())
+    return a_prev, z, bn_train_stats(stats, gamma, beta, rm, rv)
   wp = pack_weights(w, shape, False)
   stats = StatParts(lib.as_conv32_act_parts(), dev)
-  a_prev, z = POOL.get(g, dev), POOL.get(g, dev)
   call("as_conv32_act_fwd", ptr(z_prev), ptr(a_prevprev), ptr(st_prev.scale), ptr(st_prev.shift), ptr(a_prev), g, ptr(wp), ptr(b),
        LEAKY_SLOPE, ptr(z), g, shape, ptr(stats.mean), ptr(stats.m2), ptr(stats.cnt), stream())
   st = bn_train_stats(stats, gamma, beta, rm, rv)

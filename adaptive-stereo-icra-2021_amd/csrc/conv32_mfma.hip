@@ -31,6 +31,7 @@
 #include "conv3d_lds.h"
 #include "conv32_bwd.h"
 #include "conv32_act.h"
+#include "conv32_wino.h"
 
 static bool wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 
@@ -720,6 +721,7 @@ extern "C" int as_conv32_pack_weights(const float* w, float* packed, const as_co
 //   AS_PACK_S2_DGRAD (2)          as_conv32_dgrad_s2_pack: 5x5 stride-2 data gradient, the 25 taps in parity-phase-major order
 //   AS_PACK_CONV4 + Cin (16 + c)  as_conv4_pack_weights for Cin input channels, taps = T
 //   AS_PACK_MIRROR_TAP / _CH      as_mirror_taps_ch0's by_tap / by_channel layouts of a [32][4][3][3] weight
+//   AS_PACK_WINO / _T             as_conv32_wino_pack_weights (forward / data-gradient filter), taps = 16 transformed filters
 __device__ inline int s2_phase_major_tap(int t) {          // the t-th tap of the order (py, px, j, l) of as_conv32_dgrad_s2
   int n = 0;
   for (int py = 0; py < 2; ++py)
@@ -727,6 +729,29 @@ __device__ inline int s2_phase_major_tap(int t) {          // the t-th tap of th
       for (int j = py; j < 5; j += 2)
         for (int l = px; l < 5; l += 2) { if (n == t) return j * 5 + l; ++n; }
   return 0;
+}
+
+// Transformed filters of the minimal-filtering algorithm F(2x2, 3x3): U[4r+c] = (G g G^T)[r][c] of a [32][32][3][3] weight,
+// G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], in the B-fragment layout of the standard packing: [16][4 q][64 lanes][4 e],
+// element = U[ci = 16h + 4q + e][co = li].  transposed: the data gradient's filter (channels swapped, taps mirrored).
+__device__ inline float wino_g_row(int r, float x0, float x1, float x2) {
+  return r == 0 ? x0 : (r == 3 ? x2 : (r == 1 ? 0.5f * ((x0 + x2) + x1) : 0.5f * ((x0 + x2) - x1)));
+}
+__device__ inline void wino_pack_one(const float* __restrict__ w, float* __restrict__ packed, int idx, bool transposed) {
+  if (idx >= 16 * 1024) return;
+  const int e = idx & 3, j = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, kk = idx >> 10;
+  const int k = 16 * h + 4 * q + e, r = kk >> 2, c = kk & 3;
+  const float* g = transposed ? w + ((long)k * 32 + j) * 9 : w + ((long)j * 32 + k) * 9;
+  float col[3];                                              // (g G^T)[a][c] for the three filter rows a
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float* ga = g + 3 * (transposed ? 2 - a : a);
+    col[a] = transposed ? wino_g_row(c, ga[2], ga[1], ga[0]) : wino_g_row(c, ga[0], ga[1], ga[2]);
+  }
+  packed[idx] = wino_g_row(r, col[0], col[1], col[2]);
+}
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int transposed) {
+  wino_pack_one(w, packed, blockIdx.x * blockDim.x + threadIdx.x, transposed != 0);
 }
 
 __global__ void pack_weights_batch_kernel(const as_pack_job* __restrict__ jobs) {
@@ -748,6 +773,7 @@ __global__ void pack_weights_batch_kernel(const as_pack_job* __restrict__ jobs) 
     job.packed[kind == AS_PACK_MIRROR_TAP ? t * 32 + c : c * 9 + t] = v;
     return;
   }
+  if (kind == AS_PACK_WINO || kind == AS_PACK_WINO_T) { wino_pack_one(job.w, job.packed, idx, kind == AS_PACK_WINO_T); return; }
   if (idx >= T * 1024) return;
   const int e = idx & 3, j = (idx >> 2) & 31, h = (idx >> 7) & 1, q = (idx >> 8) & 3, t = idx >> 10;
   const int k = 16 * h + 4 * q + e;
@@ -761,6 +787,13 @@ extern "C" int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, 
   hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(as_div_up(max_taps * 1024, 256), njobs), dim3(256), 0,
                      (hipStream_t)stream, jobs);
   AS_CHECK_LAUNCH("as_conv32_pack_weights_batch");
+  return AS_OK;
+}
+
+extern "C" int as_conv32_wino_pack_weights(const float* w, float* packed, int transposed, void* stream) {
+  AS_CHECK_ARG(w && packed, "as_conv32_wino_pack_weights: null pointer");
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, packed, transposed);
+  AS_CHECK_LAUNCH("as_conv32_wino_pack_weights");
   return AS_OK;
 }
 
@@ -853,6 +886,36 @@ extern "C" int as_conv32_act_fwd(const float* z_prev, const float* a_prevprev, c
                                 stat_m2, stat_cnt, stream)) return e;
   as_prof_mark(AS_PROF_CONV_ACT, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
   AS_CHECK_LAUNCH("as_conv32_act_fwd");
+  return AS_OK;
+}
+
+// The same layer by the minimal-filtering algorithm F(2x2, 3x3) (csrc/conv32_wino.hip): 4 matrix products per output pixel
+// instead of 9.  wino_w: as_conv32_wino_pack_weights (or a batch job of kind AS_PACK_WINO).
+extern "C" int as_conv32_wino_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;
+  return conv32_wino_applicable(gin, gout, s) ? 1 : 0;
+}
+extern "C" int as_conv32_wino_parts(void) { return conv32_wino_parts(); }
+
+extern "C" int as_conv32_wino_fwd(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift,
+                                  float* a_out, const as_pcl* gin, const float* wino_w, const float* bias, float slope,
+                                  float* z, const as_pcl* gout, const as_conv_shape* s, float* stat_mean, float* stat_m2,
+                                  float* stat_cnt, void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_wino_fwd")) return e;
+  AS_CHECK_ARG(z_prev && in_scale && in_shift && a_out && wino_w && z, "as_conv32_wino_fwd: null pointer");
+  AS_CHECK_ARG((stat_mean != nullptr) == (stat_m2 != nullptr) && (stat_mean != nullptr) == (stat_cnt != nullptr),
+               "as_conv32_wino_fwd: pass all three moment arrays or none");
+  AS_CHECK_ARG(conv32_wino_applicable(gin, gout, s), "as_conv32_wino_fwd: configuration not supported (as_conv32_wino_ok() == 0)");
+  AS_CHECK_ARG(slope > 0.f && slope < 1.f, "as_conv32_wino_fwd: slope must lie in (0, 1)");
+  AS_CHECK_ARG(a_out != z_prev && a_out != a_prevprev && z != z_prev && z != a_out && z != a_prevprev,
+               "as_conv32_wino_fwd: outputs must not alias inputs or each other");
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(AS_PROF_CONV_ACT, st, 1, 0.0);
+  if (int e = conv32_wino_launch(z_prev, a_prevprev, in_scale, in_shift, a_out, gout, s, wino_w, bias, slope, z, stat_mean,
+                                 stat_m2, stat_cnt, stream)) return e;
+  // (ALGORITHMIC flops: the direct form's 9 taps — what the layer computes, not the 4 products per pixel it executes)
+  as_prof_mark(AS_PROF_CONV_ACT, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
+  AS_CHECK_LAUNCH("as_conv32_wino_fwd");
   return AS_OK;
 }
 

@@ -1,0 +1,391 @@
+// Training forward of a full-resolution refinement layer (3x3, dilation 1/2/4/8, stride 1, 32->32: stereo_net.py:10-18,
+// 33-51, 97) with the previous layer's BatchNorm + LeakyReLU (+ skip) applied to its operand on the way in — the job of
+// conv32_act.hip — computed with the minimal-filtering algorithm F(2x2, 3x3) (Winograd; Lavin & Gray 2016):
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A     per 2x2 output tile, 4x4 input tile d, 3x3 filter g,
+// 16 multiplications per 2x2 outputs and channel pair instead of 36: 4 x 32x32 matrix products per output pixel where the
+// direct form needs 9.  A dilated layer is d*d interleaved dense layers: the tile of dilation d is the pixels
+// (y, y+d) x (x, x+d) and its input tile the rows y-d..y+2d, columns x-d..x+2d in steps of d.
+//
+// A workgroup walks a comb of rows (y = r, r+d, ..) of a 64-pixel column segment, two comb rows per step, over a ring of four
+// activated rows in LDS (conv32_act.hip's scheme with a pair of rows where that has one).  The 32 tiles of a step are the 32
+// rows of the matrix instruction; the four waves split the sixteen products by the ROW r of the transformed tile:
+//   wave r:  R = (B^T d)[r] — a signed sum of two input rows — for the four tile columns, V[r][c] = (R B)[c]: both lane-local
+//            (the lane IS the tile; its 16 channels are the K half it feeds), 32 vector operations per 16 MFMAs;
+//            M[r][c] += V[r][c] x U[r][c]: 4 x 16 MFMAs, the wave's four U matrices resident in 64 registers;
+//            T[j] = (M[r] A)[j]: two 16-register tiles, written to LDS
+//   B1
+//   wave w = (i, j): Y[i][j] = (A^T T)[i][j] = a signed sum of three waves' T[j]; + bias; 16 stores; BatchNorm moments
+//   rows j+3, j+4: activate, by-product, into the two freed slots
+//   B2
+// Two workgroups per CU (73,984 B of LDS each): one's vector phases under the other's matrix phase.
+// The LDS rows are swizzled for the stride-2d tile gather: with key(v) = the voxel index with bit log2(d) removed, the 32
+// tiles of one read are 32 consecutive keys; key bit 0 selects the bank half (it is the voxel's parity for d > 1; for d = 1
+// voxels are stored with bits 0 and 1 swapped) and key bits 1-3 the 16-byte slot.
+//
+// Numerics: B^T and A^T are signed sums (no constants); G carries two factors 1/2.  Against the direct form in fp32 the
+// result differs by reassociation-level rounding (tests/test_gpu_kernels.py states the bound).
+#include "as_common.h"
+#include "conv_epilogue.h"
+#include "conv32_wino.h"
+
+#define WN_SEG 64
+#define WN_W 80                          // staged voxels per row: 8 + 64 + 8
+#define WN_ROW_BYTES (WN_W * 128)        // 10,240
+#define WN_COEF_OFF (4 * WN_ROW_BYTES)   // 40,960: scale, shift [2][32]
+#define WN_X_OFF (WN_COEF_OFF + 256)     // exchange [4 waves][2 j][4 g][64 lanes] float4 = 32,768
+#define WN_LDS_BYTES (WN_X_OFF + 32768)  // 73,984
+#ifndef WN_GRID
+#define WN_GRID 512
+#endif
+
+struct WinoArgs {
+  const float* zin;        // previous layer's pre-activation
+  const float* ain;        // previous layer's input (skip connection) or null
+  const float* in_scale;   // previous layer's BatchNorm as an affine
+  const float* in_shift;
+  float* a_out;            // by-product: the activated operand = previous layer's output
+  const float* wq;         // transformed weights [16][4][64][4] (pack kind AS_PACK_WINO)
+  EpilogueArgs ep;         // bias, z, moments
+  PclDev g;
+  int nseg, pairs;         // column segments per row; row pairs per (image, segment) over all combs
+  float slope;
+};
+
+__device__ inline void wn_load4(f32x4& v, const float* sbase, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ inline void wn_store4(float* sbase, unsigned voff, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+template <int IMM> __device__ inline void wn_store_imm(float* sbase, unsigned voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+
+// first column (relative to the segment) of tile t at dilation 2^L: blocks of 2d columns hold d tiles
+template <int L> __host__ __device__ constexpr int wn_c0(int t) { return ((t >> L) << (L + 1)) | (t & ((1 << L) - 1)); }
+// LDS position and swizzle of staged voxel v (0..79)
+template <int L> __device__ inline int wn_pos(int v) { return L == 0 ? ((v & ~3) | ((v & 1) << 1) | ((v >> 1) & 1)) : v; }
+template <int L> __device__ inline int wn_swz(int v) {
+  const int w = v + 8;
+  const int key = ((w >> (L + 1)) << L) | (w & ((1 << L) - 1));
+  return (key >> 1) & 7;
+}
+template <int L> __device__ inline int wn_addr(int v, int chunk) { return wn_pos<L>(v) * 128 + ((chunk ^ wn_swz<L>(v)) << 4); }
+
+#define WN_FOR_8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+
+template <bool SKIP, int L>
+__global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int d = 1 << L;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, li = lane & 31;
+  const int H = p.g.H, W = p.g.W, Wp = p.g.Wp;
+
+  // the wave's four transformed filters U[wave][c]: R[c][4q+e] = chunk q, element e
+  f32x16 R[4];
+  {
+    const float* wb = p.wq + (wave * 4) * 1024 + lane * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(wb + c * 1024 + q * 256);
+        R[c][4 * q + 0] = t4.x; R[c][4 * q + 1] = t4.y; R[c][4 * q + 2] = t4.z; R[c][4 * q + 3] = t4.w;
+      }
+  }
+  const float bias_v = p.ep.bias ? p.ep.bias[li] : 0.f;
+  if (threadIdx.x < 64) {
+    float* tab = reinterpret_cast<float*>(smem + WN_COEF_OFF);
+    tab[threadIdx.x] = threadIdx.x < 32 ? p.in_scale[threadIdx.x] : p.in_shift[threadIdx.x - 32];
+  }
+  __syncthreads();
+
+  // ---- row conversion: a PAIR of rows is 1,280 chunks, five per thread: chunk f = t + 256k; f < 640 row A else row B ----
+  const int t = threadIdx.x;
+  const int c4 = (t & 7) * 4;
+  int cv_vox[5];                                            // staged voxel of chunk k (its row: k < 2 A, k > 2 B, k == 2 by wave)
+  cv_vox[0] = t >> 3; cv_vox[1] = 32 + (t >> 3); cv_vox[2] = wave < 2 ? 64 + (t >> 3) : (t >> 3) - 16;
+  cv_vox[3] = 16 + (t >> 3); cv_vox[4] = 48 + (t >> 3);
+  const bool k2_is_a = wave < 2;
+
+  // ---- operand gather: this lane's tile li, input column m -> staged voxel 8 + c0 + (m-1) d; chunk 4h + q ----
+  int op_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) op_off[m] = wn_addr<L>(8 + wn_c0<L>(li) + (m - 1) * d, 4 * h);
+  // input rows (of the four of a tile) and sign of this wave's row transform: R = d[ra] + sg * d[rb]
+  const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+  const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+  const float sg = wave == 1 ? 1.f : -1.f;
+  // epilogue: this wave finishes output (oi, oj) of every tile
+  const int oi = wave >> 1, oj = wave & 1;
+  const unsigned io_off = (unsigned)((wn_c0<L>(4 * h) + oj * d) * 128 + 4 * li);
+  const unsigned io_off2 = io_off + 4096u;                  // rows 8..15 of the accumulator layout: tiles +16 = 32 columns
+  float st_c = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;      // BatchNorm moments of this lane's channel: shifted sums
+
+  const long t_total = (long)p.g.B * p.nseg * p.pairs;
+  long t_next = t_total * blockIdx.x / gridDim.x;
+  const long t_end = t_total * (blockIdx.x + 1) / gridDim.x;
+  while (t_next < t_end) {
+    const int blk = (int)(t_next / p.pairs);
+    int pj0 = (int)(t_next - (long)blk * p.pairs);
+    int r0 = 0, nrow = (H + d - 1) / d;                   // rows of comb r0
+    while (pj0 >= (nrow + 1) / 2) { pj0 -= (nrow + 1) / 2; ++r0; nrow = (H - r0 + d - 1) / d; }
+    const int pj1 = (int)min((long)((nrow + 1) / 2), pj0 + (t_end - t_next));
+    t_next += pj1 - pj0;
+    const int j0 = 2 * pj0, j1 = min(2 * pj1, nrow);
+    const int seg = blk % p.nseg;
+    const int b = blk / p.nseg;
+    const int x_new = WN_SEG * seg;
+    const int x0 = min(x_new, W - WN_SEG);
+    const int dup = x_new - x0;                           // columns below `dup` also belong to the neighbouring segment
+    const long img = (long)b * p.g.Hp;
+    const int px0 = x0 - 8 + p.g.pw;
+
+    f32x4 pz[5], pa[5];
+    auto fetch_one = [&](int ja, const float* src, f32x4 (&pv)[5]) {     // rows ja, ja + 1; outside the image: any valid row
+      const int ya = min(max(r0 + ja * d, 0), H - 1), yb = min(max(r0 + (ja + 1) * d, 0), H - 1);
+      const long offa = ((img + ya + p.g.ph) * Wp + px0) * 32, offb = ((img + yb + p.g.ph) * Wp + px0) * 32;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const long off = (k < 2 || (k == 2 && k2_is_a)) ? offa : offb;
+        wn_load4(pv[k], src + off, (unsigned)(cv_vox[k] * 128 + c4 * 4));
+      }
+    };
+    auto fetch_into = [&](int ja, f32x4 (&pz)[5], f32x4 (&pa)[5]) {
+      fetch_one(ja, p.zin, pz);
+      if (SKIP) fetch_one(ja, p.ain, pa);
+    };
+    auto convert_from = [&](int ja, f32x4 (&pz)[5], f32x4 (&pa)[5]) {    // -> ring slots (ja + 1) & 3, (ja + 2) & 3
+      const float* tab = reinterpret_cast<const float*>(smem + WN_COEF_OFF) + c4;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(tab), sh = *reinterpret_cast<const f32x4*>(tab + 32);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const bool is_a = k < 2 || (k == 2 && k2_is_a);
+        const int jj = is_a ? ja : ja + 1;
+        const int y = r0 + jj * d;
+        const bool row_in = y >= 0 && y < H;               // (wave-uniform)
+        const int v = cv_vox[k];
+        const int xx = x0 - 8 + v;
+        f32x4 yv = pz[k] * sc + sh;
+        const f32x4 ys = yv * p.slope;                      // 0 < slope < 1: lrelu(y) = max(y, slope*y)
+        yv.x = fmaxf(yv.x, ys.x); yv.y = fmaxf(yv.y, ys.y);
+        yv.z = fmaxf(yv.z, ys.z); yv.w = fmaxf(yv.w, ys.w);
+        if (SKIP) yv += pa[k];
+        yv = (row_in && xx >= 0 && xx < W) ? yv : (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * WN_ROW_BYTES + wn_addr<L>(v, t & 7)) = yv;
+        const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
+        if (own && v >= 8 && v < 8 + WN_SEG) {
+          float* aout = p.a_out + ((img + y + p.g.ph) * Wp + px0) * 32;
+          wn_store4(aout, (unsigned)(v * 128 + c4 * 4), yv);
+        }
+      }
+    };
+    auto wait_all = [&](f32x4 (&pz)[5], f32x4 (&pa)[5]) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+    };
+
+    // ---- run-in: activated rows j0-1 .. j0+2 (two pairs in flight; the loads of the second pair retire after the first's) ----
+    {
+      f32x4 qz[5], qa[5];
+      fetch_into(j0 - 1, pz, pa); fetch_into(j0 + 1, qz, qa);
+      if (SKIP) asm volatile("s_waitcnt vmcnt(10)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+      convert_from(j0 - 1, pz, pa);
+      wait_all(qz, qa);
+      convert_from(j0 + 1, qz, qa);
+    }
+    __syncthreads();
+
+    for (int j = j0; j < j1; j += 2) {
+      fetch_one(j + 3, p.zin, pz);                         // in flight during the matrix phase (the skip rows follow it:
+                                                           // ten more registers across the matrix phase spilled)
+      const char* row_a = smem + ((j + ra) & 3) * WN_ROW_BYTES;   // input row m of the tile = comb row j-1+m = slot (j+m) & 3
+      const char* row_b = smem + ((j + rb) & 3) * WN_ROW_BYTES;
+      f32x16 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+      f32x4 xa[4], xb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        xa[m] = *reinterpret_cast<const f32x4*>(row_a + op_off[m]);
+        xb[m] = *reinterpret_cast<const f32x4*>(row_b + op_off[m]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 V[4];
+        {
+          f32x4 Rt[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) Rt[m] = xa[m] + sg * xb[m];
+          V[0] = Rt[0] - Rt[2]; V[1] = Rt[1] + Rt[2]; V[2] = Rt[2] - Rt[1]; V[3] = Rt[1] - Rt[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < 4) {                                   // the next chunk's operands: in flight under this chunk's MFMAs
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            xa[m] = *reinterpret_cast<const f32x4*>(row_a + (op_off[m] ^ ((q + 1) << 4)));
+            xb[m] = *reinterpret_cast<const f32x4*>(row_b + (op_off[m] ^ ((q + 1) << 4)));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].x, R[c][4 * q + 0], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].y, R[c][4 * q + 1], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].z, R[c][4 * q + 2], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].w, R[c][4 * q + 3], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // T[j] = (M[r] A)[j]: A^T = [1 1 1 0; 0 1 -1 -1]
+      {
+        char* xw = smem + WN_X_OFF + (wave * 2) * 4096 + lane * 16;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          f32x4 t0, t1;
+          t0.x = (acc[0][4 * gq + 0] + acc[1][4 * gq + 0]) + acc[2][4 * gq + 0];
+          t0.y = (acc[0][4 * gq + 1] + acc[1][4 * gq + 1]) + acc[2][4 * gq + 1];
+          t0.z = (acc[0][4 * gq + 2] + acc[1][4 * gq + 2]) + acc[2][4 * gq + 2];
+          t0.w = (acc[0][4 * gq + 3] + acc[1][4 * gq + 3]) + acc[2][4 * gq + 3];
+          t1.x = (acc[1][4 * gq + 0] - acc[2][4 * gq + 0]) - acc[3][4 * gq + 0];
+          t1.y = (acc[1][4 * gq + 1] - acc[2][4 * gq + 1]) - acc[3][4 * gq + 1];
+          t1.z = (acc[1][4 * gq + 2] - acc[2][4 * gq + 2]) - acc[3][4 * gq + 2];
+          t1.w = (acc[1][4 * gq + 3] - acc[2][4 * gq + 3]) - acc[3][4 * gq + 3];
+          *reinterpret_cast<f32x4*>(xw + gq * 1024) = t0;
+          *reinterpret_cast<f32x4*>(xw + 4096 + gq * 1024) = t1;
+        }
+      }
+      if (SKIP) fetch_one(j + 3, p.ain, pa);               // (the accumulators are dead: registers to spare)
+      __syncthreads();                                     // B1: the T tiles are in place; nobody reads rows j-1, j any more
+      // ---- Y[oi][oj] = (A^T T)[oi][oj]: waves (oi, oi+1, oi+2) with signs (+,+,+) / (+,-,-) ----
+      const int yrow = j + oi;
+      const bool row_ok = yrow < j1;                       // (wave-uniform) the pair's second row may lie outside the piece
+      f32x16 Y;
+      {
+        const char* xr = smem + WN_X_OFF + (oi * 2 + oj) * 4096 + lane * 16;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 u0 = *reinterpret_cast<const f32x4*>(xr + gq * 1024);
+          const f32x4 u1 = *reinterpret_cast<const f32x4*>(xr + 8192 + gq * 1024);
+          const f32x4 u2 = *reinterpret_cast<const f32x4*>(xr + 16384 + gq * 1024);
+          const f32x4 yv = oi == 0 ? (u0 + u1) + u2 : (u0 - u1) - u2;
+          Y[4 * gq + 0] = yv.x + bias_v; Y[4 * gq + 1] = yv.y + bias_v; Y[4 * gq + 2] = yv.z + bias_v; Y[4 * gq + 3] = yv.w + bias_v;
+        }
+      }
+      if (row_ok) {
+        const int y = r0 + yrow * d;
+        float* z_base = p.ep.z + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
+#define WN_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
+#define WN_ST(r) wn_store_imm<WN_IMM(r)>(z_base, io_off, Y[r]); wn_store_imm<WN_IMM(r)>(z_base, io_off2, Y[8 + r]);
+        WN_FOR_8(WN_ST)
+#undef WN_ST
+        if (p.ep.stat_mean != nullptr) {
+          if (dup <= 0) {
+            st_c = st_n == 0.f ? Y[0] : st_c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float dd = Y[r] - st_c; st_s1 += dd; st_s2 = fmaf(dd, dd, st_s2); }
+            st_n += 16.f;
+          } else {
+            st_c = st_n == 0.f ? Y[15] : st_c;             // (the last tile's column is never a duplicate: dup < 64)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int col = wn_c0<L>((r & 3) + 8 * (r >> 2)) + wn_c0<L>(4 * h) + oj * d;
+              const bool in = col >= dup;
+              const float dd = in ? Y[r] - st_c : 0.f;
+              st_s1 += dd; st_s2 = fmaf(dd, dd, st_s2); st_n += in ? 1.f : 0.f;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the operand rows are home when only this tile's own stores are outstanding (vector memory retires in order)
+      if (row_ok) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+      if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+      convert_from(j + 3, pz, pa);
+      __syncthreads();                                     // B2: activated rows j+3, j+4 are in place; the exchange is free
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (p.ep.stat_mean != nullptr) {
+    // lane sums -> (n, mean, M2) -> one partial per workgroup: 8 (wave, half) partials per channel, merged in fixed order
+    float* part = reinterpret_cast<float*>(smem);      // [8][32][3]
+    const float mean_l = st_n > 0.f ? st_c + st_s1 / st_n : 0.f;
+    const float m2_l = st_n > 0.f ? fmaxf(st_s2 - st_s1 * st_s1 / st_n, 0.f) : 0.f;
+    float* mine = part + ((wave * 2 + h) * 32 + li) * 3;
+    mine[0] = st_n; mine[1] = mean_l; mine[2] = m2_l;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      TileStats run; run.n = 0.f; run.mean = 0.f; run.m2 = 0.f;
+      for (int q = 0; q < 8; ++q) {
+        TileStats ts;
+        ts.n = part[(q * 32 + li) * 3]; ts.mean = part[(q * 32 + li) * 3 + 1]; ts.m2 = part[(q * 32 + li) * 3 + 2];
+        stats_merge(run, ts);
+      }
+      stats_write(p.ep, blockIdx.x, run);
+    }
+  }
+}
+
+static int wn_log2(int d) { return d == 1 ? 0 : d == 2 ? 1 : d == 4 ? 2 : d == 8 ? 3 : -1; }
+
+static long wn_pairs(int H, int d) {
+  long n = 0;
+  for (int r = 0; r < d; ++r) n += ((H - r + d - 1) / d + 1) / 2;
+  return n;
+}
+
+// Applicable to the refinement geometry: 2-D 3x3 stride 1, dilation 1/2/4/8 within the halo, rows of at least 64 pixels and
+// enough row pairs for the fixed grid.
+bool conv32_wino_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (s->kd != 1 || s->kh != 3 || s->kw != 3 || s->stride != 1) return false;
+  if (wn_log2(s->dil) < 0 || s->pad_h != s->dil || s->pad_w != s->dil) return false;
+  if (gin->D != 1 || gout->D != 1 || gin->pd != 0) return false;
+  if (gin->B != gout->B || gin->H != gout->H || gin->W != gout->W) return false;
+  if (gin->ph != gout->ph || gin->pw != gout->pw || gin->pw < 8 || gin->ph < s->dil) return false;
+  if (gout->W < WN_SEG || gout->H < 2 * s->dil) return false;
+  const long units = (long)gout->B * ((gout->W + WN_SEG - 1) / WN_SEG) * wn_pairs(gout->H, s->dil);
+  return units >= 4L * WN_GRID && units < (1L << 31);
+}
+
+int conv32_wino_parts(void) { return WN_GRID; }
+
+template <bool SKIP> static const void* wn_kernel(int L) {
+  switch (L) {
+    case 0: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 0>);
+    case 1: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 1>);
+    case 2: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 2>);
+    default: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 3>);
+  }
+}
+
+int conv32_wino_launch(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift, float* a_out,
+                       const as_pcl* g, const as_conv_shape* s, const float* wino_w, const float* bias, float slope,
+                       float* z, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream) {
+  static AsPerDevice attr_set[8];
+  const int L = wn_log2(s->dil);
+  const int fi = (a_prevprev != nullptr ? 4 : 0) + L;
+  const void* fn = a_prevprev != nullptr ? wn_kernel<true>(L) : wn_kernel<false>(L);
+  if (!attr_set[fi].get()) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES);
+    if (e != hipSuccess) { as_set_error("as_conv32_wino_fwd: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
+    attr_set[fi].set();
+  }
+  WinoArgs a;
+  a.zin = z_prev; a.ain = a_prevprev; a.in_scale = in_scale; a.in_shift = in_shift; a.a_out = a_out; a.wq = wino_w;
+  a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = nullptr; a.ep.ep_shift = nullptr; a.ep.residual = nullptr;
+  a.ep.stat_mean = stat_mean; a.ep.stat_m2 = stat_m2; a.ep.stat_cnt = stat_cnt; a.ep.epilogue = 0; a.ep.slope = slope;
+  a.g = as_make_dev(g);
+  a.nseg = (g->W + WN_SEG - 1) / WN_SEG; a.pairs = (int)wn_pairs(g->H, s->dil); a.slope = slope;
+  void* kargs[] = {&a};
+  hipError_t le = hipLaunchKernel(fn, dim3(WN_GRID), dim3(256), kargs, WN_LDS_BYTES, (hipStream_t)stream);
+  if (le != hipSuccess) { as_set_error("as_conv32_wino_fwd: launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
+  return AS_OK;
+}

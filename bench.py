@@ -336,6 +336,7 @@ def main():
 
   if rank != 0:
     if world > 1:
+      adapter.close()
       dist.destroy_process_group()
     return
 
@@ -518,8 +519,9 @@ def main():
   if world == 1 and not args.no_cpu_baseline:
     out["cpu_baseline"] = cpu_baseline(args, fsd, ssd)
     log("cpu baseline done")
-  print(json.dumps(out))
+  print(json.dumps(out), flush=True)
   if world > 1:
+    adapter.close()
     dist.destroy_process_group()
 
 

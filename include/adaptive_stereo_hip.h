@@ -97,6 +97,8 @@ typedef struct as_pack_job {
 #define AS_PACK_CONV4 16        /* + Cin: as_conv4_pack_weights for Cin input channels (packed: taps * 128 floats) */
 #define AS_PACK_MIRROR_TAP 32   /* as_mirror_taps_ch0's by_tap [9][32] of a [32][4][3][3] weight */
 #define AS_PACK_MIRROR_CH 33    /* ... its by_channel [32][9] */
+#define AS_PACK_WINO 34         /* as_conv32_wino_pack_weights(transposed = 0): taps = 16 (packed: 16 * 1024 floats) */
+#define AS_PACK_WINO_T 35       /* ... transposed = 1: the data gradient's filter */
 int as_conv32_pack_weights_batch(const as_pack_job* jobs, int njobs, int max_taps, void* stream);
 int as_conv32_num_blocks(const as_pcl* gout);
 int as_conv32_stat_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
@@ -148,6 +150,19 @@ int as_conv32_act_fwd(const float* z_prev, const float* a_prevprev, const float*
                       float* a_out, const as_pcl* gin, const float* packed_w, const float* bias, float slope,
                       float* z, const as_pcl* gout, const as_conv_shape* s, float* stat_mean, float* stat_m2,
                       float* stat_cnt, void* stream);
+
+/* ---- the same layer (same arguments, same outputs) by the minimal-filtering algorithm F(2x2, 3x3) (csrc/conv32_wino.hip):
+ * four 32x32 matrix products per output pixel where the direct form has nine; dilation 1, 2, 4 or 8; rows of >= 64 pixels.
+ * The result differs from as_conv32_act_fwd's by fp32 rounding only (a different, equally valid association).
+ *   wino_w     as_conv32_wino_pack_weights(w, out, transposed = 0) — 16 * 1024 floats — or a batch job of kind AS_PACK_WINO
+ *   stat_*     as_conv32_wino_parts() partials */
+int as_conv32_wino_ok(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+int as_conv32_wino_parts(void);
+int as_conv32_wino_pack_weights(const float* w, float* packed, int transposed, void* stream);
+int as_conv32_wino_fwd(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift,
+                       float* a_out, const as_pcl* gin, const float* wino_w, const float* bias, float slope,
+                       float* z, const as_pcl* gout, const as_conv_shape* s, float* stat_mean, float* stat_m2,
+                       float* stat_cnt, void* stream);
 
 /* ---- a3, second generation: one 3x3x3 stride-1 32->32 aggregation layer (stereo_net.py:21-30,155-161,185-186) or its data
  * gradient, walking down the disparity axis with a rolling window of planes in LDS (csrc/agg3d.hip).

@@ -486,6 +486,8 @@ def _rccl_kitti_worker(rank, world, port, out_path):
     losses = [float(adapter.step(left, right)["loss"]) for _ in range(2)]
     torch.cuda.synchronize()
     out[mode] = (first, losses, adapter.arena.params.detach().cpu().clone())
+    adapter.close()                      # the communicator goes before the next one (and the process group) does
+    assert adapter.comm is None and adapter.graph_count() == 0
   torch.save(out, out_path)
   dist.barrier()
   dist.destroy_process_group()

@@ -1138,6 +1138,63 @@ def test_conv32_forward_with_previous_activation_on_the_way_in(B, H, W, dil, ski
   parity_note("conv32_act[%s]" % tag, by_product_bit_identical=a_exact, z_bit_identical=z_exact)
 
 
+@pytest.mark.parametrize("B,H,W,dil,skip", [(2, 160, 1242, 1, True), (2, 161, 1242, 2, True), (1, 375, 1030, 4, True),
+                                            (2, 163, 1237, 8, True), (4, 97, 700, 1, False), (1, 375, 1242, 8, False),
+                                            (12, 375, 64, 2, True)])
+def test_conv32_forward_by_minimal_filtering(B, H, W, dil, skip):
+  """as_conv32_wino_fwd — the layer of as_conv32_act_fwd by the minimal-filtering algorithm F(2x2, 3x3) — against
+  as_conv32_act_fwd's two-launch equivalent (as_bn_act_fwd, as_conv32_fwd): the by-product bit for bit (the same element-wise
+  chain); the convolution output is a different association of the same sum, so it is compared with the fp64 convolution of the
+  SAME fp32 operand, where its error must stay within 2x the direct kernel's own (and the direct kernel within 2e-6 of it).
+  Odd comb lengths (a pair with one row), ragged last segment, every dilation, with and without skip, W == one segment."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_wino_ok(g, g, shape) == 1
+  z_prev = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=1).to(DEV), g)
+  a_pp = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=2).to(DEV), g) if skip else None
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  b = (rnd(32, seed=10) * 0.1).to(DEV)
+  wp = ops.pack_weights(w, shape, False)
+  ww = torch.empty(16 * 1024, device=DEV)
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww), 0, nat.stream())
+  st = ops.BnState(DEV)
+  st.scale.copy_(rnd(32, seed=5).abs().to(DEV) + 0.5); st.shift.copy_(rnd(32, seed=6).to(DEV) * 0.3)
+  a_ref = ops.bn_act(z_prev, st, g, residual=a_pp, out=ops.pcl_zeros(g, DEV))
+  stats_ref = ops.conv32_stat_parts(g, g, shape, DEV)
+  z_ref = ops.conv32(a_ref, g, wp, b, g, shape, out=ops.pcl_zeros(g, DEV), stats=stats_ref)
+  a_out, z = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  stats = ops.StatParts(lib.as_conv32_wino_parts(), DEV)
+  nat.call("as_conv32_wino_fwd", nat.ptr(z_prev), nat.ptr(a_pp), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a_out), g,
+           nat.ptr(ww), nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats.mean), nat.ptr(stats.m2), nat.ptr(stats.cnt),
+           nat.stream())
+  tag = "wino B%d H%d W%d d%d %s" % (B, H, W, dil, "skip" if skip else "plain")
+  for name, got in (("a_out", a_out), ("z", z)):
+    full = ops.pcl_view(got, g).clone(); ops.pcl_interior(full, g).zero_()
+    assert float(full.abs().max()) == 0.0, tag + ": %s written into the halo" % name
+  ai, ai_ref = ops.pcl_interior(ops.pcl_view(a_out, g), g), ops.pcl_interior(ops.pcl_view(a_ref, g), g)
+  zi, zi_ref = ops.pcl_interior(ops.pcl_view(z, g), g), ops.pcl_interior(ops.pcl_view(z_ref, g), g)
+  assert bool(torch.equal(ai, ai_ref)), tag + ": by-product differs from as_bn_act_fwd"
+  # the fp64 convolution of the same fp32 operand
+  a_nchw = ops.pcl_to_ncdhw(a_ref, g)[:, :, 0].double().cpu()
+  z64 = torch.nn.functional.conv2d(a_nchw, w.double().cpu(), b.double().cpu(), padding=dil, dilation=dil)
+  z64 = z64.permute(0, 2, 3, 1).reshape(zi.shape).to(DEV)
+  err_w = float((zi.double() - z64).abs().max()); err_d = float((zi_ref.double() - z64).abs().max())
+  scale = float(z64.abs().max())
+  assert err_d <= 2e-6 * scale, (tag, err_d, scale)
+  assert err_w <= max(2.0 * err_d, 1e-6 * scale), (tag, err_w, err_d, scale)
+  rms_w = float((zi.double() - z64).pow(2).mean().sqrt()); rms_d = float((zi_ref.double() - z64).pow(2).mean().sqrt())
+  assert rms_w <= 2.0 * rms_d, (tag, rms_w, rms_d)
+  gam, bet = torch.ones(32, device=DEV), torch.zeros(32, device=DEV)
+  fin = [ops.bn_train_stats(sp, gam, bet, torch.zeros(32, device=DEV), torch.ones(32, device=DEV)) for sp in (stats, stats_ref)]
+  close(fin[0].mean, fin[1].mean, 2e-6, 1e-5, tag + " batch mean")
+  close(fin[0].invstd, fin[1].invstd, 0, 2e-6, tag + " batch invstd")
+  assert float(stats.cnt.sum()) == float(B * H * W)
+  from conftest import parity_note
+  parity_note("conv32_wino[%s]" % tag, by_product_bit_identical=True, max_err_vs_fp64=err_w, direct_max_err_vs_fp64=err_d,
+              rms_err_vs_fp64=rms_w, direct_rms_err_vs_fp64=rms_d)
+
+
 def test_fused_full_resolution_kernels_refuse_unsupported_geometry():
   """as_conv32_act_fwd / as_conv32_bwd_fused are built for the refinement's geometry (2-D 3x3, dilation <= 8 inside an 8-voxel
   halo, rows of >= 128 / 64 pixels, enough tiles for the fixed grid): everything else is declined by the *_ok query and

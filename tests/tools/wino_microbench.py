@@ -1,0 +1,42 @@
+"""Times as_conv32_act_fwd against as_conv32_wino_fwd at the bench workload (B pairs x 375 x 1242), every dilation.
+usage: python tests/tools/wino_microbench.py [B]"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "adaptive-stereo-icra-2021_amd"))
+import torch
+from adaptive_stereo import _native as nat, hip_ops as ops
+from adaptive_stereo._native import Pcl
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+DEV = torch.device("cuda", 0)
+H, W = 375, 1242
+g = Pcl(B, 1, H, W, 0, 8, 8)
+lib = nat.load()
+gen = torch.Generator().manual_seed(0)
+z_prev = ops.ncdhw_to_pcl(torch.randn(B, 32, 1, H, W, generator=gen).to(DEV), g)
+a_pp = ops.ncdhw_to_pcl(torch.randn(B, 32, 1, H, W, generator=gen).to(DEV), g)
+w = (torch.randn(32, 32, 3, 3, generator=gen) * 0.06).to(DEV)
+b = torch.zeros(32, device=DEV)
+st = ops.BnState(DEV); st.scale.fill_(1.0); st.shift.fill_(0.1)
+a_out, z = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+ww = torch.empty(16 * 1024, device=DEV)
+nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww), 0, nat.stream())
+flops = 2.0 * B * H * W * 1024 * 9
+for dil in (1, 2, 4, 8):
+  shape = ops.conv_shape_2d(dil)
+  wp = ops.pack_weights(w, shape, False)
+  for skip in (True, False):
+    for name, wt, parts in (("act", wp, lib.as_conv32_act_parts()), ("wino", ww, lib.as_conv32_wino_parts())):
+      stats = ops.StatParts(parts, DEV)
+      def run():
+        nat.call("as_conv32_%s_fwd" % name, nat.ptr(z_prev), nat.ptr(a_pp) if skip else None, nat.ptr(st.scale), nat.ptr(st.shift),
+                 nat.ptr(a_out), g, nat.ptr(wt), nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats.mean), nat.ptr(stats.m2),
+                 nat.ptr(stats.cnt), nat.stream())
+      for _ in range(3): run()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(20): run()
+      e1.record(); torch.cuda.synchronize()
+      us = e0.elapsed_time(e1) * 1e3 / 20
+      print("B%d d%d %-5s %-4s %8.1f us  %6.1f TFLOP/s algorithmic (%.3f of 157.3)" % (B, dil, "skip" if skip else "plain", name, us,
+            flops / us * 1e-6, flops / us * 1e-6 / 157.3), flush=True)
