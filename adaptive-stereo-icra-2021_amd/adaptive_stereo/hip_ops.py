@@ -702,12 +702,27 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
     ws = sums.workspace if sums is not None else _empty(lib.as_bn_bwd_workspace(g), dev)
     bn_bwd_coefs(g_out, z, st, gamma, g, train, sg, sbeta, True, ws, sums)
     coef = ws[lib.as_bn_bwd_coef_offset():]
-    wp_t = pack_weights(w, shape, True)
     g_x = POOL.get(g, dev)
     nws = _empty(lib.as_bn_bwd_workspace(g), dev)
+    next_z, next_st = next_bn
+    if _WINOGRAD and lib.as_conv32_wino_ok(g, g, shape) == 1:
+      # both gradients by minimal filtering (csrc/conv32_wino.hip MODE 2, csrc/conv32_wino_wgrad.hip): 4 matrix products per
+      # pixel and gradient instead of 9; g_z makes one round trip through HBM between the two launches
+      ww_t = pack_special(w, PACK_WINO_T, 16, 16 * 1024,
+                          lambda w_, o_: call("as_conv32_wino_pack_weights", ptr(w_), ptr(o_), 1, stream()))
+      wws = _empty(lib.as_conv32_wino_bwd_workspace(), dev)
+      _keep_for_deferred_reduce(wws)
+      g_z = POOL.get(g, dev)
+      _rmw_wait(sw)
+      call("as_conv32_wino_bwd", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(ww_t), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+           ptr(coef), LEAKY_SLOPE, ptr(next_z), ptr(next_st.scale), ptr(next_st.shift), ptr(next_st.mean), ptr(g_z), ptr(g_x),
+           ptr(sw), ptr(sb), 1, ptr(nws), ptr(wws), stream())
+      _rmw_done(sw)
+      POOL.put(g_z, g)
+      return g_x, None, None, None, None, BnBwdSums(nws, lib.as_conv32_wino_bwd_parts())
+    wp_t = pack_weights(w, shape, True)
     wws = _empty(lib.as_conv32_bwd_fused_workspace(), dev)
     _keep_for_deferred_reduce(wws)
-    next_z, next_st = next_bn
     _rmw_wait(sw)
     call("as_conv32_bwd_fused", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(wp_t), ptr(st.scale), ptr(st.shift), ptr(st.mean),
          ptr(coef), LEAKY_SLOPE, ptr(next_z), ptr(next_st.scale), ptr(next_st.shift), ptr(next_st.mean), ptr(g_x), ptr(sw),

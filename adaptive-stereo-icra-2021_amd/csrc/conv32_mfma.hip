@@ -919,6 +919,42 @@ extern "C" int as_conv32_wino_fwd(const float* z_prev, const float* a_prevprev, 
   return AS_OK;
 }
 
+// Backward of the same layer by minimal filtering, two launches: data gradient F(2x2, 3x3) with stage 3 of the BatchNorm
+// backward on the way in (g_z written once), skip connection and next-BatchNorm sums in the epilogue; then weight / bias
+// gradient F(3x3, 2x2) from x and g_z.  Arguments as as_conv32_bwd_fused, plus g_z (a PCL buffer of the layer's geometry).
+extern "C" int as_conv32_wino_bwd_parts(void) { return conv32_wino_parts(); }
+extern "C" int64_t as_conv32_wino_bwd_workspace(void) { return (int64_t)conv32_wino_wgrad_slabs() * (9 * 1024 + 32); }
+
+extern "C" int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                                  const as_conv_shape* s, const float* wino_wt, const float* scale, const float* shift,
+                                  const float* mean, const float* coef, float slope, const float* next_z,
+                                  const float* next_scale, const float* next_shift, const float* next_mean, float* g_z,
+                                  float* g_x, float* dW, float* db, int accumulate, float* next_bn_workspace,
+                                  float* workspace, void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_wino_bwd")) return e;
+  AS_CHECK_ARG(x && g_a && z && wino_wt && scale && shift && mean && coef && next_z && next_scale && next_shift && next_mean &&
+               g_z && g_x && dW && next_bn_workspace && workspace, "as_conv32_wino_bwd: null pointer");
+  AS_CHECK_ARG(conv32_wino_applicable(gin, gout, s), "as_conv32_wino_bwd: configuration not supported (as_conv32_wino_ok() == 0)");
+  AS_CHECK_ARG(((uintptr_t)next_bn_workspace & 7) == 0, "as_conv32_wino_bwd: the BatchNorm workspace must be 8-byte aligned");
+  AS_CHECK_ARG(slope > 0.f && slope < 1.f, "as_conv32_wino_bwd: slope must lie in (0, 1)");
+  AS_CHECK_ARG(g_x != g_a && g_x != x && g_x != z && g_z != g_a && g_z != x && g_z != z && g_z != g_x && g_z != next_z &&
+               g_x != next_z, "as_conv32_wino_bwd: outputs must not alias inputs or each other");
+  const int T = 9;
+  const int slabs = conv32_wino_wgrad_slabs();
+  float* partial_db = workspace + (int64_t)slabs * T * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(AS_PROF_BWD_FUSED, st, 1, 0.0);
+  if (int e = conv32_wino_dgrad_launch(g_a, z, gout, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift,
+                                       next_mean, g_z, g_x, reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
+  if (int e = conv32_wino_wgrad_launch(x, g_z, gout, s, workspace, partial_db, stream)) return e;
+  // (ALGORITHMIC flops of both gradients in their direct form, as as_conv32_bwd_fused)
+  as_prof_mark(AS_PROF_BWD_FUSED, st, 0, 2.0 * 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);
+  AS_CHECK_LAUNCH("as_conv32_wino_bwd");
+  wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
+  AS_CHECK_LAUNCH("as_conv32_wino_bwd(reduce)");
+  return AS_OK;
+}
+
 // Convolution (data gradient) fused with stage 1 of the BatchNorm backward that consumes its output.
 extern "C" int as_conv32_bnbwd_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
   if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;

@@ -22,6 +22,12 @@
 // tiles of one read are 32 consecutive keys; key bit 0 selects the bank half (it is the voxel's parity for d > 1; for d = 1
 // voxels are stored with bits 0 and 1 swapped) and key bits 1-3 the 16-byte slot.
 //
+// MODE 2 is the DATA GRADIENT of such a layer (the first half of its backward pass; conv32_wino_wgrad.hip is the second):
+// the staged operand is g_z = stage 3 of the layer's BatchNorm backward applied to (g_a, z) on the way in — written back once
+// as a by-product for the weight gradient —, the filter is the transposed one (AS_PACK_WINO_T), the epilogue adds the skip
+// connection (g_x = dgrad(g_z) + g_a) and forms stage 1 of the NEXT BatchNorm backward from the g_x register tile: the
+// data-gradient half of conv32_bwd.hip with 4 matrix products per pixel instead of 9.
+//
 // Numerics: B^T and A^T are signed sums (no constants); G carries two factors 1/2.  Against the direct form in fp32 the
 // result differs by reassociation-level rounding (tests/test_gpu_kernels.py states the bound).
 #include "as_common.h"
@@ -32,8 +38,8 @@
 #define WN_W 80                          // staged voxels per row: 8 + 64 + 8
 #define WN_ROW_BYTES (WN_W * 128)        // 10,240
 #define WN_COEF_OFF (4 * WN_ROW_BYTES)   // 40,960: scale, shift [2][32]
-#define WN_X_OFF (WN_COEF_OFF + 256)     // exchange [4 waves][2 j][4 g][64 lanes] float4 = 32,768
-#define WN_LDS_BYTES (WN_X_OFF + 32768)  // 73,984
+#define WN_X_OFF (WN_COEF_OFF + 768)     // (backward: k1, k2, k3, scale, shift, mean [6][32])  exchange [4 waves][2 j][4 g][64 lanes] float4
+#define WN_LDS_BYTES (WN_X_OFF + 32768)  // 74,496
 #ifndef WN_GRID
 #define WN_GRID 512
 #endif
@@ -49,6 +55,15 @@ struct WinoArgs {
   PclDev g;
   int nseg, pairs;         // column segments per row; row pairs per (image, segment) over all combs
   float slope;
+  // MODE 2 (data gradient): zin = z, ain = g_a, a_out = g_z (by-product), in_scale / in_shift = this layer's BatchNorm affine,
+  // ep.z = g_x; plus
+  const float* bn_mean;    // this layer's batch mean
+  const float* bn_coef;    // stage-3 coefficients k1, k2, k3 [96]
+  const float* nz;         // next BatchNorm backward (the layer below): pre-activation, affine, mean
+  const float* n_scale;
+  const float* n_shift;
+  const float* n_mean;
+  double* n_partial;       // [grid][64]: sum g_y, sum g_y * (z - mean) of the next BatchNorm
 };
 
 __device__ inline void wn_load4(f32x4& v, const float* sbase, unsigned voff) {
@@ -56,6 +71,9 @@ __device__ inline void wn_load4(f32x4& v, const float* sbase, unsigned voff) {
 }
 __device__ inline void wn_store4(float* sbase, unsigned voff, const f32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+template <int IMM> __device__ inline void wn_load_imm(float& v, const float* sbase, unsigned voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
 }
 template <int IMM> __device__ inline void wn_store_imm(float* sbase, unsigned voff, float v) {
   asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
@@ -74,10 +92,13 @@ template <int L> __device__ inline int wn_addr(int v, int chunk) { return wn_pos
 
 #define WN_FOR_8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 
-template <bool SKIP, int L>
+// MODE 0: forward, no skip input; 1: forward with skip input; 2: data gradient
+template <int MODE, int L>
 __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int d = 1 << L;
+  constexpr bool SKIP = MODE != 0;                          // a second tensor rides along with the operand rows
+  constexpr bool BWD = MODE == 2;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, li = lane & 31;
   const int H = p.g.H, W = p.g.W, Wp = p.g.Wp;
@@ -94,8 +115,17 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         R[c][4 * q + 0] = t4.x; R[c][4 * q + 1] = t4.y; R[c][4 * q + 2] = t4.z; R[c][4 * q + 3] = t4.w;
       }
   }
-  const float bias_v = p.ep.bias ? p.ep.bias[li] : 0.f;
-  if (threadIdx.x < 64) {
+  const float bias_v = (!BWD && p.ep.bias) ? p.ep.bias[li] : 0.f;
+  float bn_sc = 0.f, bn_sh = 0.f, bn_mu = 0.f, bn_dy = 0.f, bn_dx = 0.f;      // data gradient: next-BatchNorm sums per lane
+  if constexpr (BWD) {
+    float* tab = reinterpret_cast<float*>(smem + WN_COEF_OFF);
+    const int i = threadIdx.x;
+    if (i < 96) tab[i] = p.bn_coef[i];
+    else if (i < 128) tab[i] = p.in_scale[i - 96];
+    else if (i < 160) tab[i] = p.in_shift[i - 128];
+    else if (i < 192) tab[i] = p.bn_mean[i - 160];
+    bn_sc = p.n_scale[li]; bn_sh = p.n_shift[li]; bn_mu = p.n_mean[li];
+  } else if (threadIdx.x < 64) {
     float* tab = reinterpret_cast<float*>(smem + WN_COEF_OFF);
     tab[threadIdx.x] = threadIdx.x < 32 ? p.in_scale[threadIdx.x] : p.in_shift[threadIdx.x - 32];
   }
@@ -158,7 +188,14 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
     };
     auto convert_from = [&](int ja, f32x4 (&pz)[5], f32x4 (&pa)[5]) {    // -> ring slots (ja + 1) & 3, (ja + 2) & 3
       const float* tab = reinterpret_cast<const float*>(smem + WN_COEF_OFF) + c4;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(tab), sh = *reinterpret_cast<const f32x4*>(tab + 32);
+      f32x4 sc, sh, k1, k2, k3, bmu;
+      if constexpr (BWD) {
+        k1 = *reinterpret_cast<const f32x4*>(tab); k2 = *reinterpret_cast<const f32x4*>(tab + 32);
+        k3 = *reinterpret_cast<const f32x4*>(tab + 64); sc = *reinterpret_cast<const f32x4*>(tab + 96);
+        sh = *reinterpret_cast<const f32x4*>(tab + 128); bmu = *reinterpret_cast<const f32x4*>(tab + 160);
+      } else {
+        sc = *reinterpret_cast<const f32x4*>(tab); sh = *reinterpret_cast<const f32x4*>(tab + 32);
+      }
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const bool is_a = k < 2 || (k == 2 && k2_is_a);
@@ -167,11 +204,22 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         const bool row_in = y >= 0 && y < H;               // (wave-uniform)
         const int v = cv_vox[k];
         const int xx = x0 - 8 + v;
-        f32x4 yv = pz[k] * sc + sh;
-        const f32x4 ys = yv * p.slope;                      // 0 < slope < 1: lrelu(y) = max(y, slope*y)
-        yv.x = fmaxf(yv.x, ys.x); yv.y = fmaxf(yv.y, ys.y);
-        yv.z = fmaxf(yv.z, ys.z); yv.w = fmaxf(yv.w, ys.w);
-        if (SKIP) yv += pa[k];
+        f32x4 yv;
+        if constexpr (BWD) {                                // stage 3 of the BatchNorm backward (conv32_bwd.hip's arithmetic)
+          const f32x4 ga = pa[k], zz = pz[k];
+          const f32x4 yy = zz * sc + sh;
+          const f32x4 gl = ga * p.slope;
+          f32x4 gy;
+          gy.x = yy.x > 0.f ? ga.x : gl.x; gy.y = yy.y > 0.f ? ga.y : gl.y;
+          gy.z = yy.z > 0.f ? ga.z : gl.z; gy.w = yy.w > 0.f ? ga.w : gl.w;
+          yv = (gy - k1 - (zz - bmu) * k2) * k3;
+        } else {
+          yv = pz[k] * sc + sh;
+          const f32x4 ys = yv * p.slope;                    // 0 < slope < 1: lrelu(y) = max(y, slope*y)
+          yv.x = fmaxf(yv.x, ys.x); yv.y = fmaxf(yv.y, ys.y);
+          yv.z = fmaxf(yv.z, ys.z); yv.w = fmaxf(yv.w, ys.w);
+          if (SKIP) yv += pa[k];
+        }
         yv = (row_in && xx >= 0 && xx < W) ? yv : (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * WN_ROW_BYTES + wn_addr<L>(v, t & 7)) = yv;
         const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
@@ -261,10 +309,21 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         }
       }
       if (SKIP) fetch_one(j + 3, p.ain, pa);               // (the accumulators are dead: registers to spare)
-      __syncthreads();                                     // B1: the T tiles are in place; nobody reads rows j-1, j any more
-      // ---- Y[oi][oj] = (A^T T)[oi][oj]: waves (oi, oi+1, oi+2) with signs (+,+,+) / (+,-,-) ----
       const int yrow = j + oi;
       const bool row_ok = yrow < j1;                       // (wave-uniform) the pair's second row may lie outside the piece
+#define WN_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
+      float res[16], zt[16];                                // data gradient: g_a (skip connection) and the next layer's
+      if constexpr (BWD) {                                  // pre-activation at this wave's output pixels
+        if (row_ok) {
+          const long ovox = ((img + r0 + yrow * d + p.g.ph) * Wp + x0 + p.g.pw) * 32;
+#define WN_LD(r) wn_load_imm<WN_IMM(r)>(res[r], p.ain + ovox, io_off); wn_load_imm<WN_IMM(r)>(res[8 + r], p.ain + ovox, io_off2); \
+                 wn_load_imm<WN_IMM(r)>(zt[r], p.nz + ovox, io_off); wn_load_imm<WN_IMM(r)>(zt[8 + r], p.nz + ovox, io_off2);
+          WN_FOR_8(WN_LD)
+#undef WN_LD
+        }
+      }
+      __syncthreads();                                     // B1: the T tiles are in place; nobody reads rows j-1, j any more
+      // ---- Y[oi][oj] = (A^T T)[oi][oj]: waves (oi, oi+1, oi+2) with signs (+,+,+) / (+,-,-) ----
       f32x16 Y;
       {
         const char* xr = smem + WN_X_OFF + (oi * 2 + oj) * 4096 + lane * 16;
@@ -277,10 +336,39 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
           Y[4 * gq + 0] = yv.x + bias_v; Y[4 * gq + 1] = yv.y + bias_v; Y[4 * gq + 2] = yv.z + bias_v; Y[4 * gq + 3] = yv.w + bias_v;
         }
       }
-      if (row_ok) {
+      if constexpr (BWD) {
+        // every load so far is home (operand rows, g_a / next-z at the output pixels); the stores below are younger
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]),
+                       "+v"(res[8]), "+v"(res[9]), "+v"(res[10]), "+v"(res[11]), "+v"(res[12]), "+v"(res[13]), "+v"(res[14]),
+                       "+v"(res[15]) :: "memory");
+        asm volatile("" : "+v"(zt[0]), "+v"(zt[1]), "+v"(zt[2]), "+v"(zt[3]), "+v"(zt[4]), "+v"(zt[5]), "+v"(zt[6]), "+v"(zt[7]),
+                          "+v"(zt[8]), "+v"(zt[9]), "+v"(zt[10]), "+v"(zt[11]), "+v"(zt[12]), "+v"(zt[13]), "+v"(zt[14]),
+                          "+v"(zt[15]) :: "memory");
+        asm volatile("" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]), "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]),
+                          "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+        if (row_ok) {
+          const int y = r0 + yrow * d;
+          float* gx_base = p.ep.z + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Y[r] += res[r];
+#define WN_ST(r) wn_store_imm<WN_IMM(r)>(gx_base, io_off, Y[r]); wn_store_imm<WN_IMM(r)>(gx_base, io_off2, Y[8 + r]);
+          WN_FOR_8(WN_ST)
+#undef WN_ST
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float yv = fmaf(zt[r], bn_sc, bn_sh);
+            float gy = yv > 0.f ? Y[r] : Y[r] * p.slope;
+            if (dup > 0) {
+              const int col = wn_c0<L>((r & 3) + 8 * (r >> 2)) + wn_c0<L>(4 * h) + oj * d;
+              gy = col >= dup ? gy : 0.f;
+            }
+            bn_dy += gy; bn_dx = fmaf(gy, zt[r] - bn_mu, bn_dx);
+          }
+        }
+      } else if (row_ok) {
         const int y = r0 + yrow * d;
         float* z_base = p.ep.z + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
-#define WN_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
 #define WN_ST(r) wn_store_imm<WN_IMM(r)>(z_base, io_off, Y[r]); wn_store_imm<WN_IMM(r)>(z_base, io_off2, Y[8 + r]);
         WN_FOR_8(WN_ST)
 #undef WN_ST
@@ -304,9 +392,11 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       // the operand rows are home when only this tile's own stores are outstanding (vector memory retires in order)
-      if (row_ok) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
-      if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+      if constexpr (!BWD) {
+        if (row_ok) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
+        if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
+      }
       convert_from(j + 3, pz, pa);
       __syncthreads();                                     // B2: activated rows j+3, j+4 are in place; the exchange is free
     }
@@ -314,6 +404,20 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (BWD) {
+    // next-BatchNorm sums: 8 (wave, half) partials per channel -> one fp64 pair per workgroup
+    float* scr = reinterpret_cast<float*>(smem);        // [8][2][32]
+    scr[((wave * 2 + h) * 2 + 0) * 32 + li] = bn_dy;
+    scr[((wave * 2 + h) * 2 + 1) * 32 + li] = bn_dx;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, cch = threadIdx.x & 31;
+      double sum = 0.0;
+      for (int q = 0; q < 8; ++q) sum += (double)scr[(q * 2 + which) * 32 + cch];
+      p.n_partial[(long)blockIdx.x * 64 + which * 32 + cch] = sum;
+    }
+    return;
+  }
   if (p.ep.stat_mean != nullptr) {
     // lane sums -> (n, mean, M2) -> one partial per workgroup: 8 (wave, half) partials per channel, merged in fixed order
     float* part = reinterpret_cast<float*>(smem);      // [8][32][3]
@@ -357,35 +461,54 @@ bool conv32_wino_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv
 
 int conv32_wino_parts(void) { return WN_GRID; }
 
-template <bool SKIP> static const void* wn_kernel(int L) {
+template <int MODE> static const void* wn_kernel(int L) {
   switch (L) {
-    case 0: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 0>);
-    case 1: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 1>);
-    case 2: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 2>);
-    default: return reinterpret_cast<const void*>(conv32_wino_kernel<SKIP, 3>);
+    case 0: return reinterpret_cast<const void*>(conv32_wino_kernel<MODE, 0>);
+    case 1: return reinterpret_cast<const void*>(conv32_wino_kernel<MODE, 1>);
+    case 2: return reinterpret_cast<const void*>(conv32_wino_kernel<MODE, 2>);
+    default: return reinterpret_cast<const void*>(conv32_wino_kernel<MODE, 3>);
   }
+}
+
+static int wn_launch(int mode, int L, const WinoArgs& a, const char* who, void* stream) {
+  static AsPerDevice attr_set[12];
+  const void* fn = mode == 2 ? wn_kernel<2>(L) : (mode == 1 ? wn_kernel<1>(L) : wn_kernel<0>(L));
+  const int fi = mode * 4 + L;
+  if (!attr_set[fi].get()) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES);
+    if (e != hipSuccess) { as_set_error("%s: %s", who, hipGetErrorString(e)); return AS_ERR_LAUNCH; }
+    attr_set[fi].set();
+  }
+  WinoArgs args = a;
+  void* kargs[] = {&args};
+  hipError_t le = hipLaunchKernel(fn, dim3(WN_GRID), dim3(256), kargs, WN_LDS_BYTES, (hipStream_t)stream);
+  if (le != hipSuccess) { as_set_error("%s: launch failed: %s", who, hipGetErrorString(le)); return AS_ERR_LAUNCH; }
+  return AS_OK;
 }
 
 int conv32_wino_launch(const float* z_prev, const float* a_prevprev, const float* in_scale, const float* in_shift, float* a_out,
                        const as_pcl* g, const as_conv_shape* s, const float* wino_w, const float* bias, float slope,
                        float* z, float* stat_mean, float* stat_m2, float* stat_cnt, void* stream) {
-  static AsPerDevice attr_set[8];
-  const int L = wn_log2(s->dil);
-  const int fi = (a_prevprev != nullptr ? 4 : 0) + L;
-  const void* fn = a_prevprev != nullptr ? wn_kernel<true>(L) : wn_kernel<false>(L);
-  if (!attr_set[fi].get()) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES);
-    if (e != hipSuccess) { as_set_error("as_conv32_wino_fwd: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
-    attr_set[fi].set();
-  }
-  WinoArgs a;
+  WinoArgs a = {};
   a.zin = z_prev; a.ain = a_prevprev; a.in_scale = in_scale; a.in_shift = in_shift; a.a_out = a_out; a.wq = wino_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = nullptr; a.ep.ep_shift = nullptr; a.ep.residual = nullptr;
   a.ep.stat_mean = stat_mean; a.ep.stat_m2 = stat_m2; a.ep.stat_cnt = stat_cnt; a.ep.epilogue = 0; a.ep.slope = slope;
   a.g = as_make_dev(g);
   a.nseg = (g->W + WN_SEG - 1) / WN_SEG; a.pairs = (int)wn_pairs(g->H, s->dil); a.slope = slope;
-  void* kargs[] = {&a};
-  hipError_t le = hipLaunchKernel(fn, dim3(WN_GRID), dim3(256), kargs, WN_LDS_BYTES, (hipStream_t)stream);
-  if (le != hipSuccess) { as_set_error("as_conv32_wino_fwd: launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
-  return AS_OK;
+  return wn_launch(a_prevprev != nullptr ? 1 : 0, wn_log2(s->dil), a, "as_conv32_wino_fwd", stream);
+}
+
+// Data gradient of the layer (MODE 2): g_z (by-product), g_x = dgrad(g_z) + g_a, next-BatchNorm sums [WN_GRID][64].
+int conv32_wino_dgrad_launch(const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s, const float* wino_wt,
+                             const float* scale, const float* shift, const float* mean, const float* coef, float slope,
+                             const float* next_z, const float* next_scale, const float* next_shift, const float* next_mean,
+                             float* g_z, float* g_x, double* next_partial, void* stream) {
+  WinoArgs a = {};
+  a.zin = z; a.ain = g_a; a.in_scale = scale; a.in_shift = shift; a.a_out = g_z; a.wq = wino_wt;
+  a.ep.z = g_x; a.ep.slope = slope;
+  a.g = as_make_dev(g);
+  a.nseg = (g->W + WN_SEG - 1) / WN_SEG; a.pairs = (int)wn_pairs(g->H, s->dil); a.slope = slope;
+  a.bn_mean = mean; a.bn_coef = coef; a.nz = next_z; a.n_scale = next_scale; a.n_shift = next_shift; a.n_mean = next_mean;
+  a.n_partial = next_partial;
+  return wn_launch(2, wn_log2(s->dil), a, "as_conv32_wino_bwd", stream);
 }

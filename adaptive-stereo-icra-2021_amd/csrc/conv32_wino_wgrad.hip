@@ -1,0 +1,244 @@
+// Weight / bias gradient of a full-resolution refinement layer (3x3, dilation 1/2/4/8, 32->32: stereo_net.py:10-18, 33-51,
+// 97) by the minimal-filtering algorithm F(3x3, 2x2) — the second half of the layer's backward pass (conv32_wino.hip MODE 2 is
+// the first and leaves g_z behind):
+//   dW[a][b] = sum over 2x2 tiles of g_z of  A^T [ (G g G^T) .* (B^T x B) ] A ,   g = the g_z tile, x = the 4x4 input tile
+//   A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1],  G = [1 0; 1/2 1/2; 1/2 -1/2; 0 1],  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]
+// 16 products per tile (4 output pixels) and channel pair instead of 36; the SUM OVER TILES is the K dimension of the matrix
+// instruction:  M[r][c][ci][co] += sum_tiles (B^T x B)[r][c][tile][ci] * (G g G^T)[r][c][tile][co], so the lane is the channel
+// (ci for the A operand, co for B) and one v_mfma_f32_32x32x2_f32 consumes two tiles.  The two factors 1/2 of G are applied once,
+// to M, at the end.
+//
+// Nothing here is element-wise work on a tile's way in, nothing leaves per tile: rows of x (with halo) and of g_z arrive by
+// LDS-DMA one tile ahead, the matrix waves read them with ds_read_b32 (32 lanes = one voxel's 32 channels; the two half-waves
+// read two tiles whose voxels lie in different bank halves: rows are stored in 8-voxel chunks one voxel apart), 12 vector
+// operations per 4 MFMAs form both transforms.  So ONE workgroup per CU (4 waves, the 16 accumulators split by the transformed
+// row r as in conv32_wino.hip) keeps the matrix pipe fed with one barrier per tile; 147 KB of LDS: a ring of 8 x rows and three
+// buffers of a g_z row pair — the rows of TWO tiles are in flight (with one, 9 MB in flight chip-wide against ~3 us of loaded
+// HBM latency capped the launch at ~3 TB/s: 190-210 us where the matrix work is 111).  At the end the waves exchange (M A) through LDS, apply A^T and write the workgroup's slab
+// [9][32][32] (+ bias partial) for the batch reduce that every weight gradient of the step shares.
+#include "as_common.h"
+#include "conv32_wino.h"
+
+#define WW_CHUNK 1152                        // 8 voxels of 128 B + one voxel of padding
+#define WW_XROW (10 * WW_CHUNK)              // 11,520: 80 staged voxels (8 + 64 + 8)
+#define WW_XSLOTS 8
+#define WW_GROW (8 * WW_CHUNK)               // 9,216: the segment's own 64 voxels
+#define WW_G_OFF (WW_XSLOTS * WW_XROW)       // 92,160
+#define WW_GBUF (2 * WW_GROW)                // 18,432: a pair of g_z rows
+#define WW_LDS_BYTES (WW_G_OFF + 3 * WW_GBUF)    // 147,456
+#ifndef WW_GRID
+#define WW_GRID 256
+#endif
+
+struct WgradWinoArgs {
+  const float* x;          // layer input (PCL, zero halo)
+  const float* gz;         // gradient w.r.t. the layer's pre-activation (PCL, zero halo)
+  float* partial;          // [WW_GRID][9][32][32]
+  float* partial_db;       // [WW_GRID][32]
+  PclDev g;
+  int nseg, pairs;
+};
+
+typedef __attribute__((address_space(3))) void* ww_lds_t;
+
+__device__ inline void ww_dma_1kb(const float* sbase, unsigned voff, unsigned m0) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(m0), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+
+template <int L> __host__ __device__ constexpr int ww_c0(int t) { return ((t >> L) << (L + 1)) | (t & ((1 << L) - 1)); }
+__host__ __device__ constexpr int ww_off(int v) { return (v >> 3) * WW_CHUNK + (v & 7) * 128; }
+// tile of matrix step s, half 0 (half 1: + 1 for d > 1, + 4 for d = 1 — a voxel in the other bank half either way)
+template <int L> __host__ __device__ constexpr int ww_tile(int s) { return L == 0 ? (s & 3) + 8 * (s >> 2) : 2 * s; }
+
+template <int RW, int L>
+__device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, char* smem) {
+  constexpr int d = 1 << L;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((ww_lds_t)smem));
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5, li = lane & 31;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int H = p.g.H, W = p.g.W, Wp = p.g.Wp;
+  // this wave's row of the transformed tiles: R = x[ra] + sg * x[rb]  (B^T rows: x0-x2, x1+x2, x2-x1, x3-x1)
+  constexpr int ra = RW == 0 ? 0 : (RW == 1 ? 1 : (RW == 2 ? 2 : 3));
+  constexpr int rb = RW == 0 ? 2 : (RW == 1 ? 2 : 1);
+  constexpr float sg = RW == 1 ? 1.f : -1.f;
+  const int lane_off = li * 4 + h * (L == 0 ? WW_CHUNK : 128);
+  const int lane_col = L == 0 ? 8 * h : h;                  // this half's share of a tile's first column
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  float bsum = 0.f;
+
+  const long t_total = (long)p.g.B * p.nseg * p.pairs;
+  long t_next = t_total * blockIdx.x / gridDim.x;
+  const long t_end = t_total * (blockIdx.x + 1) / gridDim.x;
+  while (t_next < t_end) {
+    const int blk = (int)(t_next / p.pairs);
+    int pj0 = (int)(t_next - (long)blk * p.pairs);
+    int r0 = 0, nrow = (H + d - 1) / d;                   // rows of comb r0
+    while (pj0 >= (nrow + 1) / 2) { pj0 -= (nrow + 1) / 2; ++r0; nrow = (H - r0 + d - 1) / d; }
+    const int pj1 = (int)min((long)((nrow + 1) / 2), pj0 + (t_end - t_next));
+    t_next += pj1 - pj0;
+    const int j0 = 2 * pj0, j1 = min(2 * pj1, nrow);
+    const int seg = blk % p.nseg;
+    const int b = blk / p.nseg;
+    const int x_new = 64 * seg;
+    const int x0 = min(x_new, W - 64);
+    const int dup = x_new - x0;                           // columns below `dup` were counted by the neighbouring segment
+    const long img = (long)b * p.g.Hp;
+
+    // DMA job i of a tile whose first comb row is jt: i < 20: chunk i % 10 of x row jt + 2 + i / 10 (the two NEW rows of the
+    // tile: its input rows are jt-1 .. jt+2); else chunk (i-20) % 8 of g_z row jt + (i-20) / 8.  Rows outside the image or the
+    // piece's g_z range come from the zero halo row above the image.
+    auto issue = [&](int jt, int i) {
+      if (i < 20) {
+        const int jj = jt + 2 + i / 10 - 1, c = i % 10;     // comb row jt+1 or jt+2 -> see the caller: x rows are issued as (jt+1, jt+2)
+        const int yy = r0 + jj * d;
+        const int y = (yy >= 0 && yy < H) ? yy : -1;
+        const float* src = p.x + ((img + y + p.g.ph) * Wp + x0 - 8 + p.g.pw) * 32 + c * 256;
+        ww_dma_1kb(src, lane16, lds0 + (unsigned)(((jj + 1) & (WW_XSLOTS - 1)) * WW_XROW + c * WW_CHUNK));
+      } else {
+        const int i2 = i - 20, jj = jt + i2 / 8, c = i2 % 8;
+        const int yy = r0 + jj * d;
+        const int y = (jj < j1 && yy < H) ? yy : -1;
+        const float* src = p.gz + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32 + c * 256;
+        ww_dma_1kb(src, lane16, lds0 + (unsigned)(WW_G_OFF + ((jt >> 1) % 3) * WW_GBUF + (i2 / 8) * WW_GROW + c * WW_CHUNK));
+      }
+    };
+    // ---- run-in: x rows j0-1 .. j0+2 and the g_z pair of tile j0 ----
+    // (x rows of `issue(jt, .)` are jt+1, jt+2: jt = j0-2 brings j0-1, j0; jt = j0 brings j0+1, j0+2)
+    for (int i = RW; i < 20; i += 4) issue(j0 - 2, i);
+    for (int i = RW; i < 36; i += 4) issue(j0, i);
+    if (j0 + 2 < j1) {                                     // the second tile's rows stay in flight (9 jobs per wave)
+      for (int i = RW; i < 36; i += 4) issue(j0 + 2, i);
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    for (int j = j0; j < j1; j += 2) {
+      // the rows of the tile after next: x rows j+5, j+6 into the two slots nobody reads or awaits, g_z pair into the third buffer
+      const bool ahead = j + 4 < j1;
+      if (ahead) for (int i = RW; i < 36; i += 4) issue(j + 4, i);
+      // input row m of the tile = comb row j-1+m = slot (j+m) & 7
+      const char* xa_row = smem + ((j + ra) & (WW_XSLOTS - 1)) * WW_XROW + lane_off;
+      const char* xb_row = smem + ((j + rb) & (WW_XSLOTS - 1)) * WW_XROW + lane_off;
+      const char* g_row = smem + WW_G_OFF + ((j >> 1) % 3) * WW_GBUF + lane_off;
+      float xa[2][4], xb[2][4], g0[2][2], g1[2][2];
+      auto load_step = [&](int s, float (&xa)[4], float (&xb)[4], float (&g0)[2], float (&g1)[2]) {
+        const int t0 = ww_tile<L>(s);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int off = ww_off(8 + ww_c0<L>(t0) + (m - 1) * d);
+          xa[m] = *reinterpret_cast<const float*>(xa_row + off);
+          xb[m] = *reinterpret_cast<const float*>(xb_row + off);
+        }
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) {
+          const int off = ww_off(ww_c0<L>(t0) + jc * d);
+          if (RW != 3) g0[jc] = *reinterpret_cast<const float*>(g_row + off);
+          if (RW != 0) g1[jc] = *reinterpret_cast<const float*>(g_row + WW_GROW + off);
+        }
+      };
+      load_step(0, xa[0], xb[0], g0[0], g1[0]);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (s + 1 < 16) load_step(s + 1, xa[(s + 1) & 1], xb[(s + 1) & 1], g0[(s + 1) & 1], g1[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int col0 = ww_c0<L>(ww_tile<L>(s));          // + lane_col: first column of this half's tile
+        float Gr[2];
+#pragma unroll
+        for (int jc = 0; jc < 2; ++jc) {
+          const bool counted = lane_col + col0 + jc * d >= dup;
+          const float u0 = (RW != 3 && counted) ? g0[s & 1][jc] : 0.f;
+          const float u1 = (RW != 0 && counted) ? g1[s & 1][jc] : 0.f;
+          if (RW == 1) bsum += u0 + u1;
+          Gr[jc] = RW == 0 ? u0 : (RW == 3 ? u1 : (RW == 1 ? u0 + u1 : u0 - u1));   // (the factor 1/2 of rows 1, 2: at the end)
+        }
+        const float Gt[4] = {Gr[0], Gr[0] + Gr[1], Gr[0] - Gr[1], Gr[1]};          // (likewise for columns 1, 2)
+        float Rt[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Rt[m] = xa[s & 1][m] + sg * xb[s & 1][m];
+        const float V[4] = {Rt[0] - Rt[2], Rt[1] + Rt[2], Rt[2] - Rt[1], Rt[3] - Rt[1]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c], Gt[c], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the NEXT tile's rows are home when only the jobs issued at the top of this tile are outstanding (in-order retirement)
+      if (ahead) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                     // the next tile's rows are in place; this tile's are free
+    }
+  }
+
+  // ---- (M A) in the wave, A^T across the waves, slab ----
+  constexpr float sr = (RW == 1 || RW == 2) ? 0.5f : 1.f;
+  float* ex = reinterpret_cast<float*>(smem);             // [4 r][3 b][16][64] floats = 49,152 B (the x ring is done with)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float m0 = sr * acc[0][r], m1 = (0.5f * sr) * acc[1][r], m2 = (0.5f * sr) * acc[2][r], m3 = sr * acc[3][r];
+    ex[((RW * 3 + 0) * 16 + r) * 64 + lane] = (m0 + m1) + m2;
+    ex[((RW * 3 + 1) * 16 + r) * 64 + lane] = m1 - m2;
+    ex[((RW * 3 + 2) * 16 + r) * 64 + lane] = (m1 + m2) + m3;
+  }
+  __syncthreads();
+  float* out = p.partial + (long)blockIdx.x * 9 * 1024;
+  for (int o = RW; o < 9; o += 4) {
+    const int a = o / 3, bb = o - 3 * a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float t0 = ex[((0 * 3 + bb) * 16 + r) * 64 + lane], t1 = ex[((1 * 3 + bb) * 16 + r) * 64 + lane];
+      const float t2 = ex[((2 * 3 + bb) * 16 + r) * 64 + lane], t3 = ex[((3 * 3 + bb) * 16 + r) * 64 + lane];
+      const float v = a == 0 ? (t0 + t1) + t2 : (a == 1 ? t1 - t2 : (t1 + t2) + t3);
+      const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[o * 1024 + ci * 32 + li] = v;
+    }
+  }
+  if (RW == 1) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0) p.partial_db[blockIdx.x * 32 + li] = bsum;
+  }
+}
+
+template <int L>
+__global__ __launch_bounds__(256, 1) void conv32_wino_wgrad_kernel(WgradWinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == 0) conv32_wino_wgrad_role<0, L>(p, smem_dyn);
+  else if (wave == 1) conv32_wino_wgrad_role<1, L>(p, smem_dyn);
+  else if (wave == 2) conv32_wino_wgrad_role<2, L>(p, smem_dyn);
+  else conv32_wino_wgrad_role<3, L>(p, smem_dyn);
+}
+
+int conv32_wino_wgrad_slabs(void) { return WW_GRID; }
+
+int conv32_wino_wgrad_launch(const float* x, const float* g_z, const as_pcl* g, const as_conv_shape* s, float* partial,
+                             float* partial_db, void* stream) {
+  static AsPerDevice attr_set[4];
+  const int L = s->dil == 1 ? 0 : (s->dil == 2 ? 1 : (s->dil == 4 ? 2 : 3));
+  const void* fn = L == 0 ? reinterpret_cast<const void*>(conv32_wino_wgrad_kernel<0>)
+                 : L == 1 ? reinterpret_cast<const void*>(conv32_wino_wgrad_kernel<1>)
+                 : L == 2 ? reinterpret_cast<const void*>(conv32_wino_wgrad_kernel<2>)
+                          : reinterpret_cast<const void*>(conv32_wino_wgrad_kernel<3>);
+  if (!attr_set[L].get()) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_BYTES);
+    if (e != hipSuccess) { as_set_error("as_conv32_wino_bwd: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
+    attr_set[L].set();
+  }
+  WgradWinoArgs a;
+  a.x = x; a.gz = g_z; a.partial = partial; a.partial_db = partial_db;
+  a.g = as_make_dev(g);
+  a.nseg = (g->W + 63) / 64;
+  long pairs = 0;
+  for (int r = 0; r < s->dil; ++r) pairs += ((g->H - r + s->dil - 1) / s->dil + 1) / 2;
+  a.pairs = (int)pairs;
+  void* kargs[] = {&a};
+  hipError_t le = hipLaunchKernel(fn, dim3(WW_GRID), dim3(256), kargs, WW_LDS_BYTES, (hipStream_t)stream);
+  if (le != hipSuccess) { as_set_error("as_conv32_wino_bwd: launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
+  return AS_OK;
+}

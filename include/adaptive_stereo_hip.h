@@ -164,6 +164,20 @@ int as_conv32_wino_fwd(const float* z_prev, const float* a_prevprev, const float
                        float* z, const as_pcl* gout, const as_conv_shape* s, float* stat_mean, float* stat_m2,
                        float* stat_cnt, void* stream);
 
+/* ---- backward of that layer by minimal filtering, two launches (csrc/conv32_wino.hip MODE 2, csrc/conv32_wino_wgrad.hip):
+ * arguments and results of as_conv32_bwd_fused (below), except
+ *   wino_wt    as_conv32_wino_pack_weights(w, out, transposed = 1) or a batch job of kind AS_PACK_WINO_T
+ *   g_z        a PCL buffer of the layer's geometry with a zero halo: receives the gradient w.r.t. the pre-activation
+ *   next_bn_workspace   as_conv32_wino_bwd_parts() partials of [64] doubles;  workspace: as_conv32_wino_bwd_workspace() floats */
+int as_conv32_wino_bwd_parts(void);
+int64_t as_conv32_wino_bwd_workspace(void);
+int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                       const as_conv_shape* s, const float* wino_wt, const float* scale, const float* shift,
+                       const float* mean, const float* coef, float slope, const float* next_z,
+                       const float* next_scale, const float* next_shift, const float* next_mean, float* g_z,
+                       float* g_x, float* dW, float* db, int accumulate, float* next_bn_workspace,
+                       float* workspace, void* stream);
+
 /* ---- a3, second generation: one 3x3x3 stride-1 32->32 aggregation layer (stereo_net.py:21-30,155-161,185-186) or its data
  * gradient, walking down the disparity axis with a rolling window of planes in LDS (csrc/agg3d.hip).
  *   x, z, a_out      PCL tensors of geometry g (halo 1 in d, h, w; as_agg3d_ok(g) == 1)

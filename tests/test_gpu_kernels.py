@@ -1089,6 +1089,89 @@ def test_conv32_backward_fused_in_one_launch(B, H, W, dil):
   from conftest import parity_note
   parity_note("bwd_fused[%s]" % tag, g_x_bit_identical=exact)
 
+@pytest.mark.parametrize("B,H,W,dil", [(2, 160, 1242, 1), (2, 161, 1242, 2), (1, 375, 1030, 4), (2, 163, 1237, 8)])
+def test_conv32_backward_by_minimal_filtering(B, H, W, dil):
+  """as_conv32_wino_bwd — the backward of as_conv32_bwd_fused as a data gradient F(2x2, 3x3) and a weight gradient F(3x3, 2x2)
+  — against the two-launch direct path (as_conv32_wgrad_bnapply, then as_conv32_fwd_bnbwd): g_z (stage 3 of the BatchNorm
+  backward, the by-product) bit for bit; g_x and dW are different associations of the same sums, so they are held against the
+  fp64 results computed from the SAME fp32 g_z, where they must not be further away than 2x the direct kernels are; db and
+  the next BatchNorm's sums to summation order.  Ragged last segment, every dilation, odd comb lengths."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_wino_ok(g, g, shape) == 1
+  x = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=1).to(DEV), g)
+  g_a = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=2).to(DEV), g)
+  z = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=3).to(DEV), g)
+  zn = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=4).to(DEV), g)
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  wp_t = ops.pack_weights(w, shape, True)
+  ww_t = torch.empty(16 * 1024, device=DEV)
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww_t), 1, nat.stream())
+
+  def state(seed):
+    st = ops.BnState(DEV)
+    st.mean.copy_(rnd(32, seed=seed).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=seed + 1).abs().to(DEV) + 0.5)
+    gamma = (rnd(32, seed=seed + 2).abs() + 0.5).to(DEV)
+    st.scale.copy_(st.invstd * gamma); st.shift.copy_(rnd(32, seed=seed + 3).to(DEV) * 0.1 - st.mean * st.scale)
+    return st, gamma
+  st, gamma = state(5)
+  stn, gamman = state(15)
+  ws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  gg, gb = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+  nat.call("as_bn_act_bwd", nat.ptr(g_a), nat.ptr(z), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(st.mean),
+           nat.ptr(st.invstd), nat.ptr(gamma), 0.2, 1, None, nat.ptr(gg), nat.ptr(gb), 0, nat.ptr(ws), g, nat.stream())
+  coef = ws[lib.as_bn_bwd_coef_offset():]
+  # the direct path
+  gz_ref = ops.pcl_zeros(g, DEV)
+  dW_ref = torch.zeros(32, 32, 3, 3, device=DEV); db_ref = torch.zeros(32, device=DEV)
+  wws = torch.empty(lib.as_conv32_wgrad_workspace(g, g, shape), device=DEV)
+  nat.call("as_conv32_wgrad_bnapply", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(z), g, shape, nat.ptr(st.scale), nat.ptr(st.shift),
+           nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(gz_ref), nat.ptr(dW_ref), nat.ptr(db_ref), 0, nat.ptr(wws), nat.stream())
+  gx_ref, sums_ref = ops.conv32_dgrad_bnbwd(gz_ref, g, wp_t, shape, g_a, zn, stn)
+  _, ggn_ref, gbn_ref = ops.bn_act_bwd(gx_ref, zn, stn, gamman, g, True, sums=sums_ref)
+  # minimal filtering
+  gz, gx = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  dW = torch.zeros(32, 32, 3, 3, device=DEV); db = torch.zeros(32, device=DEV)
+  nws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  fws = torch.empty(lib.as_conv32_wino_bwd_workspace(), device=DEV)
+  def run(acc):
+    nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(z), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(stn.scale), nat.ptr(stn.shift),
+             nat.ptr(stn.mean), nat.ptr(gz), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), acc, nat.ptr(nws), nat.ptr(fws), nat.stream())
+  run(0)
+  tag = "wino bwd B%d H%d W%d d%d" % (B, H, W, dil)
+  for name, got in (("g_z", gz), ("g_x", gx)):
+    full = ops.pcl_view(got, g).clone(); ops.pcl_interior(full, g).zero_()
+    assert float(full.abs().max()) == 0.0, tag + ": %s written into the halo" % name
+  assert bool(torch.equal(ops.pcl_interior(ops.pcl_view(gz, g), g), ops.pcl_interior(ops.pcl_view(gz_ref, g), g))), tag + " g_z"
+  # fp64 from the same fp32 g_z (CPU)
+  gz64 = ops.pcl_to_ncdhw(gz_ref, g)[:, :, 0].double().cpu()
+  x64 = ops.pcl_to_ncdhw(x, g)[:, :, 0].double().cpu()
+  ga64 = ops.pcl_to_ncdhw(g_a, g)[:, :, 0].double().cpu()
+  w64 = w.double().cpu()
+  gx64 = torch.nn.functional.conv_transpose2d(gz64, w64, padding=dil, dilation=dil) + ga64
+  dW64 = torch.nn.grad.conv2d_weight(x64, w64.shape, gz64, padding=dil, dilation=dil)
+  gx_got = ops.pcl_to_ncdhw(gx, g)[:, :, 0].double().cpu(); gx_dir = ops.pcl_to_ncdhw(gx_ref, g)[:, :, 0].double().cpu()
+  e_w, e_d = float((gx_got - gx64).abs().max()), float((gx_dir - gx64).abs().max())
+  r_w, r_d = float((gx_got - gx64).pow(2).mean().sqrt()), float((gx_dir - gx64).pow(2).mean().sqrt())
+  scale = float(gx64.abs().max())
+  assert e_d <= 2e-6 * scale and e_w <= max(2.0 * e_d, 1e-6 * scale) and r_w <= 2.0 * r_d, (tag, e_w, e_d, r_w, r_d, scale)
+  dw_w = float((dW.double().cpu() - dW64).norm() / dW64.norm()); dw_d = float((dW_ref.double().cpu() - dW64).norm() / dW64.norm())
+  assert dw_d < 2e-5 and dw_w <= max(2.0 * dw_d, 2e-6), (tag, dw_w, dw_d)
+  db64 = gz64.sum(dim=(0, 2, 3))
+  assert float((db.double().cpu() - db64).norm() / db64.norm()) < 2e-5
+  n = B * H * W
+  _, ggn, gbn = ops.bn_act_bwd(gx, zn, stn, gamman, g, True, sums=ops.BnBwdSums(nws, lib.as_conv32_wino_bwd_parts()))
+  close(ggn, ggn_ref, 2e-6 * n ** 0.5 * float(ggn_ref.abs().max()) + 1e-5, 1e-5, tag + " next g_gamma")
+  close(gbn, gbn_ref, 2e-6 * n ** 0.5 * float(gbn_ref.abs().max()) + 1e-5, 1e-5, tag + " next g_beta")
+  run(1)                                                   # accumulate flavour: a second launch adds the same gradient again
+  close(dW, 2 * dW_ref, 1e-4 * float(dW_ref.abs().max()), 1e-4, tag + " accumulated dW")
+  from conftest import parity_note
+  parity_note("conv32_wino_bwd[%s]" % tag, g_z_bit_identical=True, g_x_max_err_vs_fp64=e_w, direct_g_x_max_err_vs_fp64=e_d,
+              g_x_rms_err_vs_fp64=r_w, direct_g_x_rms_err_vs_fp64=r_d, dW_rel_l2_vs_fp64=dw_w, direct_dW_rel_l2_vs_fp64=dw_d)
+
+
 # ----------------------------------------------------------------------------- a7 forward with the previous BN + LReLU on the way in
 @pytest.mark.parametrize("B,H,W,dil,skip", [(2, 160, 1242, 1, True), (2, 161, 1242, 2, True), (1, 375, 1030, 4, True),
                                             (2, 163, 1237, 8, True), (4, 97, 700, 1, False)])

@@ -40,3 +40,36 @@ for dil in (1, 2, 4, 8):
       us = e0.elapsed_time(e1) * 1e3 / 20
       print("B%d d%d %-5s %-4s %8.1f us  %6.1f TFLOP/s algorithmic (%.3f of 157.3)" % (B, dil, "skip" if skip else "plain", name, us,
             flops / us * 1e-6, flops / us * 1e-6 / 157.3), flush=True)
+
+# ---- backward: as_conv32_bwd_fused against as_conv32_wino_bwd (data gradient + weight gradient launches) ----
+g_a, zn = a_pp, z_prev
+x = ops.ncdhw_to_pcl(torch.randn(B, 32, 1, H, W, generator=gen).to(DEV), g)
+zz = ops.ncdhw_to_pcl(torch.randn(B, 32, 1, H, W, generator=gen).to(DEV), g)
+st.mean.fill_(0.05); st.invstd.fill_(1.0)
+coef = torch.full((96,), 0.01, device=DEV); coef[64:] = 1.0
+gz, gx = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+dW, db = torch.zeros(32, 32, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+nws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+ww_t = torch.empty(16 * 1024, device=DEV)
+nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww_t), 1, nat.stream())
+for dil in (1, 2, 4, 8):
+  shape = ops.conv_shape_2d(dil)
+  wp_t = ops.pack_weights(w, shape, True)
+  fws = torch.empty(max(lib.as_conv32_bwd_fused_workspace(), lib.as_conv32_wino_bwd_workspace()), device=DEV)
+  def run_fused():
+    nat.call("as_conv32_bwd_fused", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(wp_t), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(st.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 1, nat.ptr(nws), nat.ptr(fws), nat.stream())
+  def run_wino():
+    nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(st.mean), nat.ptr(gz), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 1, nat.ptr(nws), nat.ptr(fws), nat.stream())
+  for name, run in (("fused", run_fused), ("wino", run_wino)):
+    for _ in range(3): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print("B%d d%d backward %-5s %8.1f us (incl. the slab reduce)  %6.1f TFLOP/s algorithmic (%.3f of 157.3)" % (
+        B, dil, name, us, 2 * flops / us * 1e-6, 2 * flops / us * 1e-6 / 157.3), flush=True)
