@@ -64,7 +64,20 @@ struct WinoArgs {
   const float* n_shift;
   const float* n_mean;
   double* n_partial;       // [grid][64]: sum g_y, sum g_y * (z - mean) of the next BatchNorm
+#ifdef WN_TIMING_BUILD
+  long long* timing;       // diagnostic build only: [workgroup][wave][12] cycle counts per phase
+#endif
 };
+
+// Diagnostic build (make EXTRA=-DWN_TIMING_BUILD): every wave adds up the shader cycles it spends in each phase; a launch
+// with AS_WN_TIMING set dumps them to gpurun_out/wino_timing.bin (tests/tools/wino_microbench.py prints the averages).
+#ifdef WN_TIMING_BUILD
+#include <cstdio>
+#include <cstdlib>
+#define WN_T(slot) do { const long long now_ = clock64(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define WN_T(slot) do { } while (0)
+#endif
 
 __device__ inline void wn_load4(f32x4& v, const float* sbase, unsigned voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
@@ -153,6 +166,11 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
   const unsigned io_off2 = io_off + 4096u;                  // rows 8..15 of the accumulator layout: tiles +16 = 32 columns
   float st_c = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;      // BatchNorm moments of this lane's channel: shifted sums
 
+#ifdef WN_TIMING_BUILD
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+  const long long wall0 = wall_clock64();
+#endif
   const long t_total = (long)p.g.B * p.nseg * p.pairs;
   long t_next = t_total * blockIdx.x / gridDim.x;
   const long t_end = t_total * (blockIdx.x + 1) / gridDim.x;
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
       if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
     };
 
+    WN_T(0);
     // ---- run-in: activated rows j0-1 .. j0+2 (two pairs in flight; the loads of the second pair retire after the first's) ----
     {
       f32x4 qz[5], qa[5];
@@ -246,6 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
       convert_from(j0 + 1, qz, qa);
     }
     __syncthreads();
+    WN_T(1);
 
     for (int j = j0; j < j1; j += 2) {
       fetch_one(j + 3, p.zin, pz);                         // in flight during the matrix phase (the skip rows follow it:
@@ -290,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].w, R[c][4 * q + 3], acc[c], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      WN_T(2);
       // T[j] = (M[r] A)[j]: A^T = [1 1 1 0; 0 1 -1 -1]
       {
         char* xw = smem + WN_X_OFF + (wave * 2) * 4096 + lane * 16;
@@ -322,7 +343,9 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
 #undef WN_LD
         }
       }
+      WN_T(3);
       __syncthreads();                                     // B1: the T tiles are in place; nobody reads rows j-1, j any more
+      WN_T(4);
       // ---- Y[oi][oj] = (A^T T)[oi][oj]: waves (oi, oi+1, oi+2) with signs (+,+,+) / (+,-,-) ----
       f32x16 Y;
       {
@@ -336,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
           Y[4 * gq + 0] = yv.x + bias_v; Y[4 * gq + 1] = yv.y + bias_v; Y[4 * gq + 2] = yv.z + bias_v; Y[4 * gq + 3] = yv.w + bias_v;
         }
       }
+      WN_T(5);
       if constexpr (BWD) {
         // every load so far is home (operand rows, g_a / next-z at the output pixels); the stores below are younger
         asm volatile("s_waitcnt vmcnt(0)"
@@ -391,19 +415,31 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      WN_T(6);
       // the operand rows are home when only this tile's own stores are outstanding (vector memory retires in order)
       if constexpr (!BWD) {
         if (row_ok) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
         if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
       }
+      WN_T(7);
       convert_from(j + 3, pz, pa);
+      WN_T(8);
       __syncthreads();                                     // B2: activated rows j+3, j+4 are in place; the exchange is free
+      WN_T(9);
     }
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef WN_TIMING_BUILD
+  WN_T(10);
+  if (p.timing && lane == 0) {
+    long long* o = p.timing + ((long)blockIdx.x * 4 + wave) * 12;
+    for (int i = 0; i < 11; ++i) o[i] = tacc[i];
+    o[11] = wall_clock64() - wall0;
+  }
+#endif
   if constexpr (BWD) {
     // next-BatchNorm sums: 8 (wave, half) partials per channel -> one fp64 pair per workgroup
     float* scr = reinterpret_cast<float*>(smem);        // [8][2][32]
@@ -480,9 +516,24 @@ static int wn_launch(int mode, int L, const WinoArgs& a, const char* who, void* 
     attr_set[fi].set();
   }
   WinoArgs args = a;
+#ifdef WN_TIMING_BUILD
+  static long long* timing_buf = nullptr;
+  const size_t timing_bytes = (size_t)WN_GRID * 4 * 12 * 8;
+  if (!timing_buf) hipMalloc(&timing_buf, timing_bytes);
+  hipMemsetAsync(timing_buf, 0, timing_bytes, (hipStream_t)stream);
+  args.timing = timing_buf;
+#endif
   void* kargs[] = {&args};
   hipError_t le = hipLaunchKernel(fn, dim3(WN_GRID), dim3(256), kargs, WN_LDS_BYTES, (hipStream_t)stream);
   if (le != hipSuccess) { as_set_error("%s: launch failed: %s", who, hipGetErrorString(le)); return AS_ERR_LAUNCH; }
+#ifdef WN_TIMING_BUILD
+  if (getenv("AS_WN_TIMING")) {                            // dump THIS launch (synchronises: diagnostic build only)
+    hipStreamSynchronize((hipStream_t)stream);
+    void* hbuf = malloc(timing_bytes); hipMemcpy(hbuf, timing_buf, timing_bytes, hipMemcpyDeviceToHost);
+    char name[128]; snprintf(name, sizeof name, "gpurun_out/wino_timing_m%d.bin", mode);
+    FILE* f = fopen(name, "wb"); if (f) { fwrite(hbuf, 1, timing_bytes, f); fclose(f); } free(hbuf);
+  }
+#endif
   return AS_OK;
 }
 

@@ -51,9 +51,14 @@ __host__ __device__ constexpr int ww_off(int v) { return (v >> 3) * WW_CHUNK + (
 // tile of matrix step s, half 0 (half 1: + 1 for d > 1, + 4 for d = 1 — a voxel in the other bank half either way)
 template <int L> __host__ __device__ constexpr int ww_tile(int s) { return L == 0 ? (s & 3) + 8 * (s >> 2) : 2 * s; }
 
-template <int RW, int L>
+// RW: the wave's row of the transformed tiles; PART: which half of a tile's 16 matrix steps it takes (two waves per SIMD: one
+// wave's operand reads and transforms under the other's MFMAs — with one wave per SIMD the launch took 195-210 us where the
+// matrix work alone is 120-127)
+template <int RW, int PART, int L>
 __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, char* smem) {
   constexpr int d = 1 << L;
+  constexpr int W8 = PART * 4 + RW;                         // wave index: DMA jobs i = W8, W8 + 8, ..
+  constexpr int NJOB = W8 < 4 ? 5 : 4;                      // of a tile's 36 DMA jobs
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((ww_lds_t)smem));
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5, li = lane & 31;
@@ -111,11 +116,12 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
     };
     // ---- run-in: x rows j0-1 .. j0+2 and the g_z pair of tile j0 ----
     // (x rows of `issue(jt, .)` are jt+1, jt+2: jt = j0-2 brings j0-1, j0; jt = j0 brings j0+1, j0+2)
-    for (int i = RW; i < 20; i += 4) issue(j0 - 2, i);
-    for (int i = RW; i < 36; i += 4) issue(j0, i);
-    if (j0 + 2 < j1) {                                     // the second tile's rows stay in flight (9 jobs per wave)
-      for (int i = RW; i < 36; i += 4) issue(j0 + 2, i);
-      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    for (int i = W8; i < 20; i += 8) issue(j0 - 2, i);
+    for (int i = W8; i < 36; i += 8) issue(j0, i);
+    if (j0 + 2 < j1) {                                     // the second tile's rows stay in flight (NJOB jobs per wave)
+      for (int i = W8; i < 36; i += 8) issue(j0 + 2, i);
+      if constexpr (NJOB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -124,7 +130,9 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
     for (int j = j0; j < j1; j += 2) {
       // the rows of the tile after next: x rows j+5, j+6 into the two slots nobody reads or awaits, g_z pair into the third buffer
       const bool ahead = j + 4 < j1;
-      if (ahead) for (int i = RW; i < 36; i += 4) issue(j + 4, i);
+#ifndef WW_EXP_NODMA
+      if (ahead) for (int i = W8; i < 36; i += 8) issue(j + 4, i);
+#endif
       // input row m of the tile = comb row j-1+m = slot (j+m) & 7
       const char* xa_row = smem + ((j + ra) & (WW_XSLOTS - 1)) * WW_XROW + lane_off;
       const char* xb_row = smem + ((j + rb) & (WW_XSLOTS - 1)) * WW_XROW + lane_off;
@@ -145,11 +153,22 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
           if (RW != 0) g1[jc] = *reinterpret_cast<const float*>(g_row + WW_GROW + off);
         }
       };
-      load_step(0, xa[0], xb[0], g0[0], g1[0]);
+#ifndef WW_EXP_NOMFMA
+      load_step(8 * PART, xa[0], xb[0], g0[0], g1[0]);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        if (s + 1 < 16) load_step(s + 1, xa[(s + 1) & 1], xb[(s + 1) & 1], g0[(s + 1) & 1], g1[(s + 1) & 1]);
+      for (int s = 8 * PART; s < 8 * PART + 8; ++s) {
+#ifndef WW_EXP_NOLOAD
+        if (s + 1 < 8 * PART + 8) load_step(s + 1, xa[(s + 1) & 1], xb[(s + 1) & 1], g0[(s + 1) & 1], g1[(s + 1) & 1]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
+#ifdef WW_EXP_NOVALU
+        {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s & 1][c], xb[s & 1][c], acc[c], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
+#endif
         const int col0 = ww_c0<L>(ww_tile<L>(s));          // + lane_col: first column of this half's tile
         float Gr[2];
 #pragma unroll
@@ -169,16 +188,39 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c], Gt[c], acc[c], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
       // the NEXT tile's rows are home when only the jobs issued at the top of this tile are outstanding (in-order retirement)
-      if (ahead) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ahead) {
+        if constexpr (NJOB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __syncthreads();                                     // the next tile's rows are in place; this tile's are free
     }
   }
 
+  // ---- the two halves of the matrix steps: waves 4-7 hand their accumulators (and bias sums) to waves 0-3 ----
+  float* ex = reinterpret_cast<float*>(smem);             // (the x ring is done with) [4 r][4 c][16][64] floats = 65,536 B
+  if constexpr (PART == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ex[((RW * 4 + c) * 16 + r) * 64 + lane] = acc[c][r];
+    if (RW == 1) ex[16384 + lane] = bsum;
+  }
+  __syncthreads();
+  if constexpr (PART == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] += ex[((RW * 4 + c) * 16 + r) * 64 + lane];
+    if (RW == 1) bsum += ex[16384 + lane];
+  }
+  __syncthreads();
   // ---- (M A) in the wave, A^T across the waves, slab ----
   constexpr float sr = (RW == 1 || RW == 2) ? 0.5f : 1.f;
-  float* ex = reinterpret_cast<float*>(smem);             // [4 r][3 b][16][64] floats = 49,152 B (the x ring is done with)
+  if constexpr (PART == 0) {                               // [4 r][3 b][16][64] floats = 49,152 B
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float m0 = sr * acc[0][r], m1 = (0.5f * sr) * acc[1][r], m2 = (0.5f * sr) * acc[2][r], m3 = sr * acc[3][r];
@@ -186,9 +228,10 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
     ex[((RW * 3 + 1) * 16 + r) * 64 + lane] = m1 - m2;
     ex[((RW * 3 + 2) * 16 + r) * 64 + lane] = (m1 + m2) + m3;
   }
+  }
   __syncthreads();
   float* out = p.partial + (long)blockIdx.x * 9 * 1024;
-  for (int o = RW; o < 9; o += 4) {
+  for (int o = W8; o < 9; o += 8) {
     const int a = o / 3, bb = o - 3 * a;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -199,20 +242,26 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
       out[o * 1024 + ci * 32 + li] = v;
     }
   }
-  if (RW == 1) {
+  if (RW == 1 && PART == 0) {
     bsum += __shfl_xor(bsum, 32, 64);
     if (h == 0) p.partial_db[blockIdx.x * 32 + li] = bsum;
   }
 }
 
 template <int L>
-__global__ __launch_bounds__(256, 1) void conv32_wino_wgrad_kernel(WgradWinoArgs p) {
+__global__ __launch_bounds__(512, 1) void conv32_wino_wgrad_kernel(WgradWinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave == 0) conv32_wino_wgrad_role<0, L>(p, smem_dyn);
-  else if (wave == 1) conv32_wino_wgrad_role<1, L>(p, smem_dyn);
-  else if (wave == 2) conv32_wino_wgrad_role<2, L>(p, smem_dyn);
-  else conv32_wino_wgrad_role<3, L>(p, smem_dyn);
+  switch (wave) {
+    case 0: conv32_wino_wgrad_role<0, 0, L>(p, smem_dyn); break;
+    case 1: conv32_wino_wgrad_role<1, 0, L>(p, smem_dyn); break;
+    case 2: conv32_wino_wgrad_role<2, 0, L>(p, smem_dyn); break;
+    case 3: conv32_wino_wgrad_role<3, 0, L>(p, smem_dyn); break;
+    case 4: conv32_wino_wgrad_role<0, 1, L>(p, smem_dyn); break;
+    case 5: conv32_wino_wgrad_role<1, 1, L>(p, smem_dyn); break;
+    case 6: conv32_wino_wgrad_role<2, 1, L>(p, smem_dyn); break;
+    default: conv32_wino_wgrad_role<3, 1, L>(p, smem_dyn); break;
+  }
 }
 
 int conv32_wino_wgrad_slabs(void) { return WW_GRID; }
@@ -238,7 +287,7 @@ int conv32_wino_wgrad_launch(const float* x, const float* g_z, const as_pcl* g, 
   for (int r = 0; r < s->dil; ++r) pairs += ((g->H - r + s->dil - 1) / s->dil + 1) / 2;
   a.pairs = (int)pairs;
   void* kargs[] = {&a};
-  hipError_t le = hipLaunchKernel(fn, dim3(WW_GRID), dim3(256), kargs, WW_LDS_BYTES, (hipStream_t)stream);
+  hipError_t le = hipLaunchKernel(fn, dim3(WW_GRID), dim3(512), kargs, WW_LDS_BYTES, (hipStream_t)stream);
   if (le != hipSuccess) { as_set_error("as_conv32_wino_bwd: launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
   return AS_OK;
 }

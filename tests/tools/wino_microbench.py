@@ -22,7 +22,8 @@ a_out, z = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
 ww = torch.empty(16 * 1024, device=DEV)
 nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww), 0, nat.stream())
 flops = 2.0 * B * H * W * 1024 * 9
-for dil in (1, 2, 4, 8):
+ONLY_BWD = os.environ.get("WMB_ONLY") == "bwd"
+for dil in (() if ONLY_BWD else (1, 2, 4, 8)):
   shape = ops.conv_shape_2d(dil)
   wp = ops.pack_weights(w, shape, False)
   for skip in (True, False):
@@ -64,7 +65,7 @@ for dil in (1, 2, 4, 8):
     nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
              nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(gz), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 1, nat.ptr(nws), nat.ptr(fws), nat.stream())
-  for name, run in (("fused", run_fused), ("wino", run_wino)):
+  for name, run in ((("wino", run_wino),) if ONLY_BWD else (("fused", run_fused), ("wino", run_wino))):
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
