@@ -910,11 +910,11 @@ extern "C" int as_conv32_wino_fwd(const float* z_prev, const float* a_prevprev, 
   AS_CHECK_ARG(a_out != z_prev && a_out != a_prevprev && z != z_prev && z != a_out && z != a_prevprev,
                "as_conv32_wino_fwd: outputs must not alias inputs or each other");
   hipStream_t st = (hipStream_t)stream;
-  as_prof_mark(AS_PROF_CONV_ACT, st, 1, 0.0);
+  as_prof_mark(AS_PROF_WINO_FWD, st, 1, 0.0);
   if (int e = conv32_wino_launch(z_prev, a_prevprev, in_scale, in_shift, a_out, gout, s, wino_w, bias, slope, z, stat_mean,
                                  stat_m2, stat_cnt, stream)) return e;
   // (ALGORITHMIC flops: the direct form's 9 taps — what the layer computes, not the 4 products per pixel it executes)
-  as_prof_mark(AS_PROF_CONV_ACT, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
+  as_prof_mark(AS_PROF_WINO_FWD, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * 9);
   AS_CHECK_LAUNCH("as_conv32_wino_fwd");
   return AS_OK;
 }
@@ -943,12 +943,14 @@ extern "C" int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float
   const int slabs = conv32_wino_wgrad_slabs();
   float* partial_db = workspace + (int64_t)slabs * T * 1024;
   hipStream_t st = (hipStream_t)stream;
-  as_prof_mark(AS_PROF_BWD_FUSED, st, 1, 0.0);
+  // (ALGORITHMIC flops of each gradient in its direct form, as as_conv32_bwd_fused counts them)
+  as_prof_mark(AS_PROF_WINO_DGRAD, st, 1, 0.0);
   if (int e = conv32_wino_dgrad_launch(g_a, z, gout, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift,
                                        next_mean, g_z, g_x, reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
+  as_prof_mark(AS_PROF_WINO_DGRAD, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);
+  as_prof_mark(AS_PROF_WINO_WGRAD, st, 1, 0.0);
   if (int e = conv32_wino_wgrad_launch(x, g_z, gout, s, workspace, partial_db, stream)) return e;
-  // (ALGORITHMIC flops of both gradients in their direct form, as as_conv32_bwd_fused)
-  as_prof_mark(AS_PROF_BWD_FUSED, st, 0, 2.0 * 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);
+  as_prof_mark(AS_PROF_WINO_WGRAD, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);
   AS_CHECK_LAUNCH("as_conv32_wino_bwd");
   wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
   AS_CHECK_LAUNCH("as_conv32_wino_bwd(reduce)");

@@ -238,10 +238,13 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
           yv.z = fmaxf(yv.z, ys.z); yv.w = fmaxf(yv.w, ys.w);
           if (SKIP) yv += pa[k];
         }
-        yv = (row_in && xx >= 0 && xx < W) ? yv : (f32x4){0.f, 0.f, 0.f, 0.f};
+        // halo voxels (v < 8, v >= 72: only they can lie outside the image) are whole waves of a chunk: a uniform branch
+        const bool halo = (k == 0 && wave == 0) || (k == 2 && (wave == 1 || wave == 2)) || (k == 4 && wave == 3);
+        if (!row_in) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        else if (halo) yv = (xx >= 0 && xx < W) ? yv : (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * WN_ROW_BYTES + wn_addr<L>(v, t & 7)) = yv;
         const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
-        if (own && v >= 8 && v < 8 + WN_SEG) {
+        if (own && !halo) {
           float* aout = p.a_out + ((img + y + p.g.ph) * Wp + px0) * 32;
           wn_store4(aout, (unsigned)(v * 128 + c4 * 4), yv);
         }
@@ -332,6 +335,8 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
       if (SKIP) fetch_one(j + 3, p.ain, pa);               // (the accumulators are dead: registers to spare)
       const int yrow = j + oi;
       const bool row_ok = yrow < j1;                       // (wave-uniform) the pair's second row may lie outside the piece
+      int dup_l = dup;                                     // (opaque: hipcc otherwise hoists the 16 duplicate-column masks of
+      asm volatile("" : "+s"(dup_l));                      //  the last segment out of the tile loop, into 16 registers)
 #define WN_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
       float res[16], zt[16];                                // data gradient: g_a (skip connection) and the next layer's
       if constexpr (BWD) {                                  // pre-activation at this wave's output pixels
@@ -383,9 +388,9 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
           for (int r = 0; r < 16; ++r) {
             const float yv = fmaf(zt[r], bn_sc, bn_sh);
             float gy = yv > 0.f ? Y[r] : Y[r] * p.slope;
-            if (dup > 0) {
+            if (dup_l > 0) {
               const int col = wn_c0<L>((r & 3) + 8 * (r >> 2)) + wn_c0<L>(4 * h) + oj * d;
-              gy = col >= dup ? gy : 0.f;
+              gy = col >= dup_l ? gy : 0.f;
             }
             bn_dy += gy; bn_dx = fmaf(gy, zt[r] - bn_mu, bn_dx);
           }
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         WN_FOR_8(WN_ST)
 #undef WN_ST
         if (p.ep.stat_mean != nullptr) {
-          if (dup <= 0) {
+          if (dup_l <= 0) {
             st_c = st_n == 0.f ? Y[0] : st_c;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float dd = Y[r] - st_c; st_s1 += dd; st_s2 = fmaf(dd, dd, st_s2); }
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int col = wn_c0<L>((r & 3) + 8 * (r >> 2)) + wn_c0<L>(4 * h) + oj * d;
-              const bool in = col >= dup;
+              const bool in = col >= dup_l;
               const float dd = in ? Y[r] - st_c : 0.f;
               st_s1 += dd; st_s2 = fmaf(dd, dd, st_s2); st_n += in ? 1.f : 0.f;
             }

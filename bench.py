@@ -314,7 +314,7 @@ def main():
   if not use_graph:
     t_adapt = min(t_adapt, t_adapt_eager)
   prof = []
-  for kid in range(24):
+  for kid in range(27):
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     nat.call("as_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
     prof.append((n.value, ms.value, fl.value))
@@ -362,16 +362,36 @@ def main():
     return {"kernel": "conv32_lds_kernel", "achieved": round(fl_f / (ms_f * 1e-3) / 1e12, 3), "launches": n_f,
             "avg_launch_us": round(1e3 * ms_f / n_f, 2), "flops_per_launch": fl_f / n_f}
   fam_entry = entry_family()
-  fused_entry = entry(22, "conv32_bwd_fused_kernel")
-  # the dominant kernel is the one a step spends most time in: since the full-resolution backward is one launch
-  # (conv32_bwd_fused_kernel, id 22: data gradient + weight gradient = 2 x the forward's FLOPs per launch) that is it
-  fused_is_dom = fused_entry is not None and (fam_entry is None or prof[22][1] > ms_f)
-  dom = fused_entry if fused_is_dom else fam_entry
+  # The dominant kernel is the one a step spends most time in.  Candidates: the full-resolution layers' kernels — by minimal
+  # filtering (ids 24-26: data gradient, weight gradient, forward; conv32_wino*.hip), in their direct form (22, 23) — and the
+  # conv32_lds family.  For a minimal-filtering kernel `achieved` still counts the ALGORITHMIC FLOPs of the layer (SURVEY 8d:
+  # 2 x voxels x 32 x 32 x 9, what the direct form executes), `executed` what the matrix pipe actually does (4/9 of them).
+  NAMES = {
+      24: ("conv32_wino_kernel<2, L>", "conv32_wino_kernel<2, 0>", 5,
+           "data gradient of a full-resolution layer by minimal filtering F(2x2,3x3): stage 3 of the BatchNorm backward on the way "
+           "in (g_z written once), skip connection, next BatchNorm's sums"),
+      25: ("conv32_wino_wgrad_kernel<L>", "conv32_wino_wgrad_kernel<0>", 2,
+           "weight / bias gradient of a full-resolution layer by minimal filtering F(3x3,2x2) from x and g_z (LDS-DMA rows)"),
+      26: ("conv32_wino_kernel<0|1, L>", "conv32_wino_kernel<1, 0>", 4,
+           "full-resolution training forward by minimal filtering F(2x2,3x3): previous BatchNorm + LeakyReLU + skip applied on the "
+           "way in, by-product written back, raw output + moments"),
+      22: ("conv32_bwd_fused_kernel", "conv32_bwd_fused_kernel", 5,
+           "full-resolution layer backward in one launch, direct form: BatchNorm-backward apply, data gradient + skip, weight "
+           "gradient, next BatchNorm's sums"),
+      23: ("conv32_act_kernel", "conv32_act_kernel<true>", 4,
+           "full-resolution training forward, direct form: previous BatchNorm + LeakyReLU + skip applied on the way in, by-product "
+           "written back, raw output + moments"),
+  }
+  cands = [(prof[i][1], i) for i in NAMES if prof[i][0] > 0 and prof[i][1] > 0]
+  if fam_entry is not None:
+    cands.append((ms_f, -1))
+  dom_id = max(cands)[1] if cands else None
+  dom = None if dom_id is None else (fam_entry if dom_id == -1 else entry(dom_id, NAMES[dom_id][0]))
   roofline = None
   if dom is not None:
-    # HBM bytes per launch from the committed PMC passes (profiles/r02_pmc_by_pairs.json, keyed by pairs per launch;
-    # FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes).  `traffic` is the dominant kernel's; the
-    # forward / data-gradient flavours of conv32_lds_kernel and the 3-D kernels are in traffic_detail.
+    # HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_by_pairs.json, keyed by pairs per launch;
+    # FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes).  `traffic` is the dominant kernel's; the other
+    # full-resolution kernels and the 3-D kernels are in traffic_detail.
     traffic, traffic_detail, traffic_source = None, None, None
     rec = None
     # the newest committed PMC file wins (rocprofv3 --pmc passes cannot run inside this timed process: the counters come
@@ -396,13 +416,13 @@ def main():
                                        "traffic_over_algorithmic": v["traffic_over_algorithmic"],
                                        "mfma_busy": v["mfma_busy_fraction_of_simd_cycles"]}
       scale = 1.0 if traffic_source is None or traffic_source["exact"] else B / float(traffic_source["pairs_per_launch_measured"])
-      if fused_is_dom and "conv32_bwd_fused_kernel" in ks:
-        traffic = int(ks["conv32_bwd_fused_kernel"]["hbm_bytes_per_launch"] * scale)
-      elif not fused_is_dom and "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
-        traffic = int((ks["conv32_lds_kernel<0, false>"]["hbm_bytes_per_launch"] + ks["conv32_lds_kernel<3, true>"]["hbm_bytes_per_launch"]) / 2 * scale)
+      if dom_id == -1:
+        if "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
+          traffic = int((ks["conv32_lds_kernel<0, false>"]["hbm_bytes_per_launch"] + ks["conv32_lds_kernel<3, true>"]["hbm_bytes_per_launch"]) / 2 * scale)
+      elif NAMES[dom_id][1] in ks:
+        traffic = int(ks[NAMES[dom_id][1]]["hbm_bytes_per_launch"] * scale)
       traffic_detail = {"pairs_per_launch": rec.get("pairs_per_launch"),
-                        "backward_fused": pmc_row("conv32_bwd_fused_kernel"),
-                        "forward_with_activation_on_the_way_in": pmc_row("conv32_act_kernel<true>"),
+                        "full_resolution_layers": {NAMES[i][1]: pmc_row(NAMES[i][1]) for i in NAMES if NAMES[i][1] in ks},
                         "forward": pmc_row("conv32_lds_kernel<0, false>"),
                         "dgrad_with_skip_and_bn_sums": pmc_row("conv32_lds_kernel<3, true>"),
                         "cost_aggregation_3d": {k: pmc_row(k) for k in ks if k.startswith(("agg3d", "agg_tail", "conv3d"))}}
@@ -410,17 +430,41 @@ def main():
                 "unit": "TFLOP/s", "frac": round(dom["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": traffic_source,
                 "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
-                "flops_per_launch": dom["flops_per_launch"], "traffic_detail": traffic_detail,
-                "flavours": [e for e in (entry(22, "conv32_bwd_fused_kernel (full-resolution layer backward in one launch: BatchNorm-backward apply, data gradient + skip, weight gradient, next BatchNorm's sums)"),
-                                         entry(23, "conv32_act_kernel (full-resolution training forward: previous BatchNorm + LeakyReLU + skip applied on the way in, by-product written back, raw output + moments)"),
-                                         entry(2, "conv32_lds_kernel<0,false> (training forward: raw output + BatchNorm moments)"),
-                                         entry(6, "conv32_lds_kernel<3,true> (data gradient + skip + stage 1 of the next BatchNorm backward)"))
-                             if e is not None],
-                "other_mfma_kernels": [e for e in (entry(3, "conv32_wgrad_lds_kernel"),
+                "flops_per_launch": dom["flops_per_launch"]}
+    vox_bytes = float(B) * args.height * args.width * 128.0
+    def wino_views(i, e):
+      """What a minimal-filtering kernel executes on the matrix pipe and moves through HBM, beside its algorithmic rate."""
+      t = e["avg_launch_us"] * 1e-6
+      ex = e["flops_per_launch"] * 4.0 / 9.0
+      alg_bytes = NAMES[i][2] * vox_bytes
+      return {"algorithm": "minimal filtering (Winograd) F(2x2,3x3) / F(3x3,2x2): 16 multiplications per 2x2 tile and channel pair "
+                           "where the direct form has 36 — the matrix pipe executes 4/9 of the algorithmic FLOPs",
+              "executed_mfma": {"flops_per_launch": ex, "achieved": round(ex / t / 1e12, 2), "frac": round(ex / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+              "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved": round(alg_bytes / t / 1e9, 1), "peak": 8000.0,
+                      "unit": "GB/s", "frac": round(alg_bytes / t / 8e12, 4)}}
+    if dom_id in (24, 25, 26):
+      roofline.update(wino_views(dom_id, dom))
+      roofline["note"] = ("frac = algorithmic FLOPs of the layer (direct form, SURVEY 8d) / time / fp32 matrix peak; the kernel reaches it "
+                          "with 4/9 of the multiplications, so executed_mfma and hbm show how close the matrix pipe and HBM themselves are")
+    roofline["traffic_detail"] = traffic_detail
+    flav = []
+    for i in (24, 25, 26, 22, 23):
+      e = entry(i, "%s (%s)" % (NAMES[i][0], NAMES[i][3]))
+      if e is not None:
+        if i in (24, 25, 26):
+          e.update({k_: v for k_, v in wino_views(i, e).items() if k_ != "algorithm"})
+        flav.append(e)
+    for i, nm in ((2, "conv32_lds_kernel<0,false> (training forward: raw output + BatchNorm moments)"),
+                  (6, "conv32_lds_kernel<3,true> (data gradient + skip + stage 1 of the next BatchNorm backward)")):
+      e = entry(i, nm)
+      if e is not None:
+        flav.append(e)
+    roofline["flavours"] = flav
+    roofline["other_mfma_kernels"] = [e for e in (entry(3, "conv32_wgrad_lds_kernel"),
                                                    entry(7, "agg3d_kernel (a3: rolling-window 3-D aggregation layers and their data gradients)"),
                                                    entry(9, "conv3d_wgrad_lds_kernel (a3 weight gradient)"),
                                                    entry(0, "conv32_fwd_kernel<taps> (strided, small 2-D)"),
-                                                   entry(1, "conv32_wgrad_kernel<taps>")) if e is not None]}
+                                                   entry(1, "conv32_wgrad_kernel<taps>")) if e is not None]
     # the HBM-bound passes of the step, against the 8 TB/s HBM3E peak (algorithmic bytes / HIP-event time)
     def hbm_entry(i, name):
       n, ms, by = prof[i]

@@ -53,6 +53,23 @@ if lib.as_conv32_act_ok(g, g, shape) == 1:
   for _ in range(5):
     nat.call("as_conv32_act_fwd", nat.ptr(zb), nat.ptr(x), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a_by), g, nat.ptr(wp),
              nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats_a.mean), nat.ptr(stats_a.m2), nat.ptr(stats_a.cnt), nat.stream())
+# the same layers by minimal filtering (what a step launches when as_conv32_wino_ok): forward with / without skip input,
+# data gradient (conv32_wino_kernel<2, 0>) + weight gradient (conv32_wino_wgrad_kernel<0>)
+if lib.as_conv32_wino_ok(g, g, shape) == 1:
+  ww, ww_t = torch.empty(16 * 1024, device=dev), torch.empty(16 * 1024, device=dev)
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww), 0, nat.stream())
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww_t), 1, nat.stream())
+  stats_w = ops.StatParts(lib.as_conv32_wino_parts(), dev)
+  a_by = torch.zeros(g.numel(), device=dev)
+  gzw = torch.zeros(g.numel(), device=dev)
+  fws_w = torch.empty(lib.as_conv32_wino_bwd_workspace(), device=dev)
+  for _ in range(5):
+    for skip in (x, None):
+      nat.call("as_conv32_wino_fwd", nat.ptr(zb), nat.ptr(skip), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a_by), g, nat.ptr(ww),
+               nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats_w.mean), nat.ptr(stats_w.m2), nat.ptr(stats_w.cnt), nat.stream())
+    nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(gzo), nat.ptr(z), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zb), nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(st.mean), nat.ptr(gzw), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(bws2), nat.ptr(fws_w), nat.stream())
 # a3: one 3-D cost-aggregation layer: rolling-window forward (plain, with moments, with the previous BatchNorm merged and
 # applied in LDS + by-product), the fused tail (a4 + a5 + a8) and the LDS weight gradient
 g3 = Pcl(B, 12, 24, 78, 1, 1, 1)

@@ -25,6 +25,10 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv32_wgrad_lds2_kernel<true>": 4 * vox * 128,        # x, g_a, z read; g_z written (fused BN-backward apply)
        "conv32_act_kernel<true>": 4 * vox * 128,               # z_prev, a_prevprev read; a_prev (by-product), z written
        "conv32_bwd_fused_kernel": 5 * vox * 128,               # x, g_a, z, z_next read; g_x written (2 x the flops)
+       "conv32_wino_kernel<1, 0>": 4 * vox * 128,              # minimal filtering: z_prev, a_prevprev read; a_prev, z written
+       "conv32_wino_kernel<0, 0>": 3 * vox * 128,              # ... no skip input
+       "conv32_wino_kernel<2, 0>": 5 * vox * 128,              # g_a, z, z_next read; g_z (by-product), g_x written
+       "conv32_wino_wgrad_kernel<0>": 2 * vox * 128,           # x, g_z read
        "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128,
        "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128,
        "agg3d_kernel<0, 2>": 2 * vox3 * 128 + 27 * 4096, "agg3d_kernel<0, 0>": 2 * vox3 * 128 + 27 * 4096,
