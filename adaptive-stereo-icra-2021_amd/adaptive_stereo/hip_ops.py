@@ -185,7 +185,8 @@ def flush_deferred_reductions():
 _TAIL_BNSUMS = True        # conv2d_out's data gradient also sums for the last block's BatchNorm backward
 _HEAD_PROJ = True          # conv2d_feature backward: per-tap projections instead of g_z
 _FWD_ACT = True            # full-resolution training forward: previous BatchNorm + LeakyReLU applied on the way in
-_WINOGRAD = True           # ... and its 3x3 convolution by the minimal-filtering algorithm F(2x2, 3x3) (csrc/conv32_wino.hip)
+_WINOGRAD = os.environ.get("AS_DIAG_DIRECT_FORM") != "1"   # ... and its 3x3 convolution by the minimal-filtering algorithm
+                           # F(2x2, 3x3) (csrc/conv32_wino.hip); the variable is for A/B diagnostics, set_winograd() the API
 # (module switches, each with a setter: tests/test_gpu_end_to_end.py runs both routes and compares them; timing A/B of a
 # route is a tool's business — tests/tools/ab_switch.py — not the environment's)
 
@@ -208,10 +209,15 @@ def set_fwd_act(enabled):
   return prev
 
 
-def set_winograd(enabled):
-  """False: the full-resolution training forward keeps the direct form (as_conv32_act_fwd).  Returns the previous setting."""
-  global _WINOGRAD
+_WINOGRAD_BWD = True       # (diagnostics: False keeps the direct fused backward while the forward uses minimal filtering)
+
+
+def set_winograd(enabled, backward=None):
+  """False: the full-resolution layers keep the direct form (as_conv32_act_fwd, as_conv32_bwd_fused, as_conv32_fwd).
+  ``backward`` (default: same as ``enabled``) switches the two backward launches separately.  Returns the previous setting."""
+  global _WINOGRAD, _WINOGRAD_BWD
   prev, _WINOGRAD = _WINOGRAD, bool(enabled)
+  _WINOGRAD_BWD = bool(enabled if backward is None else backward)
   return prev
 
 
@@ -639,7 +645,8 @@ def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train,
   """Returns (z or None, a, BnState).  train: batch statistics (+ running-stat update);
   otherwise running statistics, fused into the convolution epilogue when z is not needed."""
   dev = x.device
-  wp = pack_weights(w, shape, False)
+  wino_eval = (not train) and (not keep_z) and _WINOGRAD and nat.load().as_conv32_wino_ok(g, g, shape) == 1
+  wp = None if wino_eval else pack_weights(w, shape, False)
   if train:
     stats = conv32_stat_parts(g, g, shape, dev)
     z = conv32(x, g, wp, b, g, shape, stats=stats)
@@ -650,6 +657,15 @@ def block_forward(x, g: Pcl, shape: ConvShape, w, b, gamma, beta, rm, rv, train,
     if keep_z:
       z = conv32(x, g, wp, b, g, shape)
       a = bn_act(z, st, g, residual=x if skip else None)
+    elif wino_eval:
+      # inference: the block in one launch by minimal filtering (csrc/conv32_wino.hip MODE 3) — 4 matrix products per pixel
+      # instead of 9, x read once (the skip connection comes out of the staged rows)
+      z = None
+      ww = pack_special(w, PACK_WINO, 16, 16 * 1024,
+                        lambda w_, o_: call("as_conv32_wino_pack_weights", ptr(w_), ptr(o_), 0, stream()))
+      a = POOL.get(g, x.device)
+      call("as_conv32_wino_eval", ptr(x), g, shape, ptr(ww), ptr(b), ptr(st.scale), ptr(st.shift), LEAKY_SLOPE, 1 if skip else 0,
+           ptr(a), stream())
     else:
       z = None
       a = conv32(x, g, wp, b, g, shape, epilogue=1, scale=st.scale, shift=st.shift, residual=x if skip else None)
@@ -705,7 +721,7 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
     g_x = POOL.get(g, dev)
     nws = _empty(lib.as_bn_bwd_workspace(g), dev)
     next_z, next_st = next_bn
-    if _WINOGRAD and lib.as_conv32_wino_ok(g, g, shape) == 1:
+    if _WINOGRAD and _WINOGRAD_BWD and lib.as_conv32_wino_ok(g, g, shape) == 1:
       # both gradients by minimal filtering (csrc/conv32_wino.hip MODE 2, csrc/conv32_wino_wgrad.hip): 4 matrix products per
       # pixel and gradient instead of 9; g_z makes one round trip through HBM between the two launches
       ww_t = pack_special(w, PACK_WINO_T, 16, 16 * 1024,

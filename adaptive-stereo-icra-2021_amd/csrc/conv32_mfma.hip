@@ -919,10 +919,27 @@ extern "C" int as_conv32_wino_fwd(const float* z_prev, const float* a_prevprev, 
   return AS_OK;
 }
 
+// Eval-mode BasicBlock by minimal filtering: out = lrelu((conv(x) + bias) * scale + shift) (+ x).  One read of x (the skip
+// connection comes out of the staged rows), one write.
+extern "C" int as_conv32_wino_eval(const float* x, const as_pcl* g, const as_conv_shape* s, const float* wino_w, const float* bias,
+                                   const float* scale, const float* shift, float slope, int residual, float* out, void* stream) {
+  if (int e = check_conv(g, g, s, "as_conv32_wino_eval")) return e;
+  AS_CHECK_ARG(x && wino_w && scale && shift && out, "as_conv32_wino_eval: null pointer");
+  AS_CHECK_ARG(conv32_wino_applicable(g, g, s), "as_conv32_wino_eval: configuration not supported (as_conv32_wino_ok() == 0)");
+  AS_CHECK_ARG(slope > 0.f && slope < 1.f, "as_conv32_wino_eval: slope must lie in (0, 1)");
+  AS_CHECK_ARG(out != x, "as_conv32_wino_eval: out must not alias x");
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(AS_PROF_WINO_FWD, st, 1, 0.0);
+  if (int e = conv32_wino_eval_launch(x, g, s, wino_w, bias, scale, shift, slope, residual, out, stream)) return e;
+  as_prof_mark(AS_PROF_WINO_FWD, st, 0, 2.0 * (double)g->B * g->H * g->W * 1024.0 * 9);
+  AS_CHECK_LAUNCH("as_conv32_wino_eval");
+  return AS_OK;
+}
+
 // Backward of the same layer by minimal filtering, two launches: data gradient F(2x2, 3x3) with stage 3 of the BatchNorm
 // backward on the way in (g_z written once), skip connection and next-BatchNorm sums in the epilogue; then weight / bias
 // gradient F(3x3, 2x2) from x and g_z.  Arguments as as_conv32_bwd_fused, plus g_z (a PCL buffer of the layer's geometry).
-extern "C" int as_conv32_wino_bwd_parts(void) { return conv32_wino_parts(); }
+extern "C" int as_conv32_wino_bwd_parts(void) { return conv32_wino_dgrad_parts(); }
 extern "C" int64_t as_conv32_wino_bwd_workspace(void) { return (int64_t)conv32_wino_wgrad_slabs() * (9 * 1024 + 32); }
 
 extern "C" int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,

@@ -105,13 +105,21 @@ template <int L> __device__ inline int wn_addr(int v, int chunk) { return wn_pos
 
 #define WN_FOR_8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 
-// MODE 0: forward, no skip input; 1: forward with skip input; 2: data gradient
+// MODE 0: training forward, no skip input; 1: training forward with skip input; 2: data gradient;
+// 3: eval forward — the operand x is staged as is, out = lrelu((conv(x) + bias) * scale + shift) (+ x: the BasicBlock's skip
+//    connection, read from the staged rows), nothing else written
+#ifdef WN_BWD_ONE_WG
+#define WN_WGS_PER_CU(MODE) ((MODE) == 2 ? 1 : 2)
+#else
+#define WN_WGS_PER_CU(MODE) 2
+#endif
 template <int MODE, int L>
-__global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
+__global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int d = 1 << L;
-  constexpr bool SKIP = MODE != 0;                          // a second tensor rides along with the operand rows
+  constexpr bool SKIP = MODE == 1 || MODE == 2;             // a second tensor rides along with the operand rows
   constexpr bool BWD = MODE == 2;
+  constexpr bool EVAL = MODE == 3;                          // operand staged as is; epilogue: affine + LeakyReLU (+ residual)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, li = lane & 31;
   const int H = p.g.H, W = p.g.W, Wp = p.g.Wp;
@@ -138,10 +146,12 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
     else if (i < 160) tab[i] = p.in_shift[i - 128];
     else if (i < 192) tab[i] = p.bn_mean[i - 160];
     bn_sc = p.n_scale[li]; bn_sh = p.n_shift[li]; bn_mu = p.n_mean[li];
-  } else if (threadIdx.x < 64) {
+  } else if (!EVAL && threadIdx.x < 64) {
     float* tab = reinterpret_cast<float*>(smem + WN_COEF_OFF);
     tab[threadIdx.x] = threadIdx.x < 32 ? p.in_scale[threadIdx.x] : p.in_shift[threadIdx.x - 32];
   }
+  float ev_sc = 0.f, ev_sh = 0.f;
+  if constexpr (EVAL) { ev_sc = p.ep.ep_scale[li]; ev_sh = p.ep.ep_shift[li]; }
   __syncthreads();
 
   // ---- row conversion: a PAIR of rows is 1,280 chunks, five per thread: chunk f = t + 256k; f < 640 row A else row B ----
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         k1 = *reinterpret_cast<const f32x4*>(tab); k2 = *reinterpret_cast<const f32x4*>(tab + 32);
         k3 = *reinterpret_cast<const f32x4*>(tab + 64); sc = *reinterpret_cast<const f32x4*>(tab + 96);
         sh = *reinterpret_cast<const f32x4*>(tab + 128); bmu = *reinterpret_cast<const f32x4*>(tab + 160);
-      } else {
+      } else if constexpr (!EVAL) {
         sc = *reinterpret_cast<const f32x4*>(tab); sh = *reinterpret_cast<const f32x4*>(tab + 32);
       }
 #pragma unroll
@@ -231,6 +241,8 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
           gy.x = yy.x > 0.f ? ga.x : gl.x; gy.y = yy.y > 0.f ? ga.y : gl.y;
           gy.z = yy.z > 0.f ? ga.z : gl.z; gy.w = yy.w > 0.f ? ga.w : gl.w;
           yv = (gy - k1 - (zz - bmu) * k2) * k3;
+        } else if constexpr (EVAL) {
+          yv = pz[k];                                       // (the tensor's halo is zero in memory: no column mask either)
         } else {
           yv = pz[k] * sc + sh;
           const f32x4 ys = yv * p.slope;                    // 0 < slope < 1: lrelu(y) = max(y, slope*y)
@@ -241,10 +253,10 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
         // halo voxels (v < 8, v >= 72: only they can lie outside the image) are whole waves of a chunk: a uniform branch
         const bool halo = (k == 0 && wave == 0) || (k == 2 && (wave == 1 || wave == 2)) || (k == 4 && wave == 3);
         if (!row_in) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        else if (halo) yv = (xx >= 0 && xx < W) ? yv : (f32x4){0.f, 0.f, 0.f, 0.f};
+        else if (!EVAL && halo) yv = (xx >= 0 && xx < W) ? yv : (f32x4){0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * WN_ROW_BYTES + wn_addr<L>(v, t & 7)) = yv;
         const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
-        if (own && !halo) {
+        if (!EVAL && own && !halo) {
           float* aout = p.a_out + ((img + y + p.g.ph) * Wp + px0) * 32;
           wn_store4(aout, (unsigned)(v * 128 + c4 * 4), yv);
         }
@@ -273,6 +285,25 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
     for (int j = j0; j < j1; j += 2) {
       fetch_one(j + 3, p.zin, pz);                         // in flight during the matrix phase (the skip rows follow it:
                                                            // ten more registers across the matrix phase spilled)
+#define WN_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
+#define WN_COL(r) (wn_c0<L>(((r) & 3) + 8 * ((r) >> 2)) + wn_c0<L>(4 * h) + oj * d)    /* column of accumulator row r in the segment */
+      const int yrow = j + oi;
+      const bool row_ok = yrow < j1;                       // (wave-uniform) the pair's second row may lie outside the piece
+      float res[16], zt[16];                                // data gradient: g_a (skip connection) and the next layer's
+                                                            // pre-activation at this wave's output pixels
+      auto late_loads = [&]() {
+        if (SKIP) fetch_one(j + 3, p.ain, pa);
+        if constexpr (BWD) {
+          if (row_ok) {
+            const long ovox = ((img + r0 + yrow * d + p.g.ph) * Wp + x0 + p.g.pw) * 32;
+#define WN_LD(r) wn_load_imm<WN_IMM(r)>(res[r], p.ain + ovox, io_off); wn_load_imm<WN_IMM(r)>(res[8 + r], p.ain + ovox, io_off2); \
+                 wn_load_imm<WN_IMM(r)>(zt[r], p.nz + ovox, io_off); wn_load_imm<WN_IMM(r)>(zt[8 + r], p.nz + ovox, io_off2);
+            WN_FOR_8(WN_LD)
+#undef WN_LD
+          }
+        }
+      };
+      if constexpr (WN_WGS_PER_CU(MODE) == 1) late_loads();  // (one workgroup per CU: 512 registers, everything requested up front)
       const char* row_a = smem + ((j + ra) & 3) * WN_ROW_BYTES;   // input row m of the tile = comb row j-1+m = slot (j+m) & 3
       const char* row_b = smem + ((j + rb) & 3) * WN_ROW_BYTES;
       f32x16 acc[4];
@@ -332,22 +363,24 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
           *reinterpret_cast<f32x4*>(xw + 4096 + gq * 1024) = t1;
         }
       }
-      if (SKIP) fetch_one(j + 3, p.ain, pa);               // (the accumulators are dead: registers to spare)
-      const int yrow = j + oi;
-      const bool row_ok = yrow < j1;                       // (wave-uniform) the pair's second row may lie outside the piece
-      int dup_l = dup;                                     // (opaque: hipcc otherwise hoists the 16 duplicate-column masks of
-      asm volatile("" : "+s"(dup_l));                      //  the last segment out of the tile loop, into 16 registers)
-#define WN_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
-      float res[16], zt[16];                                // data gradient: g_a (skip connection) and the next layer's
-      if constexpr (BWD) {                                  // pre-activation at this wave's output pixels
-        if (row_ok) {
-          const long ovox = ((img + r0 + yrow * d + p.g.ph) * Wp + x0 + p.g.pw) * 32;
-#define WN_LD(r) wn_load_imm<WN_IMM(r)>(res[r], p.ain + ovox, io_off); wn_load_imm<WN_IMM(r)>(res[8 + r], p.ain + ovox, io_off2); \
-                 wn_load_imm<WN_IMM(r)>(zt[r], p.nz + ovox, io_off); wn_load_imm<WN_IMM(r)>(zt[8 + r], p.nz + ovox, io_off2);
-          WN_FOR_8(WN_LD)
-#undef WN_LD
+      if constexpr (WN_WGS_PER_CU(MODE) != 1) late_loads();  // (the accumulators are dead: registers to spare)
+      if constexpr (EVAL) {
+        // the skip connection of the block = the operand at the output pixels: in the staged rows j, j+1 — read before B1
+        // (afterwards other waves overwrite those slots)
+        if (p.ep.residual != nullptr) {
+          const char* rrow = smem + ((j + oi + 1) & 3) * WN_ROW_BYTES + (li & 3) * 4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tl = (r & 3) + 8 * (r >> 2);          // + 4h: this lane's tile of accumulator row r
+            res[r] = *reinterpret_cast<const float*>(rrow + wn_addr<L>(8 + wn_c0<L>(tl) + wn_c0<L>(4 * h) + oj * d, li >> 2));
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) res[r] = 0.f;
         }
       }
+      int dup_l = dup;                                     // (opaque: hipcc otherwise hoists the 16 duplicate-column masks of
+      asm volatile("" : "+s"(dup_l));                      //  the last segment out of the tile loop, into 16 registers)
       WN_T(3);
       __syncthreads();                                     // B1: the T tiles are in place; nobody reads rows j-1, j any more
       WN_T(4);
@@ -381,9 +414,14 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
           float* gx_base = p.ep.z + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
 #pragma unroll
           for (int r = 0; r < 16; ++r) Y[r] += res[r];
+          // (a pixel's rounding depends on the tile it falls into and the shifted last segment tiles its columns differently:
+          //  the columns it shares with its neighbour are written by the neighbour only)
 #define WN_ST(r) wn_store_imm<WN_IMM(r)>(gx_base, io_off, Y[r]); wn_store_imm<WN_IMM(r)>(gx_base, io_off2, Y[8 + r]);
-          WN_FOR_8(WN_ST)
+#define WN_STM(r) if (WN_COL(r) >= dup_l) wn_store_imm<WN_IMM(r)>(gx_base, io_off, Y[r]); \
+                  if (WN_COL(8 + r) >= dup_l) wn_store_imm<WN_IMM(r)>(gx_base, io_off2, Y[8 + r]);
+          if (dup_l <= 0) { WN_FOR_8(WN_ST) } else { WN_FOR_8(WN_STM) }
 #undef WN_ST
+#undef WN_STM
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float yv = fmaf(zt[r], bn_sc, bn_sh);
@@ -395,13 +433,33 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
             bn_dy += gy; bn_dx = fmaf(gy, zt[r] - bn_mu, bn_dx);
           }
         }
-      } else if (row_ok) {
+      }
+      if constexpr (!BWD) {
+        // The operand rows of the next tile are home BEFORE this tile's stores go out: one unconditional wait on the very
+        // registers the loads were issued into.  (First version: a counted wait behind the 16 stores, vmcnt(16) or vmcnt(0) by
+        // branch — hipcc merged the two asm statements' register operands by COPYING the load destinations in front of the
+        // branch, i.e. before the wait: rare stale operands, different from process to process.  tests/tools/check_async_loads.py
+        // scans the ISA for any read of an in-flight load destination.)
+        wait_all(pz, pa);
+      }
+      if (!BWD && row_ok) {
         const int y = r0 + yrow * d;
         float* z_base = p.ep.z + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
+        if constexpr (EVAL) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {                    // conv_epilogue's arithmetic (epilogue 1)
+            float yv = Y[r] * ev_sc + ev_sh;
+            yv = yv > 0.f ? yv : yv * p.slope;
+            Y[r] = yv + res[r];
+          }
+        }
 #define WN_ST(r) wn_store_imm<WN_IMM(r)>(z_base, io_off, Y[r]); wn_store_imm<WN_IMM(r)>(z_base, io_off2, Y[8 + r]);
-        WN_FOR_8(WN_ST)
+#define WN_STM(r) if (WN_COL(r) >= dup_l) wn_store_imm<WN_IMM(r)>(z_base, io_off, Y[r]); \
+                  if (WN_COL(8 + r) >= dup_l) wn_store_imm<WN_IMM(r)>(z_base, io_off2, Y[8 + r]);
+        if (dup_l <= 0) { WN_FOR_8(WN_ST) } else { WN_FOR_8(WN_STM) }   // (duplicated columns: the neighbouring segment's)
 #undef WN_ST
-        if (p.ep.stat_mean != nullptr) {
+#undef WN_STM
+        if (!EVAL && p.ep.stat_mean != nullptr) {
           if (dup_l <= 0) {
             st_c = st_n == 0.f ? Y[0] : st_c;
 #pragma unroll
@@ -421,12 +479,6 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       WN_T(6);
-      // the operand rows are home when only this tile's own stores are outstanding (vector memory retires in order)
-      if constexpr (!BWD) {
-        if (row_ok) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(pz[0]), "+v"(pz[1]), "+v"(pz[2]), "+v"(pz[3]), "+v"(pz[4]) :: "memory");
-        if (SKIP) asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]) :: "memory");
-      }
       WN_T(7);
       convert_from(j + 3, pz, pa);
       WN_T(8);
@@ -479,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_kernel(WinoArgs p) {
   }
 }
 
+static int wn_grid(int mode) { return WN_GRID / (2 / WN_WGS_PER_CU(mode)); }
 static int wn_log2(int d) { return d == 1 ? 0 : d == 2 ? 1 : d == 4 ? 2 : d == 8 ? 3 : -1; }
 
 static long wn_pairs(int H, int d) {
@@ -501,6 +554,7 @@ bool conv32_wino_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv
 }
 
 int conv32_wino_parts(void) { return WN_GRID; }
+int conv32_wino_dgrad_parts(void) { return wn_grid(2); }
 
 template <int MODE> static const void* wn_kernel(int L) {
   switch (L) {
@@ -512,8 +566,8 @@ template <int MODE> static const void* wn_kernel(int L) {
 }
 
 static int wn_launch(int mode, int L, const WinoArgs& a, const char* who, void* stream) {
-  static AsPerDevice attr_set[12];
-  const void* fn = mode == 2 ? wn_kernel<2>(L) : (mode == 1 ? wn_kernel<1>(L) : wn_kernel<0>(L));
+  static AsPerDevice attr_set[16];
+  const void* fn = mode == 3 ? wn_kernel<3>(L) : (mode == 2 ? wn_kernel<2>(L) : (mode == 1 ? wn_kernel<1>(L) : wn_kernel<0>(L)));
   const int fi = mode * 4 + L;
   if (!attr_set[fi].get()) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WN_LDS_BYTES);
@@ -529,7 +583,7 @@ static int wn_launch(int mode, int L, const WinoArgs& a, const char* who, void* 
   args.timing = timing_buf;
 #endif
   void* kargs[] = {&args};
-  hipError_t le = hipLaunchKernel(fn, dim3(WN_GRID), dim3(256), kargs, WN_LDS_BYTES, (hipStream_t)stream);
+  hipError_t le = hipLaunchKernel(fn, dim3(wn_grid(mode)), dim3(256), kargs, WN_LDS_BYTES, (hipStream_t)stream);
   if (le != hipSuccess) { as_set_error("%s: launch failed: %s", who, hipGetErrorString(le)); return AS_ERR_LAUNCH; }
 #ifdef WN_TIMING_BUILD
   if (getenv("AS_WN_TIMING")) {                            // dump THIS launch (synchronises: diagnostic build only)
@@ -552,6 +606,18 @@ int conv32_wino_launch(const float* z_prev, const float* a_prevprev, const float
   a.g = as_make_dev(g);
   a.nseg = (g->W + WN_SEG - 1) / WN_SEG; a.pairs = (int)wn_pairs(g->H, s->dil); a.slope = slope;
   return wn_launch(a_prevprev != nullptr ? 1 : 0, wn_log2(s->dil), a, "as_conv32_wino_fwd", stream);
+}
+
+// Eval forward (MODE 3): out = lrelu((conv(x) + bias) * scale + shift) (+ x if residual).
+int conv32_wino_eval_launch(const float* x, const as_pcl* g, const as_conv_shape* s, const float* wino_w, const float* bias,
+                            const float* scale, const float* shift, float slope, int residual, float* out, void* stream) {
+  WinoArgs a = {};
+  a.zin = x; a.wq = wino_w;
+  a.ep.bias = bias; a.ep.z = out; a.ep.ep_scale = scale; a.ep.ep_shift = shift; a.ep.residual = residual ? x : nullptr;
+  a.ep.epilogue = 1; a.ep.slope = slope;
+  a.g = as_make_dev(g);
+  a.nseg = (g->W + WN_SEG - 1) / WN_SEG; a.pairs = (int)wn_pairs(g->H, s->dil); a.slope = slope;
+  return wn_launch(3, wn_log2(s->dil), a, "as_conv32_wino_eval", stream);
 }
 
 // Data gradient of the layer (MODE 2): g_z (by-product), g_x = dgrad(g_z) + g_a, next-BatchNorm sums [WN_GRID][64].

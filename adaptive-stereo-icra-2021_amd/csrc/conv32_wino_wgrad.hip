@@ -69,7 +69,6 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
   constexpr int rb = RW == 0 ? 2 : (RW == 1 ? 2 : 1);
   constexpr float sg = RW == 1 ? 1.f : -1.f;
   const int lane_off = li * 4 + h * (L == 0 ? WW_CHUNK : 128);
-  const int lane_col = L == 0 ? 8 * h : h;                  // this half's share of a tile's first column
 
   f32x16 acc[4];
 #pragma unroll
@@ -91,31 +90,34 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
     const int j0 = 2 * pj0, j1 = min(2 * pj1, nrow);
     const int seg = blk % p.nseg;
     const int b = blk / p.nseg;
-    const int x_new = 64 * seg;
-    const int x0 = min(x_new, W - 64);
-    const int dup = x_new - x0;                           // columns below `dup` were counted by the neighbouring segment
+    // The last segment is NOT shifted back to end at the image edge (conv32_wino.hip does that and masks the duplicated
+    // columns): its chunks that start beyond the image come from the zero halo row, the one that straddles the edge ends inside
+    // the halo (pw >= 8) — so every g_z pixel is met exactly once and no lane-level mask is needed in the matrix loop.
+    const int x0 = 64 * seg;
     const long img = (long)b * p.g.Hp;
 
-    // DMA job i of a tile whose first comb row is jt: i < 20: chunk i % 10 of x row jt + 2 + i / 10 (the two NEW rows of the
-    // tile: its input rows are jt-1 .. jt+2); else chunk (i-20) % 8 of g_z row jt + (i-20) / 8.  Rows outside the image or the
-    // piece's g_z range come from the zero halo row above the image.
+    // DMA job i of a tile whose first comb row is jt: i < 20: chunk i % 10 of x row jt + 1 + i / 10 (the two NEW rows of the
+    // tile: its input rows are jt-1 .. jt+2); else chunk (i-20) % 8 of g_z row jt + (i-20) / 8.  Rows outside the image (or, for
+    // g_z, the piece) and chunks beyond the image's right edge come from the zero halo row above the image.
     auto issue = [&](int jt, int i) {
       if (i < 20) {
-        const int jj = jt + 2 + i / 10 - 1, c = i % 10;     // comb row jt+1 or jt+2 -> see the caller: x rows are issued as (jt+1, jt+2)
+        const int jj = jt + 1 + i / 10, c = i % 10;
         const int yy = r0 + jj * d;
-        const int y = (yy >= 0 && yy < H) ? yy : -1;
-        const float* src = p.x + ((img + y + p.g.ph) * Wp + x0 - 8 + p.g.pw) * 32 + c * 256;
+        const int xs = x0 - 8 + 8 * c;                      // first column of the chunk
+        const int y = (yy >= 0 && yy < H && xs < W + 8) ? yy : -1;
+        const float* src = p.x + ((img + y + p.g.ph) * Wp + (y < 0 ? 0 : xs) + p.g.pw) * 32;
         ww_dma_1kb(src, lane16, lds0 + (unsigned)(((jj + 1) & (WW_XSLOTS - 1)) * WW_XROW + c * WW_CHUNK));
       } else {
         const int i2 = i - 20, jj = jt + i2 / 8, c = i2 % 8;
         const int yy = r0 + jj * d;
-        const int y = (jj < j1 && yy < H) ? yy : -1;
-        const float* src = p.gz + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32 + c * 256;
+        const int xs = x0 + 8 * c;
+        const int y = (jj < j1 && yy < H && xs < W) ? yy : -1;
+        const float* src = p.gz + ((img + y + p.g.ph) * Wp + (y < 0 ? 0 : xs) + p.g.pw) * 32;
         ww_dma_1kb(src, lane16, lds0 + (unsigned)(WW_G_OFF + ((jt >> 1) % 3) * WW_GBUF + (i2 / 8) * WW_GROW + c * WW_CHUNK));
       }
     };
     // ---- run-in: x rows j0-1 .. j0+2 and the g_z pair of tile j0 ----
-    // (x rows of `issue(jt, .)` are jt+1, jt+2: jt = j0-2 brings j0-1, j0; jt = j0 brings j0+1, j0+2)
+    // (x rows of issue(jt, .) are jt+1, jt+2: jt = j0-2 brings j0-1, j0; jt = j0 brings j0+1, j0+2)
     for (int i = W8; i < 20; i += 8) issue(j0 - 2, i);
     for (int i = W8; i < 36; i += 8) issue(j0, i);
     if (j0 + 2 < j1) {                                     // the second tile's rows stay in flight (NJOB jobs per wave)
@@ -169,13 +171,10 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
           continue;
         }
 #endif
-        const int col0 = ww_c0<L>(ww_tile<L>(s));          // + lane_col: first column of this half's tile
         float Gr[2];
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
-          const bool counted = lane_col + col0 + jc * d >= dup;
-          const float u0 = (RW != 3 && counted) ? g0[s & 1][jc] : 0.f;
-          const float u1 = (RW != 0 && counted) ? g1[s & 1][jc] : 0.f;
+          const float u0 = RW != 3 ? g0[s & 1][jc] : 0.f, u1 = RW != 0 ? g1[s & 1][jc] : 0.f;
           if (RW == 1) bsum += u0 + u1;
           Gr[jc] = RW == 0 ? u0 : (RW == 3 ? u1 : (RW == 1 ? u0 + u1 : u0 - u1));   // (the factor 1/2 of rows 1, 2: at the end)
         }

@@ -164,6 +164,12 @@ int as_conv32_wino_fwd(const float* z_prev, const float* a_prevprev, const float
                        float* z, const as_pcl* gout, const as_conv_shape* s, float* stat_mean, float* stat_m2,
                        float* stat_cnt, void* stream);
 
+/* ---- eval-mode BasicBlock (stereo_net.py:10-18 with BatchNorm folded to an affine) by minimal filtering:
+ *   out = lrelu((conv(x) + bias) * scale + shift) (+ x if residual != 0);  x, out: PCL tensors of geometry g (zero halo),
+ *   as_conv32_wino_ok(g, g, s) == 1;  wino_w as for as_conv32_wino_fwd;  bias may be NULL */
+int as_conv32_wino_eval(const float* x, const as_pcl* g, const as_conv_shape* s, const float* wino_w, const float* bias,
+                        const float* scale, const float* shift, float slope, int residual, float* out, void* stream);
+
 /* ---- backward of that layer by minimal filtering, two launches (csrc/conv32_wino.hip MODE 2, csrc/conv32_wino_wgrad.hip):
  * arguments and results of as_conv32_bwd_fused (below), except
  *   wino_wt    as_conv32_wino_pack_weights(w, out, transposed = 1) or a batch job of kind AS_PACK_WINO_T

@@ -114,3 +114,17 @@ def test_division_by_9_and_3_in_three_instructions_is_correctly_rounded(tmp_path
   subprocess.run(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", "-DSTRIDE=61", src, "-o", exe, "-lm"], check=True)
   out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
   assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_hand_waited_loads_are_never_read_in_flight():
+  """The kernels that issue global loads from inline asm and retire them with their own s_waitcnt must not let hipcc read (copy,
+  spill) a destination register between the load and its wait: tests/tools/check_async_loads.py compiles them to gfx950 ISA and
+  scans for such reads (found once: ten v_mov in front of a branch that held two different waits — stale operands that came and
+  went with memory latency, different from process to process)."""
+  import shutil, subprocess, sys
+  if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+    pytest.skip("no hipcc")
+  tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "check_async_loads.py")
+  r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+  assert "conv32_wino_kernel" in r.stdout and "HAZARD" not in r.stdout

@@ -1089,6 +1089,46 @@ def test_conv32_backward_fused_in_one_launch(B, H, W, dil):
   from conftest import parity_note
   parity_note("bwd_fused[%s]" % tag, g_x_bit_identical=exact)
 
+@pytest.mark.parametrize("B,H,W,dil,skip", [(2, 160, 1242, 1, True), (1, 375, 1242, 2, True), (2, 161, 1030, 4, True),
+                                            (2, 163, 1237, 8, True), (4, 97, 700, 1, False)])
+def test_conv32_eval_block_by_minimal_filtering(B, H, W, dil, skip):
+  """as_conv32_wino_eval — an eval-mode BasicBlock in one launch, out = lrelu((conv(x) + bias) * scale + shift) (+ x) with the
+  skip connection read from the staged rows — against as_conv32_fwd's fused epilogue (direct form): both held against the fp64
+  result of the same fp32 operands, minimal filtering not further away than 2x the direct kernel."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_wino_ok(g, g, shape) == 1
+  x = ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=1).to(DEV), g)
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  b = (rnd(32, seed=10) * 0.1).to(DEV)
+  st = ops.BnState(DEV)
+  st.scale.copy_(rnd(32, seed=5).abs().to(DEV) + 0.5); st.shift.copy_(rnd(32, seed=6).to(DEV) * 0.3)
+  wp = ops.pack_weights(w, shape, False)
+  ww = torch.empty(16 * 1024, device=DEV)
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww), 0, nat.stream())
+  ref = ops.conv32(x, g, wp, b, g, shape, out=ops.pcl_zeros(g, DEV), epilogue=1, scale=st.scale, shift=st.shift,
+                   residual=x if skip else None)
+  out = ops.pcl_zeros(g, DEV)
+  nat.call("as_conv32_wino_eval", nat.ptr(x), g, shape, nat.ptr(ww), nat.ptr(b), nat.ptr(st.scale), nat.ptr(st.shift), 0.2,
+           1 if skip else 0, nat.ptr(out), nat.stream())
+  tag = "wino eval B%d H%d W%d d%d %s" % (B, H, W, dil, "skip" if skip else "plain")
+  full = ops.pcl_view(out, g).clone(); ops.pcl_interior(full, g).zero_()
+  assert float(full.abs().max()) == 0.0, tag + ": written into the halo"
+  x64 = ops.pcl_to_ncdhw(x, g)[:, :, 0].double().cpu()
+  y64 = torch.nn.functional.conv2d(x64, w.double().cpu(), b.double().cpu(), padding=dil, dilation=dil)
+  y64 = y64 * st.scale.double().cpu().view(1, 32, 1, 1) + st.shift.double().cpu().view(1, 32, 1, 1)
+  y64 = torch.where(y64 > 0, y64, 0.2 * y64) + (x64 if skip else 0.0)
+  got = ops.pcl_to_ncdhw(out, g)[:, :, 0].double().cpu(); dire = ops.pcl_to_ncdhw(ref, g)[:, :, 0].double().cpu()
+  e_w, e_d = float((got - y64).abs().max()), float((dire - y64).abs().max())
+  r_w, r_d = float((got - y64).pow(2).mean().sqrt()), float((dire - y64).pow(2).mean().sqrt())
+  scale = float(y64.abs().max())
+  assert e_d <= 2e-6 * scale and e_w <= max(2.0 * e_d, 1e-6 * scale) and r_w <= 2.0 * r_d, (tag, e_w, e_d, r_w, r_d, scale)
+  from conftest import parity_note
+  parity_note("conv32_wino_eval[%s]" % tag, max_err_vs_fp64=e_w, direct_max_err_vs_fp64=e_d, rms_err_vs_fp64=r_w,
+              direct_rms_err_vs_fp64=r_d)
+
+
 @pytest.mark.parametrize("B,H,W,dil", [(2, 160, 1242, 1), (2, 161, 1242, 2), (1, 375, 1030, 4), (2, 163, 1237, 8)])
 def test_conv32_backward_by_minimal_filtering(B, H, W, dil):
   """as_conv32_wino_bwd — the backward of as_conv32_bwd_fused as a data gradient F(2x2, 3x3) and a weight gradient F(3x3, 2x2)
@@ -1165,6 +1205,13 @@ def test_conv32_backward_by_minimal_filtering(B, H, W, dil):
   _, ggn, gbn = ops.bn_act_bwd(gx, zn, stn, gamman, g, True, sums=ops.BnBwdSums(nws, lib.as_conv32_wino_bwd_parts()))
   close(ggn, ggn_ref, 2e-6 * n ** 0.5 * float(ggn_ref.abs().max()) + 1e-5, 1e-5, tag + " next g_gamma")
   close(gbn, gbn_ref, 2e-6 * n ** 0.5 * float(gbn_ref.abs().max()) + 1e-5, 1e-5, tag + " next g_beta")
+  # determinism: a second launch into fresh buffers gives the same bits (the shifted last segment must not race its neighbour)
+  gx1, dW1, db1, nws1 = gx.clone(), dW.clone(), db.clone(), nws.clone()
+  gx.zero_(); run(0)
+  assert bool(torch.equal(gx, gx1)), tag + ": g_x differs between two launches"
+  assert bool(torch.equal(dW, dW1)) and bool(torch.equal(db, db1)), tag + ": dW / db differ between two launches"
+  nsum = lib.as_conv32_wino_bwd_parts() * 128             # [parts][64] doubles, compared as bit patterns
+  assert bool(torch.equal(nws[:nsum].view(torch.int32), nws1[:nsum].view(torch.int32))), tag + ": sums differ"
   run(1)                                                   # accumulate flavour: a second launch adds the same gradient again
   close(dW, 2 * dW_ref, 1e-4 * float(dW_ref.abs().max()), 1e-4, tag + " accumulated dW")
   from conftest import parity_note
@@ -1252,6 +1299,14 @@ def test_conv32_forward_by_minimal_filtering(B, H, W, dil, skip):
            nat.ptr(ww), nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats.mean), nat.ptr(stats.m2), nat.ptr(stats.cnt),
            nat.stream())
   tag = "wino B%d H%d W%d d%d %s" % (B, H, W, dil, "skip" if skip else "plain")
+  # determinism: the columns the shifted last segment shares with its neighbour fall into different tiles there (different
+  # rounding) — they must be written by one of the two only
+  z2, a2 = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  for _ in range(2):
+    nat.call("as_conv32_wino_fwd", nat.ptr(z_prev), nat.ptr(a_pp), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a2), g,
+             nat.ptr(ww), nat.ptr(b), 0.2, nat.ptr(z2), g, shape, nat.ptr(stats.mean), nat.ptr(stats.m2), nat.ptr(stats.cnt),
+             nat.stream())
+    assert bool(torch.equal(z2, z)), tag + ": two launches differ"
   for name, got in (("a_out", a_out), ("z", z)):
     full = ops.pcl_view(got, g).clone(); ops.pcl_interior(full, g).zero_()
     assert float(full.abs().max()) == 0.0, tag + ": %s written into the halo" % name

@@ -1,0 +1,96 @@
+"""Static check of the hand-waited vector-memory loads in csrc/*.hip.
+
+The kernels that issue `global_load_*` from inline asm and retire them with their own `s_waitcnt vmcnt(N)` tell hipcc nothing
+about WHEN the destination registers become valid: the compiler may copy (or spill) them between the load and the wait — a read
+of an in-flight destination, i.e. stale data that comes and goes with memory latency (this happened once: a v_mov of ten
+operand registers in front of a branch that held two different waits).  This script compiles a source to ISA and reports every
+instruction that reads or overwrites a register while an asm-issued load into it is outstanding; the register set is cleared at
+every `s_waitcnt vmcnt(...)`.  Waits counted with N > 0 are handled conservatively: the OLDEST outstanding loads are retired
+first (loads retire in order), N of the youngest stay pending.
+
+usage: python tests/tools/check_async_loads.py [file.hip ...]      (default: every csrc/*.hip that contains an asm load)
+exit status 1 if a hazard is found."""
+import glob, os, re, subprocess, sys, tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(REPO, "adaptive-stereo-icra-2021_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def regs(tok):
+  out = set()
+  for m in re.finditer(r"\bv\[(\d+):(\d+)\]", tok):
+    out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+  for m in re.finditer(r"\bv(\d+)\b", tok):
+    out.add(int(m.group(1)))
+  return out
+
+
+def check_kernel(name, lines):
+  """lines: the kernel's instructions in program order (straight-line approximation: branches are not followed; a loop body is
+  seen once, which is what matters — a hazard inside the body shows in its text)."""
+  pending = []        # (set of registers, line number) per outstanding VMEM op in issue order; stores carry an empty set
+  hazards = []
+  for no, l in lines:
+    parts = l.split(None, 1)
+    op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+    if op.startswith("s_waitcnt"):
+      m = re.search(r"vmcnt\((\d+)\)", args)
+      if m:
+        n = int(m.group(1))
+        pending = pending[len(pending) - n:] if n else []
+      continue
+    if op in ("s_endpgm",):
+      break
+    used = regs(args)
+    inflight = set().union(*[p[0] for p in pending]) if pending else set()
+    if op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")) and "lds" not in op:
+      dst = regs(args.split(",")[0])
+      src = used - dst
+      if src & inflight:
+        hazards.append((no, l, sorted(src & inflight)))
+      pending.append((dst, no))
+      continue
+    if op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_load_lds", "global_atomic")):
+      if used & inflight:
+        hazards.append((no, l, sorted(used & inflight)))
+      pending.append((set(), no))
+      continue
+    if used & inflight:
+      hazards.append((no, l, sorted(used & inflight)))
+  return hazards
+
+
+def main():
+  files = sys.argv[1:] or [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+                           if re.search(r'asm volatile\("global_load_dword', open(f).read())]
+  bad = 0
+  for f in files:
+    with tempfile.TemporaryDirectory() as td:
+      subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-inline-asm", "-I", CSRC, "-c", f,
+                             "-save-temps", "-o", os.path.join(td, "x.o")], cwd=td, stderr=subprocess.DEVNULL)
+      asm = glob.glob(os.path.join(td, "*gfx950*.s"))[0]
+      text = open(asm).read().split("\n")
+    kernels, cur, name = {}, None, None
+    for i, l in enumerate(text, 1):
+      m = re.match(r"^(_Z\w+):", l)
+      if m and not l.startswith("_ZN"):
+        name, cur = m.group(1), []
+        kernels[name] = cur
+        continue
+      s = l.strip()
+      if cur is not None and s and not s.startswith((";", ".", "//")) and not s.endswith(":"):
+        cur.append((i, s))
+    for name, lines in kernels.items():
+      if not any(x[1].startswith("global_load") for x in lines):
+        continue
+      hz = check_kernel(name, lines)
+      print("%-28s %-60s %s" % (os.path.basename(f), name[:60], "ok" if not hz else "%d HAZARD(S)" % len(hz)))
+      for no, l, r in hz[:6]:
+        print("      line %d: %s   <- in-flight %s" % (no, l[:90], r[:8]))
+      bad += len(hz)
+  return 1 if bad else 0
+
+
+if __name__ == "__main__":
+  sys.exit(main())

@@ -31,8 +31,8 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv32_wino_wgrad_kernel<0>": 2 * vox * 128,           # x, g_z read
        "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128,
        "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128,
-       "agg3d_kernel<0, 2>": 2 * vox3 * 128 + 27 * 4096, "agg3d_kernel<0, 0>": 2 * vox3 * 128 + 27 * 4096,
-       "agg3d_kernel<2, 0>": 3 * vox3 * 128 + 27 * 4096,      # raw operand read, activated by-product and output written
+       "agg3d_kernel<0, 2, false>": 2 * vox3 * 128 + 27 * 4096, "agg3d_kernel<0, 0, false>": 2 * vox3 * 128 + 27 * 4096,
+       "agg3d_kernel<2, 0, false>": 3 * vox3 * 128 + 27 * 4096,      # raw operand read, activated by-product and output written
        "agg_tail_kernel<2, 8, true>": 2 * vox3 * 128 + vox3 * 4}
 out = {"shape": "2-D 3x3 stride 1, 32->32, %d pair(s) x 375x1242 (one full-resolution refinement layer); 3-D rows: 12x24x78 per pair" % B,
        "pairs_per_launch": B, "algorithmic_flops_per_launch": flops,
