@@ -10,9 +10,11 @@ ONE hipGraph, and the small collectives of cross-replica BatchNorm become graph 
 ``torch.distributed`` still does what it is good at: rendezvous (the unique id travels through the process group) and the
 barrier / max-over-ranks timing of bench.py.  Collectives are enqueued on the CURRENT torch stream, in place, no host sync.
 """
+import contextlib
 import ctypes
 import glob
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -47,6 +49,26 @@ def _load():
   return _lib
 
 
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+  """librccl prints a version banner (five lines) to the C stdout when a communicator is created; a library must not write to
+  its host's stdout (bench.py's contract is ONE JSON line there): file descriptor 1 points at stderr for the duration."""
+  libc = ctypes.CDLL(None)
+  try:
+    sys.stdout.flush()
+  except Exception:
+    pass
+  libc.fflush(None)
+  saved = os.dup(1)
+  os.dup2(2, 1)
+  try:
+    yield
+  finally:
+    libc.fflush(None)
+    os.dup2(saved, 1)
+    os.close(saved)
+
+
 def _check(rc, what):
   if rc != 0:
     raise RuntimeError("RCCL %s failed: %s" % (what, _load().ncclGetErrorString(rc).decode()))
@@ -72,7 +94,8 @@ class RcclComm(object):
     self.device = torch.cuda.current_device()
     torch.zeros(1, device="cuda")                                   # a live HIP context on this device
     comm = ctypes.c_void_p()
-    _check(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
+    with _c_stdout_to_stderr():
+      _check(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
     self._comm = comm
 
   def _stream(self):
@@ -139,8 +162,9 @@ def try_create(group=None):
   if _all_agree(ok, group):
     try:
       probe = torch.ones(8, dtype=torch.float32, device="cuda")
-      comm.all_reduce(probe)
-      torch.cuda.synchronize()
+      with _c_stdout_to_stderr():
+        comm.all_reduce(probe)
+        torch.cuda.synchronize()
       ok = float(probe[0]) == float(comm.world)
       if not ok:
         last_error = "probe all-reduce returned %r over %d ranks" % (float(probe[0]), comm.world)

@@ -196,7 +196,12 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
     const int b = blk / p.nseg;
     const int x_new = WN_SEG * seg;
     const int x0 = min(x_new, W - WN_SEG);
-    const int dup = x_new - x0;                           // columns below `dup` also belong to the neighbouring segment
+    // The last segment is shifted back to end at the image edge, so it shares columns with its neighbour — and a pixel's rounding
+    // depends on the tile it falls into, which differs between the two (different tile origins): ONE of them must own a shared
+    // column.  The neighbour keeps only its first `keep` columns, the shifted segment writes and counts all 64: the cut is an
+    // UPPER bound, which the hardware applies for free — the output stores go through a buffer descriptor of keep * 128 bytes
+    // per row and the out-of-range ones are dropped (a per-lane predicate on 16 stores cost 15 registers and spilled).
+    const int keep = (seg == p.nseg - 2 && 64 * p.nseg > W) ? W - 64 * (p.nseg - 1) : WN_SEG;
     const long img = (long)b * p.g.Hp;
     const int px0 = x0 - 8 + p.g.pw;
 
@@ -379,8 +384,8 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
           for (int r = 0; r < 16; ++r) res[r] = 0.f;
         }
       }
-      int dup_l = dup;                                     // (opaque: hipcc otherwise hoists the 16 duplicate-column masks of
-      asm volatile("" : "+s"(dup_l));                      //  the last segment out of the tile loop, into 16 registers)
+      int keep_l = keep;                                   // (opaque: hipcc otherwise hoists the 16 shared-column masks of the
+      asm volatile("" : "+s"(keep_l));                     //  moments out of the tile loop, into 16 registers)
       WN_T(3);
       __syncthreads();                                     // B1: the T tiles are in place; nobody reads rows j-1, j any more
       WN_T(4);
@@ -414,22 +419,18 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
           float* gx_base = p.ep.z + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
 #pragma unroll
           for (int r = 0; r < 16; ++r) Y[r] += res[r];
-          // (a pixel's rounding depends on the tile it falls into and the shifted last segment tiles its columns differently:
-          //  the columns it shares with its neighbour are written by the neighbour only)
-#define WN_ST(r) wn_store_imm<WN_IMM(r)>(gx_base, io_off, Y[r]); wn_store_imm<WN_IMM(r)>(gx_base, io_off2, Y[8 + r]);
-#define WN_STM(r) if (WN_COL(r) >= dup_l) wn_store_imm<WN_IMM(r)>(gx_base, io_off, Y[r]); \
-                  if (WN_COL(8 + r) >= dup_l) wn_store_imm<WN_IMM(r)>(gx_base, io_off2, Y[8 + r]);
-          if (dup_l <= 0) { WN_FOR_8(WN_ST) } else { WN_FOR_8(WN_STM) }
+          {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(gx_base, 0, keep_l * 128, 0x00020000);
+#define WN_ST(r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[r]), rs, (int)io_off + WN_IMM(r), 0, 0); \
+                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[8 + r]), rs, (int)io_off2 + WN_IMM(r), 0, 0);
+            WN_FOR_8(WN_ST)
 #undef WN_ST
-#undef WN_STM
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float yv = fmaf(zt[r], bn_sc, bn_sh);
             float gy = yv > 0.f ? Y[r] : Y[r] * p.slope;
-            if (dup_l > 0) {
-              const int col = wn_c0<L>((r & 3) + 8 * (r >> 2)) + wn_c0<L>(4 * h) + oj * d;
-              gy = col >= dup_l ? gy : 0.f;
-            }
+            if (keep_l < WN_SEG) gy = WN_COL(r) < keep_l ? gy : 0.f;
             bn_dy += gy; bn_dx = fmaf(gy, zt[r] - bn_mu, bn_dx);
           }
         }
@@ -453,24 +454,24 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
             Y[r] = yv + res[r];
           }
         }
-#define WN_ST(r) wn_store_imm<WN_IMM(r)>(z_base, io_off, Y[r]); wn_store_imm<WN_IMM(r)>(z_base, io_off2, Y[8 + r]);
-#define WN_STM(r) if (WN_COL(r) >= dup_l) wn_store_imm<WN_IMM(r)>(z_base, io_off, Y[r]); \
-                  if (WN_COL(8 + r) >= dup_l) wn_store_imm<WN_IMM(r)>(z_base, io_off2, Y[8 + r]);
-        if (dup_l <= 0) { WN_FOR_8(WN_ST) } else { WN_FOR_8(WN_STM) }   // (duplicated columns: the neighbouring segment's)
+        {
+          const auto rs = __builtin_amdgcn_make_buffer_rsrc(z_base, 0, keep_l * 128, 0x00020000);
+#define WN_ST(r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[r]), rs, (int)io_off + WN_IMM(r), 0, 0); \
+                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[8 + r]), rs, (int)io_off2 + WN_IMM(r), 0, 0);
+          WN_FOR_8(WN_ST)
 #undef WN_ST
-#undef WN_STM
+        }
         if (!EVAL && p.ep.stat_mean != nullptr) {
-          if (dup_l <= 0) {
+          if (keep_l >= WN_SEG) {
             st_c = st_n == 0.f ? Y[0] : st_c;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float dd = Y[r] - st_c; st_s1 += dd; st_s2 = fmaf(dd, dd, st_s2); }
             st_n += 16.f;
           } else {
-            st_c = st_n == 0.f ? Y[15] : st_c;             // (the last tile's column is never a duplicate: dup < 64)
+            st_c = st_n == 0.f ? Y[0] : st_c;              // (any value will do as the pivot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int col = wn_c0<L>((r & 3) + 8 * (r >> 2)) + wn_c0<L>(4 * h) + oj * d;
-              const bool in = col >= dup_l;
+              const bool in = WN_COL(r) < keep_l;
               const float dd = in ? Y[r] - st_c : 0.f;
               st_s1 += dd; st_s2 = fmaf(dd, dd, st_s2); st_n += in ? 1.f : 0.f;
             }

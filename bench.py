@@ -248,8 +248,28 @@ def dp_path_overhead(args, fsd, ssd, left, right, dev, use_graph, plain_ms):
     return {"value": None, "error": repr(e)[:300]}
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+  """The contract is ONE JSON line on stdout.  Libraries underneath write there too (librccl prints a five-line version banner
+  when a communicator is created — torch.distributed's or this package's): the real stdout is kept aside for the JSON line and
+  file descriptor 1 points at stderr for everything else, C and Python alike."""
+  global _JSON_OUT
+  sys.stdout.flush()
+  _JSON_OUT = os.fdopen(os.dup(1), "w")
+  os.dup2(2, 1)
+
+
+def emit_json(obj):
+  sys.stdout.flush()
+  _JSON_OUT.write(json.dumps(obj) + "\n")
+  _JSON_OUT.flush()
+
+
 def main():
   args = parse()
+  claim_stdout()
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -563,7 +583,7 @@ def main():
   if world == 1 and not args.no_cpu_baseline:
     out["cpu_baseline"] = cpu_baseline(args, fsd, ssd)
     log("cpu baseline done")
-  print(json.dumps(out), flush=True)
+  emit_json(out)
   if world > 1:
     adapter.close()
     dist.destroy_process_group()

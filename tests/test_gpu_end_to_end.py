@@ -10,6 +10,8 @@ tests/golden/reassociation_bound.json (tests/tools/reassociation_bound.py: the o
 convolution summed tap by tap): logits move by <= 6.6e-6 x gain, so an index could only ever flip where the reference's
 own top-2 gap is below ~1.3e-5 x gain — no fixture has such a pixel (smallest gap 2.9e-5 x gain).
 """
+import os
+
 import pytest
 import torch
 
@@ -293,6 +295,22 @@ def test_input_scale_one_and_output_dictionary(side, with_volume):
     got = OnlineAdapter(fnet, snet, H, W, lr=5e-5).step(ld, rd)
     assert abs(float(got["loss"]) - float(ref_step["loss"])) < 2e-5
     assert "pred_disp_l/%d" % s in got["outputs"] and "left_warped/%d" % s in got["outputs"]
+
+
+def test_adaptation_steps_are_bit_reproducible_across_processes():
+  """Two adaptation steps and an inference pass at the benchmark size, hashed (loss, every gradient, every parameter, the
+  disparity) in three FRESH processes: identical.  In-process repeats are not enough — a kernel that consumed a load before its
+  wait (found once: registers copied by the compiler ahead of a hand-placed s_waitcnt) repeated its stale values faithfully
+  inside one process and differed from process to process."""
+  import subprocess, sys
+  tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "step_hash.py")
+  seen = []
+  for _ in range(3):
+    r = subprocess.run([sys.executable, tool, "2", "2"], capture_output=True, text=True, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("STEP_HASH")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    seen.append(lines[0])
+  assert len(set(seen)) == 1, seen
 
 
 # ---- size-independent properties at the full benchmark size ------------------------------------

@@ -62,7 +62,7 @@ def check_kernel(name, lines):
 
 
 def main():
-  files = sys.argv[1:] or [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+  files = [os.path.abspath(f) for f in sys.argv[1:]] or [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
                            if re.search(r'asm volatile\("global_load_dword', open(f).read())]
   bad = 0
   for f in files:
