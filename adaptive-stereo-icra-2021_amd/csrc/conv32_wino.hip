@@ -288,6 +288,8 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
     WN_T(1);
 
     for (int j = j0; j < j1; j += 2) {
+      const bool more = j + 2 < j1;                        // (the last tile of a piece converts nothing: its fetch stays — a
+                                                           //  conditional fetch made hipcc shuffle the load registers)
       fetch_one(j + 3, p.zin, pz);                         // in flight during the matrix phase (the skip rows follow it:
                                                            // ten more registers across the matrix phase spilled)
 #define WN_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
       __builtin_amdgcn_sched_barrier(0);
       WN_T(6);
       WN_T(7);
-      convert_from(j + 3, pz, pa);
+      if (more) convert_from(j + 3, pz, pa);
       WN_T(8);
       __syncthreads();                                     // B2: activated rows j+3, j+4 are in place; the exchange is free
       WN_T(9);
