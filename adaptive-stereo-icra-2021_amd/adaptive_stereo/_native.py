@@ -105,6 +105,9 @@ _SIGNATURES = {
   "as_conv32_wino_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_float, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp,
                                  c_vp, c_vp]),
   "as_conv32_wino_eval": (c_int, [c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp]),
+  "as_conv32_wino_bwd_data": (c_int, [c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp, c_vp, c_vp]),
+  "as_conv32_wino_bwd_filter": (c_int, [c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_conv32_wino_bwd_parts": (c_int, []),
   "as_conv32_wino_bwd_workspace": (c_i64, []),
   "as_conv32_wino_bwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp,

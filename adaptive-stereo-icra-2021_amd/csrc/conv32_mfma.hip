@@ -942,6 +942,50 @@ extern "C" int as_conv32_wino_eval(const float* x, const as_pcl* g, const as_con
 extern "C" int as_conv32_wino_bwd_parts(void) { return conv32_wino_dgrad_parts(); }
 extern "C" int64_t as_conv32_wino_bwd_workspace(void) { return (int64_t)conv32_wino_wgrad_slabs() * (9 * 1024 + 32); }
 
+// The two halves separately (a caller may run the weight gradient on another stream: nothing but the step's final slab
+// reduction waits for it) ...
+extern "C" int as_conv32_wino_bwd_data(const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s,
+                                       const float* wino_wt, const float* scale, const float* shift, const float* mean,
+                                       const float* coef, float slope, const float* next_z, const float* next_scale,
+                                       const float* next_shift, const float* next_mean, float* g_z, float* g_x,
+                                       float* next_bn_workspace, void* stream) {
+  if (int e = check_conv(g, g, s, "as_conv32_wino_bwd_data")) return e;
+  AS_CHECK_ARG(g_a && z && wino_wt && scale && shift && mean && coef && next_z && next_scale && next_shift && next_mean && g_z &&
+               g_x && next_bn_workspace, "as_conv32_wino_bwd_data: null pointer");
+  AS_CHECK_ARG(conv32_wino_applicable(g, g, s), "as_conv32_wino_bwd_data: configuration not supported (as_conv32_wino_ok() == 0)");
+  AS_CHECK_ARG(((uintptr_t)next_bn_workspace & 7) == 0, "as_conv32_wino_bwd_data: the BatchNorm workspace must be 8-byte aligned");
+  AS_CHECK_ARG(slope > 0.f && slope < 1.f, "as_conv32_wino_bwd_data: slope must lie in (0, 1)");
+  AS_CHECK_ARG(g_x != g_a && g_x != z && g_z != g_a && g_z != z && g_z != g_x && g_z != next_z && g_x != next_z,
+               "as_conv32_wino_bwd_data: outputs must not alias inputs or each other");
+  hipStream_t st = (hipStream_t)stream;
+  // (ALGORITHMIC flops of the gradient in its direct form, as as_conv32_bwd_fused counts them)
+  as_prof_mark(AS_PROF_WINO_DGRAD, st, 1, 0.0);
+  if (int e = conv32_wino_dgrad_launch(g_a, z, g, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift,
+                                       next_mean, g_z, g_x, reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
+  as_prof_mark(AS_PROF_WINO_DGRAD, st, 0, 2.0 * (double)g->B * g->H * g->W * 1024.0 * 9);
+  AS_CHECK_LAUNCH("as_conv32_wino_bwd_data");
+  return AS_OK;
+}
+
+extern "C" int as_conv32_wino_bwd_filter(const float* x, const float* g_z, const as_pcl* g, const as_conv_shape* s, float* dW,
+                                         float* db, int accumulate, float* workspace, void* stream) {
+  if (int e = check_conv(g, g, s, "as_conv32_wino_bwd_filter")) return e;
+  AS_CHECK_ARG(x && g_z && dW && workspace, "as_conv32_wino_bwd_filter: null pointer");
+  AS_CHECK_ARG(conv32_wino_applicable(g, g, s), "as_conv32_wino_bwd_filter: configuration not supported (as_conv32_wino_ok() == 0)");
+  const int T = 9;
+  const int slabs = conv32_wino_wgrad_slabs();
+  float* partial_db = workspace + (int64_t)slabs * T * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(AS_PROF_WINO_WGRAD, st, 1, 0.0);
+  if (int e = conv32_wino_wgrad_launch(x, g_z, g, s, workspace, partial_db, stream)) return e;
+  as_prof_mark(AS_PROF_WINO_WGRAD, st, 0, 2.0 * (double)g->B * g->H * g->W * 1024.0 * T);
+  AS_CHECK_LAUNCH("as_conv32_wino_bwd_filter");
+  wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
+  AS_CHECK_LAUNCH("as_conv32_wino_bwd_filter(reduce)");
+  return AS_OK;
+}
+
+// ... and both on one stream
 extern "C" int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
                                   const as_conv_shape* s, const float* wino_wt, const float* scale, const float* shift,
                                   const float* mean, const float* coef, float slope, const float* next_z,
@@ -949,29 +993,11 @@ extern "C" int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float
                                   float* g_x, float* dW, float* db, int accumulate, float* next_bn_workspace,
                                   float* workspace, void* stream) {
   if (int e = check_conv(gin, gout, s, "as_conv32_wino_bwd")) return e;
-  AS_CHECK_ARG(x && g_a && z && wino_wt && scale && shift && mean && coef && next_z && next_scale && next_shift && next_mean &&
-               g_z && g_x && dW && next_bn_workspace && workspace, "as_conv32_wino_bwd: null pointer");
-  AS_CHECK_ARG(conv32_wino_applicable(gin, gout, s), "as_conv32_wino_bwd: configuration not supported (as_conv32_wino_ok() == 0)");
-  AS_CHECK_ARG(((uintptr_t)next_bn_workspace & 7) == 0, "as_conv32_wino_bwd: the BatchNorm workspace must be 8-byte aligned");
-  AS_CHECK_ARG(slope > 0.f && slope < 1.f, "as_conv32_wino_bwd: slope must lie in (0, 1)");
-  AS_CHECK_ARG(g_x != g_a && g_x != x && g_x != z && g_z != g_a && g_z != x && g_z != z && g_z != g_x && g_z != next_z &&
-               g_x != next_z, "as_conv32_wino_bwd: outputs must not alias inputs or each other");
-  const int T = 9;
-  const int slabs = conv32_wino_wgrad_slabs();
-  float* partial_db = workspace + (int64_t)slabs * T * 1024;
-  hipStream_t st = (hipStream_t)stream;
-  // (ALGORITHMIC flops of each gradient in its direct form, as as_conv32_bwd_fused counts them)
-  as_prof_mark(AS_PROF_WINO_DGRAD, st, 1, 0.0);
-  if (int e = conv32_wino_dgrad_launch(g_a, z, gout, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift,
-                                       next_mean, g_z, g_x, reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
-  as_prof_mark(AS_PROF_WINO_DGRAD, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);
-  as_prof_mark(AS_PROF_WINO_WGRAD, st, 1, 0.0);
-  if (int e = conv32_wino_wgrad_launch(x, g_z, gout, s, workspace, partial_db, stream)) return e;
-  as_prof_mark(AS_PROF_WINO_WGRAD, st, 0, 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);
-  AS_CHECK_LAUNCH("as_conv32_wino_bwd");
-  wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
-  AS_CHECK_LAUNCH("as_conv32_wino_bwd(reduce)");
-  return AS_OK;
+  AS_CHECK_ARG(x && dW && workspace, "as_conv32_wino_bwd: null pointer");
+  AS_CHECK_ARG(g_x != x && g_z != x, "as_conv32_wino_bwd: outputs must not alias inputs or each other");
+  if (int e = as_conv32_wino_bwd_data(g_a, z, gout, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift,
+                                      next_mean, g_z, g_x, next_bn_workspace, stream)) return e;
+  return as_conv32_wino_bwd_filter(x, g_z, gout, s, dW, db, accumulate, workspace, stream);
 }
 
 // Convolution (data gradient) fused with stage 1 of the BatchNorm backward that consumes its output.

@@ -177,6 +177,14 @@ int as_conv32_wino_eval(const float* x, const as_pcl* g, const as_conv_shape* s,
  *   next_bn_workspace   as_conv32_wino_bwd_parts() partials of [64] doubles;  workspace: as_conv32_wino_bwd_workspace() floats */
 int as_conv32_wino_bwd_parts(void);
 int64_t as_conv32_wino_bwd_workspace(void);
+/* the two launches separately (the weight gradient may go to another stream: only the step's slab reduction waits for it) */
+int as_conv32_wino_bwd_data(const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s,
+                            const float* wino_wt, const float* scale, const float* shift, const float* mean,
+                            const float* coef, float slope, const float* next_z, const float* next_scale,
+                            const float* next_shift, const float* next_mean, float* g_z, float* g_x,
+                            float* next_bn_workspace, void* stream);
+int as_conv32_wino_bwd_filter(const float* x, const float* g_z, const as_pcl* g, const as_conv_shape* s, float* dW,
+                              float* db, int accumulate, float* workspace, void* stream);
 int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
                        const as_conv_shape* s, const float* wino_wt, const float* scale, const float* shift,
                        const float* mean, const float* coef, float slope, const float* next_z,
