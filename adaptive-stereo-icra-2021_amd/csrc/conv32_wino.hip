@@ -108,6 +108,8 @@ template <int L> __device__ inline int wn_addr(int v, int chunk) { return wn_pos
 // MODE 0: training forward, no skip input; 1: training forward with skip input; 2: data gradient;
 // 3: eval forward — the operand x is staged as is, out = lrelu((conv(x) + bias) * scale + shift) (+ x: the BasicBlock's skip
 //    connection, read from the staged rows), nothing else written
+// (diagnostic build -DWN_BWD_ONE_WG: the data gradient with one workgroup per CU, 512 registers per wave and every load requested
+//  at the top of the tile — measured 397-435 us against 285-317 with two workgroups per CU: DESIGN 4)
 #ifdef WN_BWD_ONE_WG
 #define WN_WGS_PER_CU(MODE) ((MODE) == 2 ? 1 : 2)
 #else

@@ -16,6 +16,11 @@
 // buffers of a g_z row pair — the rows of TWO tiles are in flight (with one, 9 MB in flight chip-wide against ~3 us of loaded
 // HBM latency capped the launch at ~3 TB/s: 190-210 us where the matrix work is 111).  At the end the waves exchange (M A) through LDS, apply A^T and write the workgroup's slab
 // [9][32][32] (+ bias partial) for the batch reduce that every weight gradient of the step shares.
+//
+// Diagnostic builds (tests/tools/wino_exp.sh rebuilds with EXTRA=-D...; results are then WRONG, only the time means something):
+// WW_EXP_NODMA (no row traffic in the tile loop), WW_EXP_NOLOAD (no operand reads), WW_EXP_NOVALU (operands fed to the MFMAs as
+// they come), WW_EXP_NOMFMA (data movement only) — they gave the floors quoted in DESIGN 4: matrix work alone 121-127 us, + loads
+// +15, + transforms +15, both +55, data movement alone 100 us.
 #include "as_common.h"
 #include "conv32_wino.h"
 
