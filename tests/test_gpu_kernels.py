@@ -1089,6 +1089,99 @@ def test_conv32_backward_fused_in_one_launch(B, H, W, dil):
   from conftest import parity_note
   parity_note("bwd_fused[%s]" % tag, g_x_bit_identical=exact)
 
+def _wino_edge_cases():
+  """Geometries around every edge of the minimal-filtering kernels' tiling: W = 64 k + {0, 1, 63} (no shifted segment; a
+  neighbour that keeps ONE column; one that keeps 63), H = 2 d and 2 d + 1 (combs of two rows and of one pair + a lone row),
+  H odd / even, every dilation — with the batch chosen so that as_conv32_wino_ok accepts the launch."""
+  cases = []
+  for dil in (1, 2, 4, 8):
+    for H, W in ((2 * dil, 129), (2 * dil + 1, 64), (37, 65), (50, 127), (51, 192), (23 + dil, 191)):
+      if H < 2 * dil:
+        continue
+      pairs = sum(((H - r + dil - 1) // dil + 1) // 2 for r in range(dil))
+      B = -(-2048 // (((W + 63) // 64) * pairs))
+      if B * H * W * 32 * 4 <= 600e6:
+        cases.append((B, H, W, dil))
+  return cases
+
+
+@pytest.mark.parametrize("B,H,W,dil", _wino_edge_cases())
+def test_minimal_filtering_kernels_on_the_edges_of_their_tiling(B, H, W, dil):
+  """Forward (with skip input), inference block, data gradient and weight gradient by minimal filtering against the direct
+  kernels on small odd geometries: every output within 3e-6 of the direct result's scale (both are fp32 roundings of the same sums),
+  nothing written into the halo, element counts exact."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_wino_ok(g, g, shape) == 1
+  T = lambda seed: ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=seed).to(DEV), g)
+  z_prev, a_pp, x, g_a, zz, zn = T(1), T(2), T(3), T(4), T(5), T(6)
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  b = (rnd(32, seed=10) * 0.1).to(DEV)
+  wp, wp_t = ops.pack_weights(w, shape, False), ops.pack_weights(w, shape, True)
+  ww, ww_t = torch.empty(16 * 1024, device=DEV), torch.empty(16 * 1024, device=DEV)
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww), 0, nat.stream())
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww_t), 1, nat.stream())
+  st = ops.BnState(DEV)
+  st.mean.copy_(rnd(32, seed=5).to(DEV) * 0.1); st.invstd.copy_(rnd(32, seed=6).abs().to(DEV) + 0.5)
+  st.scale.copy_(st.invstd * 1.1); st.shift.copy_(rnd(32, seed=7).to(DEV) * 0.1 - st.mean * st.scale)
+  tag = "edge B%d H%d W%d d%d" % (B, H, W, dil)
+  def same(got, exp, what):
+    for buf in (got,):
+      full = ops.pcl_view(buf, g).clone(); ops.pcl_interior(full, g).zero_()
+      assert float(full.abs().max()) == 0.0, "%s: %s written into the halo" % (tag, what)
+    gi, ei = ops.pcl_interior(ops.pcl_view(got, g), g), ops.pcl_interior(ops.pcl_view(exp, g), g)
+    err, scale = float((gi - ei).abs().max()), float(ei.abs().max())
+    assert err <= 3e-6 * scale, "%s: %s differs by %.3e (scale %.3e)" % (tag, what, err, scale)
+  # forward (training, with skip input)
+  a_ref = ops.bn_act(z_prev, st, g, residual=a_pp, out=ops.pcl_zeros(g, DEV))
+  z_ref = ops.conv32(a_ref, g, wp, b, g, shape, out=ops.pcl_zeros(g, DEV))
+  a_out, z = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  stats = ops.StatParts(lib.as_conv32_wino_parts(), DEV)
+  nat.call("as_conv32_wino_fwd", nat.ptr(z_prev), nat.ptr(a_pp), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a_out), g,
+           nat.ptr(ww), nat.ptr(b), 0.2, nat.ptr(z), g, shape, nat.ptr(stats.mean), nat.ptr(stats.m2), nat.ptr(stats.cnt),
+           nat.stream())
+  assert bool(torch.equal(a_out, a_ref)), tag + ": by-product"
+  same(z, z_ref, "forward z")
+  assert float(stats.cnt.sum()) == float(B * H * W), tag + ": moments count"
+  # inference block
+  e_ref = ops.conv32(x, g, wp, b, g, shape, out=ops.pcl_zeros(g, DEV), epilogue=1, scale=st.scale, shift=st.shift, residual=x)
+  e_out = ops.pcl_zeros(g, DEV)
+  nat.call("as_conv32_wino_eval", nat.ptr(x), g, shape, nat.ptr(ww), nat.ptr(b), nat.ptr(st.scale), nat.ptr(st.shift), 0.2, 1,
+           nat.ptr(e_out), nat.stream())
+  same(e_out, e_ref, "inference block")
+  # backward
+  ws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  gg, gb = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+  gamma = torch.full((32,), 1.1, device=DEV)
+  nat.call("as_bn_act_bwd", nat.ptr(g_a), nat.ptr(zz), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(st.mean),
+           nat.ptr(st.invstd), nat.ptr(gamma), 0.2, 1, None, nat.ptr(gg), nat.ptr(gb), 0, nat.ptr(ws), g, nat.stream())
+  coef = ws[lib.as_bn_bwd_coef_offset():]
+  gz, gx = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  dW, db = torch.zeros(32, 32, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+  nws = torch.empty(lib.as_bn_bwd_workspace(g), device=DEV)
+  fws = torch.empty(lib.as_conv32_wino_bwd_workspace(), device=DEV)
+  nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(st.scale), nat.ptr(st.shift),
+           nat.ptr(st.mean), nat.ptr(gz), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(nws), nat.ptr(fws), nat.stream())
+  # references from g_z itself: direct data gradient + skip, autograd-free weight gradient on the CPU in fp64
+  gx_ref = ops.conv32(gz, g, wp_t, None, g, shape, out=ops.pcl_zeros(g, DEV), residual=g_a)
+  same(gx, gx_ref, "data gradient")
+  gz64 = ops.pcl_to_ncdhw(gz, g)[:, :, 0].double().cpu(); x64 = ops.pcl_to_ncdhw(x, g)[:, :, 0].double().cpu()
+  dW64 = torch.nn.grad.conv2d_weight(x64, tuple(w.shape), gz64, padding=dil, dilation=dil)
+  assert float((dW.double().cpu() - dW64).norm() / dW64.norm()) < 3e-6, tag + ": weight gradient"
+  # (a sum of ~1e5 signed terms: its fp32 rounding scales with the sum of magnitudes, not with the result)
+  assert float((db.double().cpu() - gz64.sum(dim=(0, 2, 3))).abs().max()) <= 5e-7 * float(gz64.abs().sum(dim=(0, 2, 3)).max()), \
+      tag + ": bias gradient"
+  # g_z itself: stage 3 of the BatchNorm backward, element-wise in fp32
+  k1, k2, k3 = coef[:32].view(1, 32, 1, 1), coef[32:64].view(1, 32, 1, 1), coef[64:96].view(1, 32, 1, 1)
+  zz_n = ops.pcl_to_ncdhw(zz, g)[:, :, 0]; ga_n = ops.pcl_to_ncdhw(g_a, g)[:, :, 0]
+  yy = zz_n * st.scale.view(1, 32, 1, 1) + st.shift.view(1, 32, 1, 1)
+  gy = torch.where(yy > 0, ga_n, ga_n * 0.2)
+  gz_exp = (gy - k1 - (zz_n - st.mean.view(1, 32, 1, 1)) * k2) * k3
+  assert float((ops.pcl_to_ncdhw(gz, g)[:, :, 0] - gz_exp).abs().max()) <= 2e-6 * float(gz_exp.abs().max()), tag + ": g_z"
+
+
 @pytest.mark.parametrize("B,H,W,dil,skip", [(2, 160, 1242, 1, True), (1, 375, 1242, 2, True), (2, 161, 1030, 4, True),
                                             (2, 163, 1237, 8, True), (4, 97, 700, 1, False)])
 def test_conv32_eval_block_by_minimal_filtering(B, H, W, dil, skip):
