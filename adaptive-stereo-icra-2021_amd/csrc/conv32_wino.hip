@@ -17,7 +17,7 @@
 //   wave w = (i, j): Y[i][j] = (A^T T)[i][j] = a signed sum of three waves' T[j]; + bias; 16 stores; BatchNorm moments
 //   rows j+3, j+4: activate, by-product, into the two freed slots
 //   B2
-// Two workgroups per CU (73,984 B of LDS each): one's vector phases under the other's matrix phase.
+// Two workgroups per CU (74,496 B of LDS each): one's vector phases under the other's matrix phase.
 // The LDS rows are swizzled for the stride-2d tile gather: with key(v) = the voxel index with bit log2(d) removed, the 32
 // tiles of one read are 32 consecutive keys; key bit 0 selects the bank half (it is the voxel's parity for d > 1; for d = 1
 // voxels are stored with bits 0 and 1 swapped) and key bits 1-3 the 16-byte slot.
@@ -28,8 +28,11 @@
 // connection (g_x = dgrad(g_z) + g_a) and forms stage 1 of the NEXT BatchNorm backward from the g_x register tile: the
 // data-gradient half of conv32_bwd.hip with 4 matrix products per pixel instead of 9.
 //
-// Numerics: B^T and A^T are signed sums (no constants); G carries two factors 1/2.  Against the direct form in fp32 the
-// result differs by reassociation-level rounding (tests/test_gpu_kernels.py states the bound).
+// MODE 3 is the INFERENCE block: the operand is staged as is, the epilogue applies the folded BatchNorm, LeakyReLU and the skip
+// connection, which it reads from the staged rows (one read of x, one write).
+//
+// Numerics: B^T and A^T are signed sums (no constants); G carries two factors 1/2.  Against the fp64 result of the same fp32
+// operands the outputs are closer than the direct kernels' (tests/test_gpu_kernels.py holds them to "not further than 2x").
 #include "as_common.h"
 #include "conv_epilogue.h"
 #include "conv32_wino.h"
