@@ -21,6 +21,8 @@ Data parallel semantics (one process per GPU, ``torch.distributed`` backend "ncc
   clip + Adam.  BatchNorm statistics are per-replica
   (each rank normalises with its own shard's statistics), as in torch DDP without SyncBatchNorm.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -33,22 +35,46 @@ from .utils.feature_contrast import feature_contrast_mean
 from .utils.ema import online_ema
 
 
+def _release_comm(comm):
+  try:
+    if torch.cuda.is_available():
+      torch.cuda.synchronize()
+    comm.destroy()
+  except Exception:                        # noqa: BLE001 — interpreter shutdown: nothing left to report to
+    pass
+
+
+def never_executed(name):
+  """BasicBlock.conv2 is constructed but never called by the reference (stereo_net.py:40 against :44-51): its tensors are part
+  of the state_dict, receive no gradient (``grad is None``: torch.optim.Adam skips them, adapt.py:208-210) and never change."""
+  return ".conv2." in name
+
+
 class FlatArena(object):
-  """Re-homes the parameters of ``modules`` into one flat fp32 buffer (and a twin for gradients)."""
+  """Re-homes the parameters of ``modules`` that take part in a step into one flat fp32 buffer (and a twin for gradients).
+  The never-executed ``conv2.*`` tensors (111,744 floats at k=4) stay where they are, with ``grad = None`` as in the
+  reference: they ride neither in the gradient all-reduce nor in the clip norm nor in Adam (313,698 floats do)."""
 
   def __init__(self, modules):
-    self.entries = []          # (module index, name, param, offset, numel)
+    self.entries = []          # (module index, name, param, offset, numel): the parameters that live in the arena
     self.group_bounds = []     # (start, end) per module, in floats
+    self.all_params = []       # per module: [(name, param, in the arena?)] in named_parameters() order (adam.pth indices)
     offset = 0
     params = []
     for mi, m in enumerate(modules):
       start = offset
+      listed = []
       for name, p in m.named_parameters():
+        live = not never_executed(name)
+        listed.append((name, p, live))
+        if not live:
+          continue
         n = p.numel()
         self.entries.append((mi, name, p, offset, n))
         params.append(p)
         offset += n
         offset = (offset + 3) // 4 * 4        # keep every tensor 16-byte aligned
+      self.all_params.append(listed)
       self.group_bounds.append((start, offset))
     self.numel = offset
     dev = params[0].device
@@ -118,16 +144,17 @@ class FusedClipAdam(object):
     """torch.optim.Adam-compatible layout (what the reference writes to adam.pth, train.py:136-137): one
     entry per parameter that has received a gradient, param groups in arena order."""
     state, groups, index = {}, [], 0
-    for gi, (s, e) in enumerate(self.arena.group_bounds):
+    where = {id(p): (off, n) for _, _, p, off, n in self.arena.entries}
+    for gi, listed in enumerate(self.arena.all_params):
       ids = []
-      for mi, name, p, off, n in self.arena.entries:
-        if mi != gi:
-          continue
+      for name, p, live in listed:             # every parameter has an index; the never-executed ones have no state
         ids.append(index)
-        if self.step_count > 0 and float(self.exp_avg_sq[off:off + n].abs().sum()) > 0:
-          state[index] = {"step": torch.tensor(float(self.step_count)),
-                          "exp_avg": self.exp_avg[off:off + n].view(p.shape).detach().cpu().clone(),
-                          "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).detach().cpu().clone()}
+        if live and self.step_count > 0:
+          off, n = where[id(p)]
+          if float(self.exp_avg_sq[off:off + n].abs().sum()) > 0:
+            state[index] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view(p.shape).detach().cpu().clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).detach().cpu().clone()}
         index += 1
       groups.append({"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
                      "params": ids})
@@ -167,6 +194,10 @@ class OnlineAdapter(object):
     if self.dp and native_collectives:
       from . import rccl
       self.comm = rccl.try_create(process_group)
+      if self.comm is not None:
+        # close() is the orderly release (collective, before the process group goes); an adapter that is dropped or still alive
+        # at interpreter exit releases its communicator through this finalizer instead of leaking it
+        self._comm_finalizer = weakref.finalize(self, _release_comm, self.comm)
     self.bn_sync = hip_ops.BnSync(process_group, self.comm) if (sync_bn and (self.world > 1 or force_data_parallel)) else None
     dev = self.arena.params.device
     self.scalars = self.arena.step_scalars       # [valid count, loss sum, FCS sum, FCS count], behind the gradients
@@ -444,6 +475,7 @@ class OnlineAdapter(object):
       self._graph = None                 # a captured graph holds nodes of this communicator
       self.comm.destroy()
       self.comm = None
+      self._comm_finalizer.detach()
       if self.bn_sync is not None:
         self.bn_sync.comm = None
 
@@ -462,7 +494,7 @@ class OnlineAdapter(object):
 
   # -- hipGraph capture of the whole step ------------------------------------------------------------
   def capture(self, left, right, warmup=3):
-    """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~320 kernel launches) into
+    """Captures one adaptation step (forward, loss, backward, clip, Adam, EMA: ~130 kernel launches) into
     hipGraphs and replays them from then on.  (capture_error_mode="thread_local": the process-group watchdog thread
     queries events while a capture is open; only this thread's calls have to be capture-safe.)  Every entry point of the C ABI only enqueues work on the current
     stream, so the capture sees them as plain kernel nodes; the Adam step count lives on the device.  Inputs

@@ -15,6 +15,7 @@ import ctypes
 import glob
 import os
 import sys
+import threading
 
 import torch
 import torch.distributed as dist
@@ -49,24 +50,34 @@ def _load():
   return _lib
 
 
+_FD_LOCK = threading.Lock()
+
+
 @contextlib.contextmanager
 def _c_stdout_to_stderr():
   """librccl prints a version banner (five lines) to the C stdout when a communicator is created; a library must not write to
-  its host's stdout (bench.py's contract is ONE JSON line there): file descriptor 1 points at stderr for the duration."""
-  libc = ctypes.CDLL(None)
-  try:
-    sys.stdout.flush()
-  except Exception:
-    pass
-  libc.fflush(None)
-  saved = os.dup(1)
-  os.dup2(2, 1)
-  try:
+  its host's stdout (bench.py's contract is ONE JSON line there): file descriptor 1 points at stderr for the duration.
+  The swap is process-wide — another thread's stdout writes go to stderr meanwhile — so it is serialised by a lock (two
+  adapters built concurrently cannot restore each other's descriptor) and an application that owns its stdout already
+  (bench.py's claim_stdout) or does not mind the banner turns it off with AS_RCCL_KEEP_STDOUT=1."""
+  if os.environ.get("AS_RCCL_KEEP_STDOUT"):
     yield
-  finally:
+    return
+  with _FD_LOCK:
+    libc = ctypes.CDLL(None)
+    try:
+      sys.stdout.flush()
+    except Exception:
+      pass
     libc.fflush(None)
-    os.dup2(saved, 1)
-    os.close(saved)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+      yield
+    finally:
+      libc.fflush(None)
+      os.dup2(saved, 1)
+      os.close(saved)
 
 
 def _check(rc, what):
@@ -75,28 +86,12 @@ def _check(rc, what):
 
 
 class RcclComm(object):
-  """One RCCL communicator over the ranks of ``group`` (default: the world), created on the CURRENT HIP device.
-  Construction is collective: every rank of the group must call it."""
+  """One RCCL communicator over the ranks of ``group``, on the CURRENT HIP device.  Built by ``try_create`` (the staged,
+  agreed-on construction below); the constructor only wraps an initialised ``ncclComm_t``."""
 
-  def __init__(self, group=None):
-    lib = _load()
-    self.group = group
-    self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-    uid = _UniqueId()
-    if self.rank == 0:
-      _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-    # (all 128 bytes: reading the c_char array field would stop at the first NUL)
-    box = [ctypes.string_at(ctypes.addressof(uid), 128) if self.rank == 0 else None]
-    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    if len(box[0]) != 128:
-      raise RuntimeError("adaptive_stereo.rccl: unique id of %d bytes" % len(box[0]))
-    ctypes.memmove(ctypes.addressof(uid), box[0], 128)
+  def __init__(self, handle, group, rank, world):
+    self._comm, self.group, self.rank, self.world = handle, group, rank, world
     self.device = torch.cuda.current_device()
-    torch.zeros(1, device="cuda")                                   # a live HIP context on this device
-    comm = ctypes.c_void_p()
-    with _c_stdout_to_stderr():
-      _check(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
-    self._comm = comm
 
   def _stream(self):
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -129,54 +124,139 @@ class RcclComm(object):
     self._comm = None
 
 
+class _RcclStages(object):
+  """What the staged construction does at each stage, for real.  (tests/test_distributed_cpu.py drives the same protocol over
+  a gloo group with stand-ins for these five methods.)"""
+  agree_device = "cuda"
+
+  def load(self):
+    _load()
+
+  def unique_id(self):
+    uid = _UniqueId()
+    _check(_load().ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+    return ctypes.string_at(ctypes.addressof(uid), 128)     # (all 128 bytes: the c_char array field would stop at a NUL)
+
+  def prepare(self):
+    return torch.ones(8, dtype=torch.float32, device="cuda")    # a live HIP context on this device + the probe's buffer
+
+  def init(self, uid_bytes, group, rank, world):
+    uid = _UniqueId()
+    ctypes.memmove(ctypes.addressof(uid), uid_bytes, 128)
+    comm = ctypes.c_void_p()
+    with _c_stdout_to_stderr():
+      _check(_load().ncclCommInitRank(ctypes.byref(comm), world, uid, rank), "ncclCommInitRank")
+    return RcclComm(comm, group, rank, world)
+
+  def probe(self, comm, probe):
+    with _c_stdout_to_stderr():
+      comm.all_reduce(probe)
+      torch.cuda.synchronize()
+    if float(probe[0]) != float(comm.world):
+      raise RuntimeError("probe all-reduce returned %r over %d ranks" % (float(probe[0]), comm.world))
+
+
 last_error = None          # why the most recent try_create() on this rank gave up (for logs and tests)
 
 
-def _all_agree(ok, group):
-  flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+def _injected_failure(stage, rank):
+  """AS_RCCL_FAIL_AT="stage:rank" (stages: load, unique_id, receive, prepare, init, probe) makes that stage fail on that rank
+  — how the tests walk every exit of the protocol.  The local stages fail before they run; the two COLLECTIVE stages (init =
+  ncclCommInitRank, probe = an all-reduce of the new communicator) fail after the collective has returned, i.e. the case
+  "the call came back with an error on this rank": a rank that never ENTERS a collective the others are in is beyond what
+  any agreement can repair, which is why everything fallible and local (library, id, device context, probe buffer) is done
+  and agreed on before the first of them."""
+  spec = os.environ.get("AS_RCCL_FAIL_AT")
+  if spec and spec == "%s:%d" % (stage, rank):
+    raise RuntimeError("injected failure at stage %s on rank %d (AS_RCCL_FAIL_AT)" % (stage, rank))
+
+
+def _all_agree(ok, group, device="cuda"):
+  flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
   dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
   return int(flag) == 1
 
 
+def _create_staged(group, stages):
+  """The construction protocol: every rank runs the SAME sequence of process-group collectives whatever fails locally —
+    load | agree | rank 0 draws the unique id (None on failure) | broadcast | agree on "id received" | HIP context | agree |
+    ncclCommInitRank | agree | probe all-reduce | agree
+  — so a rank that fails at any stage never leaves the others inside a collective it does not enter itself: a failure is
+  carried to the next agreement and all ranks leave together with None.  (Round 3 raised out of the constructor when
+  ncclGetUniqueId failed on rank 0, i.e. BEFORE the broadcast the other ranks were already waiting in.)"""
+  global last_error
+  rank, world = dist.get_rank(group), dist.get_world_size(group)
+  dev = stages.agree_device
+  err = None
+
+  def attempt(stage, fn, collective=False):
+    nonlocal err
+    if err is not None:
+      return None
+    try:
+      if not collective:
+        _injected_failure(stage, rank)
+      out = fn()
+      if collective:
+        _injected_failure(stage, rank)
+      return out
+    except Exception as e:                 # noqa: BLE001 — whatever fails, the protocol goes on to the next agreement
+      err = "%s: %r" % (stage, e)
+      return None
+
+  def agreed():
+    return _all_agree(err is None, group, dev)
+
+  def give_up(comm=None):
+    global last_error
+    last_error = err if err is not None else "another rank could not build its communicator"
+    if comm is not None:
+      try:
+        comm.destroy()
+      except Exception:                    # noqa: BLE001
+        pass
+    return None
+
+  attempt("load", stages.load)
+  if not agreed():
+    return give_up()
+  uid = attempt("unique_id", stages.unique_id) if rank == 0 else None
+  box = [uid if rank == 0 else None]       # None travels when rank 0 could not draw an id: the broadcast is ALWAYS reached
+  src = dist.get_global_rank(group, 0) if group is not None else 0
+  dist.broadcast_object_list(box, src=src, group=group)
+
+  def received():
+    if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != 128:
+      raise RuntimeError("no unique id arrived from rank 0 (%r)" % (type(box[0]).__name__,))
+    return bytes(box[0])
+  uid = attempt("receive", received)
+  if not agreed():
+    return give_up()
+  probe_buf = attempt("prepare", stages.prepare)
+  if not agreed():                         # everyone holds the id, a device context and its probe buffer: only now is the
+                                           # collective init entered
+    return give_up()
+  made = []
+
+  def init():
+    made.append(stages.init(uid, group, rank, world))
+    return made[0]
+  attempt("init", init, collective=True)
+  comm = made[0] if made else None
+  if not agreed():
+    return give_up(comm)
+  attempt("probe", lambda: stages.probe(comm, probe_buf), collective=True)
+  if not agreed():
+    return give_up(comm)
+  return comm
+
+
 def try_create(group=None):
   """A communicator for ``group`` if EVERY rank can build one, else None on every rank (the caller then keeps the c10d
-  collectives, outside any capture).  Each stage is agreed on through the process group before the next collective call,
-  so a rank that fails early never leaves the others waiting inside one."""
+  collectives, outside any capture).  See ``_create_staged`` for the protocol."""
   global last_error
   last_error = None
   if not torch.cuda.is_available() or dist.get_backend(group) != "nccl":
     last_error = "not an nccl process group on a GPU"
     return None
-  try:
-    _load()
-    ok = True
-  except Exception as e:
-    ok, last_error = False, repr(e)
-  if not _all_agree(ok, group):
-    return None
-  comm = None
-  try:
-    comm = RcclComm(group)
-  except Exception as e:
-    ok, last_error = False, repr(e)
-  if _all_agree(ok, group):
-    try:
-      probe = torch.ones(8, dtype=torch.float32, device="cuda")
-      with _c_stdout_to_stderr():
-        comm.all_reduce(probe)
-        torch.cuda.synchronize()
-      ok = float(probe[0]) == float(comm.world)
-      if not ok:
-        last_error = "probe all-reduce returned %r over %d ranks" % (float(probe[0]), comm.world)
-    except Exception as e:
-      ok, last_error = False, repr(e)
-    if _all_agree(ok, group):
-      return comm
-  if last_error is None:
-    last_error = "another rank could not build its communicator"
-  if comm is not None:
-    try:
-      comm.destroy()
-    except Exception:
-      pass
-  return None
+  return _create_staged(group, _RcclStages())

@@ -163,3 +163,100 @@ def test_replay_term_denominator_is_clamped_after_the_reduction():
       if n == 0.0:
         assert float(coef) == 0.0
     assert abs(total_grad_weight / 1000.0 - w * sum(sums) / M) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The staged construction of the library's own RCCL communicator (adaptive_stereo/rccl.py: _create_staged), driven over a
+# gloo group with stand-ins for the five RCCL stages: a failure injected at EVERY stage, on either rank, must leave both
+# ranks with None — together, within the time limit, having run the same sequence of process-group collectives (a rank that
+# left early would make the trailing barrier below hang or fail).  Round 3's constructor raised out of ncclGetUniqueId on
+# rank 0 before the broadcast the other ranks were already waiting in.
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeComm(object):
+  def __init__(self, rank, world):
+    self.rank, self.world, self.destroyed = rank, world, False
+
+  def destroy(self):
+    self.destroyed = True
+
+
+class _FakeStages(object):
+  agree_device = "cpu"
+
+  def __init__(self):
+    self.calls = []
+
+  def load(self):
+    self.calls.append("load")
+
+  def unique_id(self):
+    self.calls.append("unique_id")
+    return bytes(range(128))
+
+  def prepare(self):
+    self.calls.append("prepare")
+    return torch.ones(1)
+
+  def init(self, uid, group, rank, world):
+    assert uid == bytes(range(128))
+    self.calls.append("init")
+    return _FakeComm(rank, world)
+
+  def probe(self, comm, t):
+    self.calls.append("probe")
+    dist.all_reduce(t)                      # a collective of the communicator: entered by every rank or by none
+    assert int(t) == comm.world
+
+
+RCCL_STAGES = ("load", "unique_id", "receive", "prepare", "init", "probe")
+
+
+def _staged_worker(rank, world, port, out_dir):
+  import datetime
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+  dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+  from adaptive_stereo import rccl
+  rows = []
+  cases = [None] + ["%s:%d" % (s_, r_) for s_ in RCCL_STAGES for r_ in range(world) if not (s_ == "unique_id" and r_ != 0)]
+  for spec in cases:
+    if spec is None:
+      os.environ.pop("AS_RCCL_FAIL_AT", None)
+    else:
+      os.environ["AS_RCCL_FAIL_AT"] = spec
+    stages = _FakeStages()
+    comm = rccl._create_staged(None, stages)
+    dist.barrier()                          # both ranks are out of the protocol, in step
+    rows.append((spec, comm is not None, list(stages.calls), rccl.last_error))
+  os.environ.pop("AS_RCCL_FAIL_AT", None)
+  torch.save(rows, os.path.join(out_dir, "staged_%d.pt" % rank))
+  dist.destroy_process_group()
+
+
+def test_staged_communicator_construction_never_strands_a_rank(tmp_path):
+  mp.spawn(_staged_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+  r0, r1 = (torch.load(str(tmp_path / ("staged_%d.pt" % r))) for r in range(2))
+  assert len(r0) == len(r1) == 1 + 2 * len(RCCL_STAGES) - 1
+  for (spec, ok0, calls0, err0), (spec1, ok1, calls1, err1) in zip(r0, r1):
+    assert spec == spec1
+    if spec is None:
+      assert ok0 and ok1 and calls0 == ["load", "unique_id", "prepare", "init", "probe"] and calls1 == ["load", "prepare", "init", "probe"]
+      continue
+    stage, who = spec.split(":")
+    assert not ok0 and not ok1, "a failure at %s must give None on EVERY rank" % spec
+    failed_err, other_err = (err0, err1) if who == "0" else (err1, err0)
+    assert failed_err.startswith(stage + ":") and "injected" in failed_err, (spec, failed_err)
+    if spec == "unique_id:0":               # the None that travelled instead of an id is the other rank's own evidence
+      assert other_err.startswith("receive:") and "no unique id arrived" in other_err, (spec, other_err)
+    else:
+      assert other_err == "another rank could not build its communicator", (spec, other_err)
+    # nobody entered a stage behind the failed one's agreement: the collective init / probe only run when every rank got there
+    later = RCCL_STAGES[RCCL_STAGES.index(stage) + 1:]
+    gate = {"load": ("unique_id", "prepare", "init", "probe"), "unique_id": ("prepare", "init", "probe"),
+            "receive": ("prepare", "init", "probe"), "prepare": ("init", "probe"), "init": ("probe",), "probe": ()}[stage]
+    for calls in (calls0, calls1):
+      assert not (set(calls) & set(gate)), (spec, calls, later)
+    if stage in ("init", "probe"):          # the collective stages were entered by BOTH ranks (the error came out of the call)
+      assert stage in calls0 and stage in calls1, (spec, calls0, calls1)

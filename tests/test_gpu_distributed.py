@@ -221,8 +221,13 @@ def test_two_rank_sync_batchnorm_equals_the_whole_batch_step(tmp_path):
     if key.endswith(".bias") and wkey in grads and float(ref.abs().max()) < 1e-4 * float(grads[wkey].abs().max()):
       continue                                   # a convolution bias in front of a BatchNorm: exactly zero in theory
     if key.endswith(("conv2d_out.bias", "conv3d_alone.bias")):
-      continue                                   # a single number = signed sum over every pixel: cancellation-dominated (as in
-                                                 # test_gpu_end_to_end.py; 5.2e-3 seen once the two sides ran different trunk kernels)
+      # a single number = signed sum over every pixel: cancellation-dominated, so a RELATIVE bound says nothing (5.2e-3 seen once
+      # the two sides ran different trunk kernels) — held instead to an absolute bound on the scale of the sum's terms, for which
+      # the same layer's weight gradient (the same per-pixel terms times O(1) activations) stands in
+      scale_w = float(grads[wkey].abs().max())
+      assert float((got["grads"][key] - ref).abs().max()) <= 2e-3 * scale_w + 1e-7, \
+          "%s: |%.3e - %.3e| against a weight-gradient scale of %.3e" % (key, float(got["grads"][key].reshape(-1)[0]), float(ref.reshape(-1)[0]), scale_w)
+      continue
     rel = float((got["grads"][key].double() - ref.double()).norm() / ref.double().norm())
     worst = max(worst, rel)
     # (the whole-batch step runs the cost aggregation on the rolling-window kernels, the two ranks — collectives inside the

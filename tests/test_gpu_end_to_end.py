@@ -51,8 +51,11 @@ def _measured(gain):
 
 
 def grad_bounds(gain):
-  """(per-tensor relative L2, whole-network relative L2, clip-norm relative error, sign-flip fraction): 2 x measured."""
-  return tuple(2.0 * v for v in _measured(gain))
+  """(per-tensor relative L2, whole-network relative L2, clip-norm relative error, sign-flip fraction): 2 x measured — the
+  clip norm capped at 4e-3 whatever the reassociation experiment shows (it scales EVERY stereo_net gradient: the GPU has never
+  been further off than 1.8e-3, and a 1.7 % error, which 2 x measured would admit at gain 20, is not an acceptable norm)."""
+  t, w, c, f = (2.0 * v for v in _measured(gain))
+  return t, w, min(c, 4e-3), f
 
 
 BN_ATOL, BN_RTOL = 6e-5, 3e-4      # measured worst: 4.6e-5 absolute on a running_var of the refinement at gain 20
@@ -189,6 +192,16 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
       continue
     orc.adam_step(w0, g * (coef_gpu if mi == 0 else 1.0), {}, lr)
     assert float((p.detach().cpu() - w0).abs().max()) <= 2e-7, "Adam step of %s.%s" % (names[mi], name)
+  # BasicBlock.conv2 (stereo_net.py:40: constructed, never called): outside the arena, no gradient, never moved — exactly the
+  # fixture's list of parameters the reference left without a gradient
+  outside = set()
+  for mi, listed in enumerate(arena.all_params):
+    for name, p, live in listed:
+      if not live:
+        outside.add("%s.%s" % (names[mi], name))
+        assert p.grad is None and torch.equal(p.detach().cpu(), init[names[mi]][name]), name
+  assert outside == set(gold.no_grad_keys), (sorted(outside ^ set(gold.no_grad_keys)))
+  assert arena.numel == sum(n for _, _, _, _, n in arena.entries)      # (every tensor's size is a multiple of 4: no padding)
 
   # the state after the step against the reference's (fixture "after/..."), every element: Adam's first step is
   # lr*g/(|g|+1e-8), i.e. +-lr by the SIGN of g, so the GPU's weight can differ from the reference's (by 2 lr) exactly

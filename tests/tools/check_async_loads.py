@@ -26,38 +26,61 @@ def regs(tok):
   return out
 
 
-def check_kernel(name, lines):
-  """lines: the kernel's instructions in program order (straight-line approximation: branches are not followed; a loop body is
-  seen once, which is what matters — a hazard inside the body shows in its text)."""
-  pending = []        # (set of registers, line number) per outstanding VMEM op in issue order; stores carry an empty set
-  hazards = []
+def _scan(lines, pending, hazards, seen):
+  """One straight-line pass over `lines` from the given queue of outstanding operations; returns the queue at its end."""
   for no, l in lines:
+    if l.endswith(":"):
+      continue
     parts = l.split(None, 1)
     op, args = parts[0], (parts[1] if len(parts) > 1 else "")
     if op.startswith("s_waitcnt"):
       m = re.search(r"vmcnt\((\d+)\)", args)
       if m:
         n = int(m.group(1))
-        pending = pending[len(pending) - n:] if n else []
+        pending = pending[max(0, len(pending) - n):] if n else []       # (vmcnt(n) with fewer than n outstanding retires nothing)
       continue
     if op in ("s_endpgm",):
       break
     used = regs(args)
     inflight = set().union(*[p[0] for p in pending]) if pending else set()
+
+    def hazard(rs):
+      if (no, tuple(rs)) not in seen:
+        seen.add((no, tuple(rs)))
+        hazards.append((no, l, rs))
     if op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")) and "lds" not in op:
       dst = regs(args.split(",")[0])
       src = used - dst
       if src & inflight:
-        hazards.append((no, l, sorted(src & inflight)))
-      pending.append((dst, no))
+        hazard(sorted(src & inflight))
+      pending = pending + [(dst, no)]
       continue
     if op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_load_lds", "global_atomic")):
       if used & inflight:
-        hazards.append((no, l, sorted(used & inflight)))
-      pending.append((set(), no))
+        hazard(sorted(used & inflight))
+      pending = pending + [(set(), no)]
       continue
     if used & inflight:
-      hazards.append((no, l, sorted(used & inflight)))
+      hazard(sorted(used & inflight))
+  return pending
+
+
+def check_kernel(name, lines):
+  """lines: the kernel's instructions and labels in program order.  The pass is straight-line, plus ONE more turn of every
+  loop: at a backward branch the body (label .. branch) is scanned again starting from the queue of operations outstanding
+  at the branch, so a load issued textually BEHIND a wait in the body is seen in flight at the top of the next iteration."""
+  hazards, seen = [], set()
+  label_at = {l[:-1]: i for i, (no, l) in enumerate(lines) if l.endswith(":")}
+  pending, start = [], 0
+  for i, (no, l) in enumerate(lines):
+    parts = l.split(None, 1)
+    if parts and parts[0].startswith(("s_cbranch", "s_branch")) and len(parts) > 1:
+      tgt = label_at.get(parts[1].strip())
+      if tgt is not None and tgt < i:
+        pending = _scan(lines[start:i], pending, hazards, seen)
+        _scan(lines[tgt:i], list(pending), hazards, seen)        # the next iteration, from what this one left in flight
+        start = i
+  _scan(lines[start:], pending, hazards, seen)
   return hazards
 
 
@@ -79,8 +102,8 @@ def main():
         kernels[name] = cur
         continue
       s = l.strip()
-      if cur is not None and s and not s.startswith((";", ".", "//")) and not s.endswith(":"):
-        cur.append((i, s))
+      if cur is not None and s and not s.startswith((";", "//")) and (not s.startswith(".") or s.endswith(":")):
+        cur.append((i, s.split(";")[0].strip() if not s.endswith(":") else s))      # (labels kept: .LBB0_3:)
     for name, lines in kernels.items():
       if not any(x[1].startswith("global_load") for x in lines):
         continue
