@@ -1,0 +1,461 @@
+// Data gradient of a full-resolution refinement layer (3x3, dilation 1/2/4/8, stride 1, 32->32: stereo_net.py:10-18, 33-51,
+// 97) by minimal filtering F(2x2, 3x3) — second generation of conv32_wino.hip's MODE 2, same arithmetic, same outputs:
+//   g_z = stage 3 of the layer's BatchNorm backward applied to (g_a, z) on the way in (written once, for the weight gradient),
+//   g_x = dgrad(g_z) + g_a (skip connection), per-workgroup sums of stage 1 of the NEXT BatchNorm backward from the g_x tile.
+//
+// What the first generation paid for in HBM bytes it did not need (PMC, round 3: 1.70 GB per launch at 4 pairs against 1.19 GB
+// algorithmic, 5.6 TB/s on the counters — the kernel was bound by its own excess traffic):
+//   * g_a was read TWICE: 80 staged voxels per 64-voxel row for the conversion, and again two to four tiles later at the output
+//     pixels for the skip connection (16 + 16 one-dword loads per lane; by then the rows had left the XCD's 4-MB L2);
+//   * rows were staged 8 + 64 + 8 voxels wide whatever the dilation, although a tile only reaches d voxels beyond its segment.
+// Here the four waves of a workgroup have ROLES (separate instantiations of the whole loop under a wave branch, as in
+// conv32_wino_wgrad.hip), which is what makes room for the fix in the 80 KB a workgroup may have at two per CU:
+//   all four    matrix phase as before: wave r holds the transformed filters U[r][0..3] and accumulates M[r][c] (64 MFMAs),
+//               forms T[j] = (M[r] A)[j]
+//   waves 1, 2  ("inner": Y[0][j] and Y[1][j] both need T1 and T2) publish T[0], T[1] in LDS — 16 KB instead of the 32 KB all
+//               four published — and do ALL of the row conversion: rows j+3, j+4 of g_a and z arrive in their registers
+//               (64 + 2d voxels per row), become g_z in the two freed ring slots and the by-product in HBM, and the RAW g_a
+//               chunks of the segment's own 64 voxels go to a small ring of raw rows in LDS
+//   waves 0, 3  ("outer": T0 is only needed by Y[0][j], T3 only by Y[1][j]) keep their own T in registers, read T1, T2 and
+//               finish output row j (wave 0) / j+1 (wave 3), BOTH column parities: skip connection from the raw ring
+//               (ds_read_b32 with immediate offsets: the lane is the channel), next layer's pre-activation from HBM, 32 stores,
+//               the next BatchNorm's sums
+// Raw rows: the conversion of tile j brings comb rows j+3 (output row of tile j+2: one slot, read before barrier B1 of that tile,
+// rewritten after it) and j+4 (output row of tile j+4: two alternating slots) — three slots of 8 KB.  With d = 8 the ring rows
+// are 80 voxels and only the first of the three fits: wave 0 (even rows) keeps the second read from HBM there.
+// LDS: ring 4 x (64 + 2d) x 128 B | coefficients 768 B | exchange 16 KB | raw ring 24 KB (8 KB at d = 8) = 75.5 / 76.5 / 78.6 /
+// 66.3 KB for d = 1 / 2 / 4 / 8: two workgroups per CU as before.
+//
+// Bit-identical to the first generation (tests/test_gpu_kernels.py: g_z, g_x and the next-BatchNorm partials against
+// conv32_wino_kernel<2, L>): same element-wise chains, same order in every sum, the same ownership of shared columns.
+#include "as_common.h"
+#include "conv32_wino.h"
+#include "conv32_wino_dev.h"
+
+#ifndef DG_GRID
+#define DG_GRID 512
+#endif
+
+template <int L> struct DgGeo {
+  static constexpr int d = 1 << L;
+  static constexpr int NV = 64 + 2 * d;                  // staged voxels per row: d + 64 + d
+  static constexpr int V0 = 8 - d;                       // first staged voxel in conv32_wino.hip's 80-voxel frame (wn_addr)
+  static constexpr int ROWB = NV * 128;                  // bytes of a ring row
+  static constexpr int RC = 8 * NV;                      // 16-byte chunks per row
+  static constexpr int K = (2 * RC + 127) / 128;         // conversion chunks per inner-wave thread and row pair: 9, 9, 9, 10
+  static constexpr int COEF_OFF = 4 * ROWB;              // k1, k2, k3, scale, shift, mean [6][32]
+  static constexpr int X_OFF = COEF_OFF + 768;           // T tiles of waves 1, 2: [2 waves][2 j][4 g][64 lanes] float4
+  static constexpr int RAW_OFF = X_OFF + 16384;          // raw g_a rows [slots][64 voxels][32]
+  static constexpr bool RAW_EVEN = L < 3;                // even comb rows (wave 0's) have their two slots
+  static constexpr int RAW_SLOTS = RAW_EVEN ? 3 : 1;
+  static constexpr int LDS = RAW_OFF + RAW_SLOTS * 8192;
+};
+
+struct DgradArgs {
+  const float* z;          // this layer's pre-activation
+  const float* g_a;        // gradient w.r.t. the layer's output a = lrelu(BN(z)) + x
+  float* g_z;              // by-product: gradient w.r.t. z
+  float* g_x;              // dgrad(g_z) + g_a
+  const float* wq;         // transformed transposed weights [16][4][64][4] (pack kind AS_PACK_WINO_T)
+  const float* in_scale;   // this layer's BatchNorm affine, batch mean, stage-3 coefficients k1, k2, k3 [96]
+  const float* in_shift;
+  const float* bn_mean;
+  const float* bn_coef;
+  const float* nz;         // next BatchNorm backward (the layer below): pre-activation, affine, mean
+  const float* n_scale;
+  const float* n_shift;
+  const float* n_mean;
+  double* n_partial;       // [grid][64]: sum g_y, sum g_y * (z - mean) of the next BatchNorm
+  PclDev g;
+  int nseg, pairs;         // column segments per row; row pairs per (image, segment) over all combs
+  float slope;
+};
+
+#define DG_FOR_8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define DG_IMM(r) (wn_c0<L>(((r) & 3) + 8 * (((r) >> 2) & 1)) * 128)
+// column (in the segment) of accumulator row r of output parity jc for this lane's half h
+#define DG_COL(r, jc) (wn_c0<L>(((r) & 3) + 8 * ((r) >> 2)) + wn_c0<L>(4 * h) + (jc) * d)
+
+template <int ROLE, int L>
+__device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
+  using G = DgGeo<L>;
+  constexpr int d = G::d;
+  constexpr bool INNER = ROLE == 1 || ROLE == 2;
+  constexpr int K = G::K;
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5, li = lane & 31;
+  const int H = p.g.H, W = p.g.W, Wp = p.g.Wp;
+
+  // the wave's four transformed filters U[ROLE][c]: R[c][4q+e] = chunk q, element e
+  f32x16 R[4];
+  {
+    const float* wb = p.wq + (ROLE * 4) * 1024 + lane * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(wb + c * 1024 + q * 256);
+        R[c][4 * q + 0] = t4.x; R[c][4 * q + 1] = t4.y; R[c][4 * q + 2] = t4.z; R[c][4 * q + 3] = t4.w;
+      }
+  }
+  // ---- operand gather: this lane's tile li, input column m -> staged voxel 8 + c0 + (m-1) d (80-voxel frame); chunk 4h + q ----
+  int op_off[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) op_off[m] = wn_addr<L>(8 + wn_c0<L>(li) + (m - 1) * d, 4 * h) - G::V0 * 128;
+  // input rows (of the four of a tile) and sign of this wave's row transform: R = d[ra] + sg * d[rb]
+  constexpr int ra = ROLE == 0 ? 0 : (ROLE == 2 ? 2 : 1);
+  constexpr int rb = ROLE == 0 ? 2 : (ROLE == 1 ? 2 : (ROLE == 2 ? 1 : 3));
+  constexpr bool SG_PLUS = ROLE == 1;
+
+  // ---- inner waves: conversion geometry.  Chunk f = tid2 + 128 k of a row pair: f < RC row A, else row B ----
+  const int tid2 = (ROLE - 1) * 64 + lane;                 // 0..127 over waves 1, 2
+  const int cq = tid2 & 7;                                  // 16-byte chunk of the voxel (constant over k: 128 and RC divide by 8)
+  // ---- outer waves: this wave finishes output row oi of every tile, both column parities ----
+  constexpr int oi = ROLE == 3 ? 1 : 0;
+  const unsigned io_off = (unsigned)(wn_c0<L>(4 * h) * 128 + 4 * li);
+  float bn_sc = 0.f, bn_sh = 0.f, bn_mu = 0.f;
+  float bn_dy[2] = {0.f, 0.f}, bn_dx[2] = {0.f, 0.f};       // next-BatchNorm sums per lane and column parity
+  if constexpr (!INNER) { bn_sc = p.n_scale[li]; bn_sh = p.n_shift[li]; bn_mu = p.n_mean[li]; }
+
+  const long t_total = (long)p.g.B * p.nseg * p.pairs;
+  long t_next = t_total * blockIdx.x / gridDim.x;
+  const long t_end = t_total * (blockIdx.x + 1) / gridDim.x;
+  while (t_next < t_end) {
+    const int blk = (int)(t_next / p.pairs);
+    int pj0 = (int)(t_next - (long)blk * p.pairs);
+    int r0 = 0, nrow = (H + d - 1) / d;                   // rows of comb r0
+    while (pj0 >= (nrow + 1) / 2) { pj0 -= (nrow + 1) / 2; ++r0; nrow = (H - r0 + d - 1) / d; }
+    const int pj1 = (int)min((long)((nrow + 1) / 2), pj0 + (t_end - t_next));
+    t_next += pj1 - pj0;
+    const int j0 = 2 * pj0, j1 = min(2 * pj1, nrow);
+    const int seg = blk % p.nseg;
+    const int b = blk / p.nseg;
+    const int x0 = min(64 * seg, W - 64);
+    // one owner per column shared with the shifted last segment: conv32_wino.hip
+    const int keep = (seg == p.nseg - 2 && 64 * p.nseg > W) ? W - 64 * (p.nseg - 1) : 64;
+    const long img = (long)b * p.g.Hp;
+    const int px0 = x0 - d + p.g.pw;                       // first staged column (padded coordinates)
+
+    // ================= inner waves: fetch and convert a row pair (ja, ja + 1) =================
+    f32x4 pz[K], pa[K];
+    long pair_off = 0;                                      // float offset of row A's first staged voxel
+    unsigned pair_delta = 0;                                // byte distance row A -> row B (rows outside the image are clamped)
+    auto chunk = [&](int k, bool& active, bool& isb, int& fr) {
+      const int f = tid2 + 128 * k;
+      active = 128 * (k + 1) <= 2 * G::RC || f < 2 * G::RC;
+      isb = 128 * k >= G::RC || (128 * (k + 1) > G::RC && f >= G::RC);
+      fr = isb ? f - G::RC : f;
+    };
+    auto pair_rows = [&](int ja) {
+      const int ya = min(max(r0 + ja * d, 0), H - 1), yb = min(max(r0 + (ja + 1) * d, 0), H - 1);
+      pair_off = ((img + ya + p.g.ph) * Wp + px0) * 32;
+      pair_delta = (unsigned)((yb - ya) * Wp * 128);
+    };
+    auto fetch_one = [&](const float* src, f32x4 (&pv)[K]) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        bool active, isb; int fr;
+        chunk(k, active, isb, fr);
+        if (active) wn_load4(pv[k], src + pair_off, (unsigned)(fr * 16) + (isb ? pair_delta : 0u));
+      }
+    };
+    auto convert = [&](int ja, f32x4 (&pz)[K], f32x4 (&pa)[K]) {           // -> ring slots (ja + 1) & 3, (ja + 2) & 3
+      const float* tab = reinterpret_cast<const float*>(smem + G::COEF_OFF) + cq * 4;
+      const f32x4 k1 = *reinterpret_cast<const f32x4*>(tab), k2 = *reinterpret_cast<const f32x4*>(tab + 32);
+      const f32x4 k3 = *reinterpret_cast<const f32x4*>(tab + 64), sc = *reinterpret_cast<const f32x4*>(tab + 96);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(tab + 128), bmu = *reinterpret_cast<const f32x4*>(tab + 160);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        bool active, isb; int fr;
+        chunk(k, active, isb, fr);
+        if (!active) continue;
+        const int jj = isb ? ja + 1 : ja;
+        const int y = r0 + jj * d;
+        const bool row_in = y >= 0 && y < H;
+        const int vq = fr >> 3;                             // staged voxel 0..NV-1; column x0 - d + vq
+        const int xx = x0 - d + vq;
+        // stage 3 of the BatchNorm backward (conv32_wino.hip MODE 2 / conv32_bwd.hip's arithmetic)
+        const f32x4 ga = pa[k], zz = pz[k];
+        const f32x4 yy = zz * sc + sh;
+        const f32x4 gl = ga * p.slope;
+        f32x4 gy;
+        gy.x = yy.x > 0.f ? ga.x : gl.x; gy.y = yy.y > 0.f ? ga.y : gl.y;
+        gy.z = yy.z > 0.f ? ga.z : gl.z; gy.w = yy.w > 0.f ? ga.w : gl.w;
+        f32x4 yv = (gy - k1 - (zz - bmu) * k2) * k3;
+        const bool halo = vq < d || vq >= 64 + d;           // (only halo voxels can lie outside the image)
+        if (!row_in || (halo && !(xx >= 0 && xx < W))) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * G::ROWB + wn_addr<L>(vq + G::V0, cq) - G::V0 * 128) = yv;
+        const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
+        if (own && !halo) {
+          wn_store4(p.g_z + pair_off, (unsigned)(fr * 16) + (isb ? pair_delta : 0u), yv);
+          if (G::RAW_EVEN || (jj & 1)) {                    // the raw row for the skip connection: odd rows slot 0, even 1 / 2
+            const int slot = (jj & 1) ? 0 : 1 + ((jj >> 1) & 1);
+            *reinterpret_cast<f32x4*>(smem + G::RAW_OFF + slot * 8192 + (vq - d) * 128 + cq * 16) = ga;
+          }
+        }
+      }
+    };
+    auto wait_all = [&](f32x4 (&pv)[K]) {                   // every load so far is home (in-order retirement)
+      if constexpr (K == 9)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
+                     "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]) :: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]),
+                     "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]), "+v"(pv[K - 1]) :: "memory");
+    };
+    auto touch = [&](f32x4 (&pv)[K]) {                      // (no instruction: ties the registers to the wait above)
+      if constexpr (K == 9)
+        asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]),
+                     "+v"(pv[8]) :: "memory");
+      else
+        asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]),
+                     "+v"(pv[8]), "+v"(pv[K - 1]) :: "memory");
+    };
+
+    // ---- run-in: g_z rows j0-1 .. j0+2 (inner waves, one pair after the other; the outer waves wait at the barrier) ----
+    if constexpr (INNER) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) { pz[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; pa[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      pair_rows(j0 - 1);
+      fetch_one(p.z, pz); fetch_one(p.g_a, pa);
+      wait_all(pz); touch(pa);
+      convert(j0 - 1, pz, pa);
+      pair_rows(j0 + 1);
+      fetch_one(p.z, pz); fetch_one(p.g_a, pa);
+      wait_all(pz); touch(pa);
+      convert(j0 + 1, pz, pa);
+    }
+    __syncthreads();
+
+    for (int j = j0; j < j1; j += 2) {
+      const bool more = j + 2 < j1;                        // (the last tile of a piece converts nothing)
+      if constexpr (INNER) {
+        if (more) { pair_rows(j + 3); fetch_one(p.z, pz); }  // in flight during the matrix phase (g_a follows it)
+      }
+      const char* row_a = smem + ((j + ra) & 3) * G::ROWB;   // input row m of the tile = comb row j-1+m = slot (j+m) & 3
+      const char* row_b = smem + ((j + rb) & 3) * G::ROWB;
+      f32x16 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+      f32x4 xa[4], xb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        xa[m] = *reinterpret_cast<const f32x4*>(row_a + op_off[m]);
+        xb[m] = *reinterpret_cast<const f32x4*>(row_b + op_off[m]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 V[4];
+        {
+          f32x4 Rt[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) Rt[m] = SG_PLUS ? xa[m] + xb[m] : xa[m] - xb[m];
+          V[0] = Rt[0] - Rt[2]; V[1] = Rt[1] + Rt[2]; V[2] = Rt[2] - Rt[1]; V[3] = Rt[1] - Rt[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < 4) {                                   // the next chunk's operands: in flight under this chunk's MFMAs
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            xa[m] = *reinterpret_cast<const f32x4*>(row_a + (op_off[m] ^ ((q + 1) << 4)));
+            xb[m] = *reinterpret_cast<const f32x4*>(row_b + (op_off[m] ^ ((q + 1) << 4)));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].x, R[c][4 * q + 0], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].y, R[c][4 * q + 1], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].z, R[c][4 * q + 2], acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].w, R[c][4 * q + 3], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // T[jc] = (M[r] A)[jc]: A^T = [1 1 1 0; 0 1 -1 -1]
+      f32x16 T0, T1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        T0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+        T1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+      }
+
+      if constexpr (INNER) {
+        // ---------------- publish T[0], T[1]; request the g_a rows of the pair; B1; convert; B2 ----------------
+        char* xw = smem + G::X_OFF + ((ROLE - 1) * 2) * 4096 + lane * 16;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          *reinterpret_cast<f32x4*>(xw + gq * 1024) = (f32x4){T0[4 * gq], T0[4 * gq + 1], T0[4 * gq + 2], T0[4 * gq + 3]};
+          *reinterpret_cast<f32x4*>(xw + 4096 + gq * 1024) = (f32x4){T1[4 * gq], T1[4 * gq + 1], T1[4 * gq + 2], T1[4 * gq + 3]};
+        }
+        if (more) fetch_one(p.g_a, pa);                    // (the accumulators are dead: registers to spare)
+        __syncthreads();                                   // B1: the T tiles are in place; nobody reads rows j-1, j any more
+        if (more) {
+          wait_all(pz); touch(pa);
+          convert(j + 3, pz, pa);
+        }
+        __syncthreads();                                   // B2: g_z rows j+3, j+4 and their raw rows are in place
+      } else {
+        // ---------------- outer: skip rows and next pre-activation requested; B1; finish the output row; B2 ----------------
+        const int yrow = j + oi;
+        const bool row_ok = yrow < j1;                     // (wave-uniform) the pair's second row may lie outside the piece
+        float res[2][16], zt[2][16];
+        const long ovox = ((img + r0 + yrow * d + p.g.ph) * Wp + x0 + p.g.pw) * 32;
+        if (row_ok) {
+#define DG_LDZ(r) wn_load_imm<DG_IMM(r)>(zt[0][r], p.nz + ovox, io_off); wn_load_imm<DG_IMM(r)>(zt[0][8 + r], p.nz + ovox, io_off + 4096u); \
+                  wn_load_imm<DG_IMM(r) + d * 128>(zt[1][r], p.nz + ovox, io_off); wn_load_imm<DG_IMM(r) + d * 128>(zt[1][8 + r], p.nz + ovox, io_off + 4096u);
+          DG_FOR_8(DG_LDZ)
+#undef DG_LDZ
+          if constexpr (oi == 1 || G::RAW_EVEN) {
+            // the raw g_a row the inner waves parked when they converted it (odd comb rows: slot 0; even: 1 + (row / 2) % 2)
+            const int slot = oi == 1 ? 0 : 1 + ((j >> 1) & 1);
+            const char* rr = smem + G::RAW_OFF + slot * 8192 + io_off;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int imm = DG_IMM(r & 7) + (r >> 3) * 4096;
+              res[0][r] = *reinterpret_cast<const float*>(rr + imm);
+              res[1][r] = *reinterpret_cast<const float*>(rr + imm + d * 128);
+            }
+          } else {
+#define DG_LDA(r) wn_load_imm<DG_IMM(r)>(res[0][r], p.g_a + ovox, io_off); wn_load_imm<DG_IMM(r)>(res[0][8 + r], p.g_a + ovox, io_off + 4096u); \
+                  wn_load_imm<DG_IMM(r) + d * 128>(res[1][r], p.g_a + ovox, io_off); wn_load_imm<DG_IMM(r) + d * 128>(res[1][8 + r], p.g_a + ovox, io_off + 4096u);
+            DG_FOR_8(DG_LDA)
+#undef DG_LDA
+          }
+        }
+        int keep_l = keep;                                 // (opaque: hipcc otherwise hoists the shared-column masks of the
+        asm volatile("" : "+s"(keep_l));                   //  sums out of the tile loop, into registers)
+        __syncthreads();                                   // B1
+        // Y[oi][jc] = (A^T T)[oi][jc]: (T0 + T1) + T2 for the first output row, (T1 - T2) - T3 for the second
+        f32x16 Y[2];
+        {
+          const char* xr = smem + G::X_OFF + lane * 16;
+#pragma unroll
+          for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const f32x4 u1 = *reinterpret_cast<const f32x4*>(xr + jc * 4096 + gq * 1024);             // T of wave 1
+              const f32x4 u2 = *reinterpret_cast<const f32x4*>(xr + (2 + jc) * 4096 + gq * 1024);       // T of wave 2
+              const f32x16& own = jc == 0 ? T0 : T1;
+              const f32x4 o4 = (f32x4){own[4 * gq], own[4 * gq + 1], own[4 * gq + 2], own[4 * gq + 3]};
+              const f32x4 yv = oi == 0 ? (o4 + u1) + u2 : (u1 - u2) - o4;
+              Y[jc][4 * gq + 0] = yv.x; Y[jc][4 * gq + 1] = yv.y; Y[jc][4 * gq + 2] = yv.z; Y[jc][4 * gq + 3] = yv.w;
+            }
+        }
+        if (row_ok) {
+          // every load of this tile is home (next pre-activation, and g_a where it still comes from HBM); the stores are younger
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(zt[0][0]), "+v"(zt[0][1]), "+v"(zt[0][2]), "+v"(zt[0][3]), "+v"(zt[0][4]), "+v"(zt[0][5]), "+v"(zt[0][6]),
+                         "+v"(zt[0][7]), "+v"(zt[0][8]), "+v"(zt[0][9]), "+v"(zt[0][10]), "+v"(zt[0][11]), "+v"(zt[0][12]),
+                         "+v"(zt[0][13]), "+v"(zt[0][14]), "+v"(zt[0][15]) :: "memory");
+          asm volatile("" : "+v"(zt[1][0]), "+v"(zt[1][1]), "+v"(zt[1][2]), "+v"(zt[1][3]), "+v"(zt[1][4]), "+v"(zt[1][5]), "+v"(zt[1][6]),
+                            "+v"(zt[1][7]), "+v"(zt[1][8]), "+v"(zt[1][9]), "+v"(zt[1][10]), "+v"(zt[1][11]), "+v"(zt[1][12]),
+                            "+v"(zt[1][13]), "+v"(zt[1][14]), "+v"(zt[1][15]) :: "memory");
+          if constexpr (!(oi == 1 || G::RAW_EVEN)) {
+            asm volatile("" : "+v"(res[0][0]), "+v"(res[0][1]), "+v"(res[0][2]), "+v"(res[0][3]), "+v"(res[0][4]), "+v"(res[0][5]),
+                              "+v"(res[0][6]), "+v"(res[0][7]), "+v"(res[0][8]), "+v"(res[0][9]), "+v"(res[0][10]), "+v"(res[0][11]),
+                              "+v"(res[0][12]), "+v"(res[0][13]), "+v"(res[0][14]), "+v"(res[0][15]) :: "memory");
+            asm volatile("" : "+v"(res[1][0]), "+v"(res[1][1]), "+v"(res[1][2]), "+v"(res[1][3]), "+v"(res[1][4]), "+v"(res[1][5]),
+                              "+v"(res[1][6]), "+v"(res[1][7]), "+v"(res[1][8]), "+v"(res[1][9]), "+v"(res[1][10]), "+v"(res[1][11]),
+                              "+v"(res[1][12]), "+v"(res[1][13]), "+v"(res[1][14]), "+v"(res[1][15]) :: "memory");
+          }
+          const int y = r0 + yrow * d;
+          float* gx_base = p.g_x + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
+          const auto rs = __builtin_amdgcn_make_buffer_rsrc(gx_base, 0, keep_l * 128, 0x00020000);
+#pragma unroll
+          for (int jc = 0; jc < 2; ++jc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[jc][r] += res[jc][r];
+#define DG_ST(r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[jc][r]), rs, (int)io_off + jc * d * 128 + DG_IMM(r), 0, 0); \
+                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[jc][8 + r]), rs, (int)io_off + 4096 + jc * d * 128 + DG_IMM(r), 0, 0);
+            DG_FOR_8(DG_ST)
+#undef DG_ST
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float yv = fmaf(zt[jc][r], bn_sc, bn_sh);
+              float gy = yv > 0.f ? Y[jc][r] : Y[jc][r] * p.slope;
+              if (keep_l < 64) gy = DG_COL(r, jc) < keep_l ? gy : 0.f;
+              bn_dy[jc] += gy; bn_dx[jc] = fmaf(gy, zt[jc][r] - bn_mu, bn_dx[jc]);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                   // B2
+      }
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // next-BatchNorm sums: 8 (output position, half) partials per channel -> one fp64 pair per workgroup, in the order of the
+  // first generation (its wave = oi * 2 + jc)
+  float* scr = reinterpret_cast<float*>(smem);            // [8][2][32]
+  if constexpr (!INNER) {
+#pragma unroll
+    for (int jc = 0; jc < 2; ++jc) {
+      scr[(((oi * 2 + jc) * 2 + h) * 2 + 0) * 32 + li] = bn_dy[jc];
+      scr[(((oi * 2 + jc) * 2 + h) * 2 + 1) * 32 + li] = bn_dx[jc];
+    }
+  }
+  __syncthreads();
+  if constexpr (ROLE == 0) {
+    const int which = lane >> 5, cch = lane & 31;
+    double sum = 0.0;
+    for (int q = 0; q < 8; ++q) sum += (double)scr[(q * 2 + which) * 32 + cch];
+    p.n_partial[(long)blockIdx.x * 64 + which * 32 + cch] = sum;
+  }
+}
+
+template <int L>
+__global__ __launch_bounds__(256, 2) void conv32_wino_dgrad_kernel(DgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dg[];
+  {
+    float* tab = reinterpret_cast<float*>(smem_dg + DgGeo<L>::COEF_OFF);
+    const int i = threadIdx.x;
+    if (i < 96) tab[i] = p.bn_coef[i];
+    else if (i < 128) tab[i] = p.in_scale[i - 96];
+    else if (i < 160) tab[i] = p.in_shift[i - 128];
+    else if (i < 192) tab[i] = p.bn_mean[i - 160];
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  switch (wave) {
+    case 0: dgrad_role<0, L>(p, smem_dg); break;
+    case 1: dgrad_role<1, L>(p, smem_dg); break;
+    case 2: dgrad_role<2, L>(p, smem_dg); break;
+    default: dgrad_role<3, L>(p, smem_dg); break;
+  }
+}
+
+int conv32_wino_dgrad2_parts(void) { return DG_GRID; }
+
+int conv32_wino_dgrad2_launch(const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s, const float* wino_wt,
+                              const float* scale, const float* shift, const float* mean, const float* coef, float slope,
+                              const float* next_z, const float* next_scale, const float* next_shift, const float* next_mean,
+                              float* g_z, float* g_x, double* next_partial, void* stream) {
+  static AsPerDevice attr_set[4];
+  const int L = s->dil == 1 ? 0 : (s->dil == 2 ? 1 : (s->dil == 4 ? 2 : 3));
+  const void* fn = L == 0 ? reinterpret_cast<const void*>(conv32_wino_dgrad_kernel<0>)
+                 : L == 1 ? reinterpret_cast<const void*>(conv32_wino_dgrad_kernel<1>)
+                 : L == 2 ? reinterpret_cast<const void*>(conv32_wino_dgrad_kernel<2>)
+                          : reinterpret_cast<const void*>(conv32_wino_dgrad_kernel<3>);
+  const int lds = L == 0 ? DgGeo<0>::LDS : (L == 1 ? DgGeo<1>::LDS : (L == 2 ? DgGeo<2>::LDS : DgGeo<3>::LDS));
+  if (!attr_set[L].get()) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { as_set_error("as_conv32_wino_bwd_data: %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
+    attr_set[L].set();
+  }
+  DgradArgs a;
+  a.z = z; a.g_a = g_a; a.g_z = g_z; a.g_x = g_x; a.wq = wino_wt;
+  a.in_scale = scale; a.in_shift = shift; a.bn_mean = mean; a.bn_coef = coef;
+  a.nz = next_z; a.n_scale = next_scale; a.n_shift = next_shift; a.n_mean = next_mean; a.n_partial = next_partial;
+  a.g = as_make_dev(g);
+  a.nseg = (g->W + 63) / 64;
+  long pairs = 0;
+  for (int r = 0; r < s->dil; ++r) pairs += ((g->H - r + s->dil - 1) / s->dil + 1) / 2;
+  a.pairs = (int)pairs; a.slope = slope;
+  void* kargs[] = {&a};
+  hipError_t le = hipLaunchKernel(fn, dim3(DG_GRID), dim3(256), kargs, lds, (hipStream_t)stream);
+  if (le != hipSuccess) { as_set_error("as_conv32_wino_bwd_data: launch failed: %s", hipGetErrorString(le)); return AS_ERR_LAUNCH; }
+  return AS_OK;
+}

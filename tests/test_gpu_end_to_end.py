@@ -201,7 +201,9 @@ def test_adapt_step_matches_reference_golden(case, golden_loader):
         outside.add("%s.%s" % (names[mi], name))
         assert p.grad is None and torch.equal(p.detach().cpu(), init[names[mi]][name]), name
   assert outside == set(gold.no_grad_keys), (sorted(outside ^ set(gold.no_grad_keys)))
-  assert arena.numel == sum(n for _, _, _, _, n in arena.entries)      # (every tensor's size is a multiple of 4: no padding)
+  # what rides in the all-reduce: the gradients of the executed parameters + alignment padding behind the two 1-element biases
+  live = sum(n for _, _, _, _, n in arena.entries)
+  assert live <= arena.numel <= live + 3 * sum(1 for _, _, _, _, n in arena.entries if n % 4)
 
   # the state after the step against the reference's (fixture "after/..."), every element: Adam's first step is
   # lr*g/(|g|+1e-8), i.e. +-lr by the SIGN of g, so the GPU's weight can differ from the reference's (by 2 lr) exactly
