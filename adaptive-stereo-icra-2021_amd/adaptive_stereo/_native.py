@@ -110,6 +110,7 @@ _SIGNATURES = {
   "as_conv32_wino_bwd_filter": (c_int, [c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_conv32_wino_bwd_parts": (c_int, []),
   "as_conv32_wino_bwd_workspace": (c_i64, []),
+  "as_conv32_wino_bwd_generation": (c_int, [c_int]),
   "as_conv32_wino_bwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
   "as_conv32_bwd_fused_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),

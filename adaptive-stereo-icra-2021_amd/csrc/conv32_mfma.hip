@@ -940,6 +940,15 @@ extern "C" int as_conv32_wino_eval(const float* x, const as_pcl* g, const as_con
 // backward on the way in (g_z written once), skip connection and next-BatchNorm sums in the epilogue; then weight / bias
 // gradient F(3x3, 2x2) from x and g_z.  Arguments as as_conv32_bwd_fused, plus g_z (a PCL buffer of the layer's geometry).
 extern "C" int as_conv32_wino_bwd_parts(void) { return conv32_wino_dgrad_parts(); }
+// Which data-gradient kernel as_conv32_wino_bwd_data launches: 2 (default) = conv32_wino_dgrad.hip where it is the faster one
+// (dilation 1, 2, 4), 1 = conv32_wino.hip MODE 2 everywhere, 3 = conv32_wino_dgrad.hip everywhere (its dilation-8 instantiation
+// is slower than generation 1 and only here for the parity tests).  All write the same bits; returns the previous setting.
+static int g_wino_dgrad_generation = 2;
+extern "C" int as_conv32_wino_bwd_generation(int generation) {
+  const int prev = g_wino_dgrad_generation;
+  if (generation >= 1 && generation <= 3) g_wino_dgrad_generation = generation;
+  return prev;
+}
 extern "C" int64_t as_conv32_wino_bwd_workspace(void) { return (int64_t)conv32_wino_wgrad_slabs() * (9 * 1024 + 32); }
 
 // The two halves separately (a caller may run the weight gradient on another stream: nothing but the step's final slab
@@ -960,8 +969,13 @@ extern "C" int as_conv32_wino_bwd_data(const float* g_a, const float* z, const a
   hipStream_t st = (hipStream_t)stream;
   // (ALGORITHMIC flops of the gradient in its direct form, as as_conv32_bwd_fused counts them)
   as_prof_mark(AS_PROF_WINO_DGRAD, st, 1, 0.0);
-  if (int e = conv32_wino_dgrad_launch(g_a, z, g, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift,
-                                       next_mean, g_z, g_x, reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
+  if (conv32_wino_dgrad2_parts() != conv32_wino_dgrad_parts()) { as_set_error("as_conv32_wino_bwd_data: partial counts differ"); return AS_ERR_ARG; }
+  // (generation 2 wins for dilation 1, 2, 4 — 286 / 269 / 268 us against 343 / 300 / 287 at 4 pairs — and loses at 8, where
+  //  only one of its three raw-row slots fits the LDS: 335 against 288; profiles/r04_b_dgrad_generations.txt)
+  const bool gen2 = g_wino_dgrad_generation == 3 || (g_wino_dgrad_generation == 2 && s->dil <= 4);
+  if (int e = (gen2 ? conv32_wino_dgrad2_launch : conv32_wino_dgrad_launch)(
+          g_a, z, g, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift, next_mean, g_z, g_x,
+          reinterpret_cast<double*>(next_bn_workspace), stream)) return e;
   as_prof_mark(AS_PROF_WINO_DGRAD, st, 0, 2.0 * (double)g->B * g->H * g->W * 1024.0 * 9);
   AS_CHECK_LAUNCH("as_conv32_wino_bwd_data");
   return AS_OK;

@@ -17,6 +17,13 @@ int conv32_wino_dgrad_launch(const float* g_a, const float* z, const as_pcl* g, 
                              const float* next_z, const float* next_scale, const float* next_shift, const float* next_mean,
                              float* g_z, float* g_x, double* next_partial, void* stream);
 int conv32_wino_dgrad_parts(void);     // workgroups of the data-gradient launch = next-BatchNorm partials it writes
+// second generation of that data gradient (conv32_wino_dgrad.hip: waves with roles, raw g_a rows kept in LDS for the skip
+// connection, rows staged 64 + 2d voxels wide): same arguments, bit-identical results, the same number of partials
+int conv32_wino_dgrad2_launch(const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s, const float* wino_wt,
+                              const float* scale, const float* shift, const float* mean, const float* coef, float slope,
+                              const float* next_z, const float* next_scale, const float* next_shift, const float* next_mean,
+                              float* g_z, float* g_x, double* next_partial, void* stream);
+int conv32_wino_dgrad2_parts(void);
 int conv32_wino_wgrad_slabs(void);
 int conv32_wino_wgrad_launch(const float* x, const float* g_z, const as_pcl* g, const as_conv_shape* s, float* partial,
                              float* partial_db, void* stream);

@@ -136,13 +136,20 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
   if constexpr (EVAL) { ev_sc = p.ep.ep_scale[li]; ev_sh = p.ep.ep_shift[li]; }
   __syncthreads();
 
-  // ---- row conversion: a PAIR of rows is 1,280 chunks, five per thread: chunk f = t + 256k; f < 640 row A else row B ----
+  // ---- row conversion: a row is staged d + 64 + d voxels wide (round 4: it was 8 + 64 + 8 whatever the dilation — 1.25 x the
+  // operand tensors from HBM where a tile only reaches d voxels beyond its segment); a PAIR of rows is 2 * RC 16-byte chunks,
+  // RC = 8 * (64 + 2d): chunk f = t + 256k, f < RC row A else row B, up to five per thread (the fifth: 32 / 64 / 128 / 256
+  // threads at d = 1 / 2 / 4 / 8).  Staged voxel v = V0 + (chunk / 8) in the 80-voxel frame the LDS image keeps.
   const int t = threadIdx.x;
-  const int c4 = (t & 7) * 4;
-  int cv_vox[5];                                            // staged voxel of chunk k (its row: k < 2 A, k > 2 B, k == 2 by wave)
-  cv_vox[0] = t >> 3; cv_vox[1] = 32 + (t >> 3); cv_vox[2] = wave < 2 ? 64 + (t >> 3) : (t >> 3) - 16;
-  cv_vox[3] = 16 + (t >> 3); cv_vox[4] = 48 + (t >> 3);
-  const bool k2_is_a = wave < 2;
+  constexpr int NV = 64 + 2 * d, V0 = 8 - d, RC = 8 * NV;
+  // (t2: an opaque copy of the thread index per use — see conv32_wino_dgrad.hip: keeps the per-chunk offsets out of registers
+  //  that would live across the matrix phase)
+  auto chunk = [&](int t2, int k, bool& active, bool& isb, int& fr) {
+    const int f = t2 + 256 * k;
+    active = 256 * (k + 1) <= 2 * RC || f < 2 * RC;
+    isb = 256 * k >= RC || (256 * (k + 1) > RC && f >= RC);
+    fr = isb ? f - RC : f;
+  };
 
   // ---- operand gather: this lane's tile li, input column m -> staged voxel 8 + c0 + (m-1) d; chunk 4h + q ----
   int op_off[4];
@@ -190,11 +197,18 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
     f32x4 pz[5], pa[5];
     auto fetch_one = [&](int ja, const float* src, f32x4 (&pv)[5]) {     // rows ja, ja + 1; outside the image: any valid row
       const int ya = min(max(r0 + ja * d, 0), H - 1), yb = min(max(r0 + (ja + 1) * d, 0), H - 1);
-      const long offa = ((img + ya + p.g.ph) * Wp + px0) * 32, offb = ((img + yb + p.g.ph) * Wp + px0) * 32;
+      const long offa = ((img + ya + p.g.ph) * Wp + px0) * 32;
+      const unsigned delta = (unsigned)((yb - ya) * Wp * 128);           // byte distance row A -> row B (clamped rows: >= 0)
+      int t2 = t;
+      asm volatile("" : "+v"(t2));
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
-        const long off = (k < 2 || (k == 2 && k2_is_a)) ? offa : offb;
-        wn_load4(pv[k], src + off, (unsigned)(cv_vox[k] * 128 + c4 * 4));
+        bool active, isb; int fr;
+        chunk(t2, k, active, isb, fr);
+        // EVERY lane issues all five loads (the counted waits below rest on that): a lane without a fifth chunk re-reads the
+        // pair's last one
+        const int frc = active ? fr : RC - 1;
+        wn_load4(pv[k], src + offa, (unsigned)((V0 * 8 + frc) * 16) + (isb ? delta : 0u));
       }
     };
     auto fetch_into = [&](int ja, f32x4 (&pz)[5], f32x4 (&pa)[5]) {
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
       if (SKIP) fetch_one(ja, p.ain, pa);
     };
     auto convert_from = [&](int ja, f32x4 (&pz)[5], f32x4 (&pa)[5]) {    // -> ring slots (ja + 1) & 3, (ja + 2) & 3
-      const float* tab = reinterpret_cast<const float*>(smem + WN_COEF_OFF) + c4;
+      const float* tab = reinterpret_cast<const float*>(smem + WN_COEF_OFF) + (t & 7) * 4;
       f32x4 sc, sh, k1, k2, k3, bmu;
       if constexpr (BWD) {
         k1 = *reinterpret_cast<const f32x4*>(tab); k2 = *reinterpret_cast<const f32x4*>(tab + 32);
@@ -211,13 +225,20 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
       } else if constexpr (!EVAL) {
         sc = *reinterpret_cast<const f32x4*>(tab); sh = *reinterpret_cast<const f32x4*>(tab + 32);
       }
+      const int ya_c = min(max(r0 + ja * d, 0), H - 1), yb_c = min(max(r0 + (ja + 1) * d, 0), H - 1);
+      const long offa = ((img + ya_c + p.g.ph) * Wp + px0) * 32;       // (an own row is never a clamped one)
+      const unsigned delta = (unsigned)((yb_c - ya_c) * Wp * 128);
+      int t2 = t;
+      asm volatile("" : "+v"(t2));
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
-        const bool is_a = k < 2 || (k == 2 && k2_is_a);
-        const int jj = is_a ? ja : ja + 1;
+        bool active, isb; int fr;
+        chunk(t2, k, active, isb, fr);
+        if (!active) continue;
+        const int jj = isb ? ja + 1 : ja;
         const int y = r0 + jj * d;
-        const bool row_in = y >= 0 && y < H;               // (wave-uniform)
-        const int v = cv_vox[k];
+        const bool row_in = y >= 0 && y < H;
+        const int v = V0 + (fr >> 3);
         const int xx = x0 - 8 + v;
         f32x4 yv;
         if constexpr (BWD) {                                // stage 3 of the BatchNorm backward (conv32_bwd.hip's arithmetic)
@@ -237,16 +258,11 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
           yv.z = fmaxf(yv.z, ys.z); yv.w = fmaxf(yv.w, ys.w);
           if (SKIP) yv += pa[k];
         }
-        // halo voxels (v < 8, v >= 72: only they can lie outside the image) are whole waves of a chunk: a uniform branch
-        const bool halo = (k == 0 && wave == 0) || (k == 2 && (wave == 1 || wave == 2)) || (k == 4 && wave == 3);
-        if (!row_in) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        else if (!EVAL && halo) yv = (xx >= 0 && xx < W) ? yv : (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * WN_ROW_BYTES + wn_addr<L>(v, t & 7)) = yv;
+        const bool halo = v < 8 || v >= 72;                // (only halo voxels can lie outside the image)
+        if (!row_in || (!EVAL && halo && !(xx >= 0 && xx < W))) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * WN_ROW_BYTES + wn_addr<L>(v, t2 & 7)) = yv;
         const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
-        if (!EVAL && own && !halo) {
-          float* aout = p.a_out + ((img + y + p.g.ph) * Wp + px0) * 32;
-          wn_store4(aout, (unsigned)(v * 128 + c4 * 4), yv);
-        }
+        if (!EVAL && own && !halo) wn_store4(p.a_out + offa, (unsigned)((V0 * 8 + fr) * 16) + (isb ? delta : 0u), yv);
       }
     };
     auto wait_all = [&](f32x4 (&pz)[5], f32x4 (&pa)[5]) {

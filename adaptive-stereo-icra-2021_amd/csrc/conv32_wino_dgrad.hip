@@ -21,10 +21,13 @@
 //               (ds_read_b32 with immediate offsets: the lane is the channel), next layer's pre-activation from HBM, 32 stores,
 //               the next BatchNorm's sums
 // Raw rows: the conversion of tile j brings comb rows j+3 (output row of tile j+2: one slot, read before barrier B1 of that tile,
-// rewritten after it) and j+4 (output row of tile j+4: two alternating slots) — three slots of 8 KB.  With d = 8 the ring rows
-// are 80 voxels and only the first of the three fits: wave 0 (even rows) keeps the second read from HBM there.
-// LDS: ring 4 x (64 + 2d) x 128 B | coefficients 768 B | exchange 16 KB | raw ring 24 KB (8 KB at d = 8) = 75.5 / 76.5 / 78.6 /
-// 66.3 KB for d = 1 / 2 / 4 / 8: two workgroups per CU as before.
+// rewritten after it) and j+4 (output row of tile j+4: two alternating slots) — three slots of 8 KB.
+// LDS: ring 4 x (64 + 2d) x 128 B | coefficients 768 B | exchange 16 KB | raw ring 24 KB = 75.5 / 76.5 / 78.6 KB for d = 1 / 2 / 4:
+// two workgroups per CU as before.  With d = 8 the ring rows are 80 voxels and the three raw slots miss the 80 KB by the 768 bytes
+// of the coefficient table (the coefficients in 24 registers per thread instead: the resident filters go to scratch, measured);
+// the instantiation for d = 8 keeps one slot — wave 0 reads its skip rows from HBM as the first generation does — and is SLOWER
+// than the first generation there (335 against 288 us at 4 pairs: 64 loads on wave 0): as_conv32_wino_bwd_data launches the
+// first generation for d = 8.
 //
 // Bit-identical to the first generation (tests/test_gpu_kernels.py: g_z, g_x and the next-BatchNorm partials against
 // conv32_wino_kernel<2, L>): same element-wise chains, same order in every sum, the same ownership of shared columns.
@@ -140,8 +143,8 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
     f32x4 pz[K], pa[K];
     long pair_off = 0;                                      // float offset of row A's first staged voxel
     unsigned pair_delta = 0;                                // byte distance row A -> row B (rows outside the image are clamped)
-    auto chunk = [&](int k, bool& active, bool& isb, int& fr) {
-      const int f = tid2 + 128 * k;
+    auto chunk = [&](int t2, int k, bool& active, bool& isb, int& fr) {
+      const int f = t2 + 128 * k;
       active = 128 * (k + 1) <= 2 * G::RC || f < 2 * G::RC;
       isb = 128 * k >= G::RC || (128 * (k + 1) > G::RC && f >= G::RC);
       fr = isb ? f - G::RC : f;
@@ -151,11 +154,15 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
       pair_off = ((img + ya + p.g.ph) * Wp + px0) * 32;
       pair_delta = (unsigned)((yb - ya) * Wp * 128);
     };
+    // (t2: an opaque copy of the thread index per use — hipcc otherwise hoists the 3 K per-chunk offsets of the conversion out
+    //  of the tile loop, into registers that then live across the matrix phase: 16-36 spills)
     auto fetch_one = [&](const float* src, f32x4 (&pv)[K]) {
+      int t2 = tid2;
+      asm volatile("" : "+v"(t2));
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         bool active, isb; int fr;
-        chunk(k, active, isb, fr);
+        chunk(t2, k, active, isb, fr);
         if (active) wn_load4(pv[k], src + pair_off, (unsigned)(fr * 16) + (isb ? pair_delta : 0u));
       }
     };
@@ -164,10 +171,13 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
       const f32x4 k1 = *reinterpret_cast<const f32x4*>(tab), k2 = *reinterpret_cast<const f32x4*>(tab + 32);
       const f32x4 k3 = *reinterpret_cast<const f32x4*>(tab + 64), sc = *reinterpret_cast<const f32x4*>(tab + 96);
       const f32x4 sh = *reinterpret_cast<const f32x4*>(tab + 128), bmu = *reinterpret_cast<const f32x4*>(tab + 160);
+      int t2 = tid2;
+      asm volatile("" : "+v"(t2));
+      const int cq = t2 & 7;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         bool active, isb; int fr;
-        chunk(k, active, isb, fr);
+        chunk(t2, k, active, isb, fr);
         if (!active) continue;
         const int jj = isb ? ja + 1 : ja;
         const int y = r0 + jj * d;
@@ -279,6 +289,7 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
         T0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
         T1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
       }
+      __builtin_amdgcn_sched_barrier(0);                   // (the accumulators die HERE, before anything below asks for registers)
 
       if constexpr (INNER) {
         // ---------------- publish T[0], T[1]; request the g_a rows of the pair; B1; convert; B2 ----------------
@@ -419,12 +430,16 @@ __global__ __launch_bounds__(256, 2) void conv32_wino_dgrad_kernel(DgradArgs p) 
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef DG_ONLY_ROLE                                       // (diagnostic: one role's register count — results are wrong)
+  dgrad_role<DG_ONLY_ROLE, L>(p, smem_dg);
+#else
   switch (wave) {
     case 0: dgrad_role<0, L>(p, smem_dg); break;
     case 1: dgrad_role<1, L>(p, smem_dg); break;
     case 2: dgrad_role<2, L>(p, smem_dg); break;
     default: dgrad_role<3, L>(p, smem_dg); break;
   }
+#endif
 }
 
 int conv32_wino_dgrad2_parts(void) { return DG_GRID; }

@@ -177,6 +177,13 @@ int as_conv32_wino_eval(const float* x, const as_pcl* g, const as_conv_shape* s,
  *   next_bn_workspace   as_conv32_wino_bwd_parts() partials of [64] doubles;  workspace: as_conv32_wino_bwd_workspace() floats */
 int as_conv32_wino_bwd_parts(void);
 int64_t as_conv32_wino_bwd_workspace(void);
+/* which data-gradient kernel as_conv32_wino_bwd_data launches: 2 (default) = csrc/conv32_wino_dgrad.hip — the waves of a
+ * workgroup have roles, the skip connection's g_a rows stay in LDS between conversion and output (one HBM read of g_a instead
+ * of two), rows are staged 64 + 2 * dilation voxels wide — for dilation 1, 2, 4 and csrc/conv32_wino.hip MODE 2 for dilation 8
+ * (where the second generation's LDS ring does not fit and it is the slower one); 1 = csrc/conv32_wino.hip MODE 2 always;
+ * 3 = csrc/conv32_wino_dgrad.hip always (parity tests).  Same bits in every case (what the parity tests hold them to);
+ * returns the previous setting, any other argument only queries */
+int as_conv32_wino_bwd_generation(int generation);
 /* the two launches separately (the weight gradient may go to another stream: only the step's slab reduction waits for it) */
 int as_conv32_wino_bwd_data(const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s,
                             const float* wino_wt, const float* scale, const float* shift, const float* mean,

@@ -1222,6 +1222,61 @@ def test_conv32_eval_block_by_minimal_filtering(B, H, W, dil, skip):
               direct_rms_err_vs_fp64=r_d)
 
 
+def _dgrad_generation_cases():
+  return _wino_edge_cases() + [(2, 160, 1242, 1), (2, 161, 1242, 2), (1, 375, 1030, 4), (2, 163, 1237, 8), (4, 375, 1242, 1),
+                               (3, 375, 1242, 8), (12, 375, 64, 2), (5, 97, 700, 4)]
+
+
+@pytest.mark.parametrize("B,H,W,dil", _dgrad_generation_cases())
+def test_data_gradient_generations_write_the_same_bits(B, H, W, dil):
+  """as_conv32_wino_bwd_data on csrc/conv32_wino_dgrad.hip (generation 2: the waves of a workgroup have roles, the skip
+  connection's g_a rows wait in LDS between conversion and output, rows staged 64 + 2d voxels wide) against generation 1
+  (csrc/conv32_wino.hip MODE 2, itself held against the direct kernels and fp64 below): g_z, g_x and the next BatchNorm's
+  per-workgroup sums BIT FOR BIT — the same element-wise chains, the same order in every sum, the same owner for the columns
+  the shifted last segment shares —, nothing written into a halo, two launches identical.  Every dilation, the small odd
+  geometries of the tiling's edges, the KITTI size (4 pairs, the bench workload), single-segment images."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_wino_ok(g, g, shape) == 1
+  T = lambda seed: ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=seed).to(DEV), g)
+  g_a, zz, zn = T(4), T(5), T(6)
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  ww_t = torch.empty(16 * 1024, device=DEV)
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww_t), 1, nat.stream())
+  st, stn = ops.BnState(DEV), ops.BnState(DEV)
+  for i, s_ in enumerate((st, stn)):
+    s_.mean.copy_(rnd(32, seed=5 + 10 * i).to(DEV) * 0.1); s_.invstd.copy_(rnd(32, seed=6 + 10 * i).abs().to(DEV) + 0.5)
+    s_.scale.copy_(s_.invstd * 1.1); s_.shift.copy_(rnd(32, seed=7 + 10 * i).to(DEV) * 0.1 - s_.mean * s_.scale)
+  coef = (rnd(96, seed=21) * 0.05).to(DEV); coef[64:] = coef[64:].abs() + 0.7
+  nparts = lib.as_conv32_wino_bwd_parts()
+  out = {}
+  prev = lib.as_conv32_wino_bwd_generation(0)
+  try:
+    for gen in (1, 2, 2):
+      lib.as_conv32_wino_bwd_generation(3 if gen == 2 else 1)      # (3: the second generation for EVERY dilation, 8 included)
+      gz, gx = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+      nws = torch.zeros(lib.as_bn_bwd_workspace(g), device=DEV)
+      nat.call("as_conv32_wino_bwd_data", nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale), nat.ptr(st.shift),
+               nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(stn.scale), nat.ptr(stn.shift), nat.ptr(stn.mean),
+               nat.ptr(gz), nat.ptr(gx), nat.ptr(nws), nat.stream())
+      torch.cuda.synchronize()
+      out.setdefault(gen, []).append((gz, gx, nws[:nparts * 128].view(torch.int32).clone()))
+  finally:
+    lib.as_conv32_wino_bwd_generation(prev)
+  tag = "dgrad generations B%d H%d W%d d%d" % (B, H, W, dil)
+  (gz1, gx1, s1), (gz2, gx2, s2), (gz3, gx3, s3) = out[1][0], out[2][0], out[2][1]
+  for name, a, b_ in (("g_z", gz1, gz2), ("g_x", gx1, gx2)):
+    if not bool(torch.equal(a, b_)):
+      va, vb = ops.pcl_view(a, g), ops.pcl_view(b_, g)
+      bad = (va != vb).nonzero()
+      raise AssertionError("%s: %s differs at %d elements; first [b, d, y, x, c] (padded) = %s: %r against %r" % (
+          tag, name, bad.shape[0], bad[0].tolist(), float(va[tuple(bad[0])]), float(vb[tuple(bad[0])])))
+  assert bool(torch.equal(s1, s2)), tag + ": next-BatchNorm partial sums differ"
+  assert bool(torch.equal(gz2, gz3)) and bool(torch.equal(gx2, gx3)) and bool(torch.equal(s2, s3)), tag + ": two launches differ"
+  assert float(ops.pcl_interior(ops.pcl_view(gx2, g), g).abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("B,H,W,dil", [(2, 160, 1242, 1), (2, 161, 1242, 2), (1, 375, 1030, 4), (2, 163, 1237, 8)])
 def test_conv32_backward_by_minimal_filtering(B, H, W, dil):
   """as_conv32_wino_bwd — the backward of as_conv32_bwd_fused as a data gradient F(2x2, 3x3) and a weight gradient F(3x3, 2x2)

@@ -4,9 +4,9 @@ The kernels that issue `global_load_*` from inline asm and retire them with thei
 about WHEN the destination registers become valid: the compiler may copy (or spill) them between the load and the wait — a read
 of an in-flight destination, i.e. stale data that comes and goes with memory latency (this happened once: a v_mov of ten
 operand registers in front of a branch that held two different waits).  This script compiles a source to ISA and reports every
-instruction that reads or overwrites a register while an asm-issued load into it is outstanding; the register set is cleared at
-every `s_waitcnt vmcnt(...)`.  Waits counted with N > 0 are handled conservatively: the OLDEST outstanding loads are retired
-first (loads retire in order), N of the youngest stay pending.
+instruction that reads or overwrites a register while a load into it is outstanding, along every path of the kernel's
+control-flow graph (loops included: a block is walked again for every new queue of outstanding operations it is reached with).
+`s_waitcnt vmcnt(N)` retires the OLDEST outstanding operations (they retire in order), the N youngest stay pending.
 
 usage: python tests/tools/check_async_loads.py [file.hip ...]      (default: every csrc/*.hip that contains an asm load)
 exit status 1 if a hazard is found."""
@@ -26,67 +26,145 @@ def regs(tok):
   return out
 
 
-def _scan(lines, pending, hazards, seen):
-  """One straight-line pass over `lines` from the given queue of outstanding operations; returns the queue at its end."""
-  for no, l in lines:
-    if l.endswith(":"):
-      continue
-    parts = l.split(None, 1)
-    op, args = parts[0], (parts[1] if len(parts) > 1 else "")
-    if op.startswith("s_waitcnt"):
-      m = re.search(r"vmcnt\((\d+)\)", args)
-      if m:
-        n = int(m.group(1))
-        pending = pending[max(0, len(pending) - n):] if n else []       # (vmcnt(n) with fewer than n outstanding retires nothing)
-      continue
-    if op in ("s_endpgm",):
-      break
-    used = regs(args)
-    inflight = set().union(*[p[0] for p in pending]) if pending else set()
+def _step(no, l, pending, hazards, seen):
+  """One instruction against the queue of outstanding vector-memory operations (a tuple of (registers, line) in issue order;
+  stores carry an empty register set).  Returns the queue behind the instruction."""
+  parts = l.split(None, 1)
+  op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+  if op.startswith("s_waitcnt"):
+    m = re.search(r"vmcnt\((\d+)\)", args)
+    if m:
+      n = int(m.group(1))
+      pending = pending[max(0, len(pending) - n):] if n else ()       # (vmcnt(n) with fewer than n outstanding retires nothing)
+    return pending
+  used = regs(args)
+  inflight = set().union(*[p[0] for p in pending]) if pending else set()
 
-    def hazard(rs):
-      if (no, tuple(rs)) not in seen:
-        seen.add((no, tuple(rs)))
-        hazards.append((no, l, rs))
-    if op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")) and "lds" not in op:
-      dst = regs(args.split(",")[0])
-      src = used - dst
-      if src & inflight:
-        hazard(sorted(src & inflight))
-      pending = pending + [(dst, no)]
-      continue
-    if op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_load_lds", "global_atomic")):
-      if used & inflight:
-        hazard(sorted(used & inflight))
-      pending = pending + [(set(), no)]
-      continue
+  def hazard(rs):
+    if (no, tuple(rs)) not in seen:
+      seen.add((no, tuple(rs)))
+      hazards.append((no, l, rs))
+  if op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")) and "lds" not in op:
+    dst = regs(args.split(",")[0])
+    src = used - dst
+    if src & inflight:
+      hazard(sorted(src & inflight))
+    return (pending + ((frozenset(dst), no),))[-63:]                  # (vmcnt counts to 63)
+  if op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_load_lds", "global_atomic")):
     if used & inflight:
       hazard(sorted(used & inflight))
+    return (pending + ((frozenset(), no),))[-63:]
+  if used & inflight:
+    hazard(sorted(used & inflight))
   return pending
 
 
 def check_kernel(name, lines):
-  """lines: the kernel's instructions and labels in program order.  The pass is straight-line, plus ONE more turn of every
-  loop: at a backward branch the body (label .. branch) is scanned again starting from the queue of operations outstanding
-  at the branch, so a load issued textually BEHIND a wait in the body is seen in flight at the top of the next iteration."""
+  """lines: the kernel's instructions and labels in program order.  The queue of outstanding operations is carried along EVERY
+  path of the control-flow graph (basic blocks cut at labels and branches; a block is walked again whenever it is reached
+  with a queue it has not seen yet, so a load issued behind a wait in a loop body is seen in flight at the top of the next
+  iteration, and the code of one wave role never inherits what another role — laid out in front of it, but not a predecessor —
+  left in flight)."""
   hazards, seen = [], set()
   label_at = {l[:-1]: i for i, (no, l) in enumerate(lines) if l.endswith(":")}
-  pending, start = [], 0
+  n = len(lines)
+
+  def successors(i):
+    """indices of the instructions that may execute after lines[i]"""
+    no, l = lines[i]
+    if l.endswith(":"):
+      return [i + 1] if i + 1 < n else []
+    parts = l.split(None, 1)
+    op = parts[0]
+    if op == "s_endpgm":
+      return []
+    if op == "s_branch":
+      t = label_at.get(parts[1].strip()) if len(parts) > 1 else None
+      return [t] if t is not None else []
+    if op.startswith("s_cbranch"):
+      t = label_at.get(parts[1].strip()) if len(parts) > 1 else None
+      out = [i + 1] if i + 1 < n else []
+      if t is not None:
+        out.append(t)
+      return out
+    if op.startswith(("s_setpc", "s_swappc")):
+      return []
+    return [i + 1] if i + 1 < n else []
+
+  leaders = {0}
+  for i, (no, l) in enumerate(lines):
+    if l.endswith(":"):
+      leaders.add(i)
+    else:
+      op = l.split(None, 1)[0]
+      if op.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc", "s_swappc")) and i + 1 < n:
+        leaders.add(i + 1)
+  visited = set()
+  work = [(0, ())]
+  states = 0
+  while work:
+    i, pending = work.pop()
+    key = (i, tuple(p[1] for p in pending))
+    if key in visited:
+      continue
+    visited.add(key)
+    states += 1
+    if states > 400000:
+      raise RuntimeError("%s: more than 400000 (block, queue) states" % name)
+    while True:                                # walk the block
+      no, l = lines[i]
+      if not l.endswith(":"):
+        pending = _step(no, l, pending, hazards, seen)
+      succ = successors(i)
+      if len(succ) == 1 and succ[0] == i + 1 and (i + 1) not in leaders:
+        i += 1
+        continue
+      for t in succ:
+        work.append((t, pending))
+      break
+  return hazards
+
+
+def check_kernel_linear(name, lines):
+  """Straight-line pass in program order (branches not followed) plus ONE more turn of every loop body.  For kernels whose
+  counted waits rest on a data-dependent invariant a path analysis cannot know (LINEAR_ONLY below)."""
+  hazards, seen = [], set()
+  label_at = {l[:-1]: i for i, (no, l) in enumerate(lines) if l.endswith(":")}
+
+  def scan(seg, pending):
+    for no, l in seg:
+      if l.endswith(":"):
+        continue
+      if l.split(None, 1)[0] == "s_endpgm":
+        break
+      pending = _step(no, l, pending, hazards, seen)
+    return pending
+  pending, start = (), 0
   for i, (no, l) in enumerate(lines):
     parts = l.split(None, 1)
     if parts and parts[0].startswith(("s_cbranch", "s_branch")) and len(parts) > 1:
       tgt = label_at.get(parts[1].strip())
       if tgt is not None and tgt < i:
-        pending = _scan(lines[start:i], pending, hazards, seen)
-        _scan(lines[tgt:i], list(pending), hazards, seen)        # the next iteration, from what this one left in flight
+        pending = scan(lines[start:i], pending)
+        scan(lines[tgt:i], pending)                        # the next iteration, from what this one left in flight
         start = i
-  _scan(lines[start:], pending, hazards, seen)
+  scan(lines[start:], pending)
   return hazards
 
 
+# Kernels checked in program order only, and why the path analysis does not apply to them.
+LINEAR_ONLY = {
+    "conv32_act.hip": "its run-in waits with vmcnt(4) for a row behind 'exactly four by-product stores per wave' of the row before — "
+                      "true because row j0 is always one of the piece's own rows and row j0-1 never is, which no path analysis "
+                      "knows: on the (infeasible) paths with fewer stores the wait retires fewer loads",
+}
+
+
 def main():
-  files = [os.path.abspath(f) for f in sys.argv[1:]] or [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-                           if re.search(r'asm volatile\("global_load_dword', open(f).read())]
+  def hand_waited(f):
+    text = open(f).read()                  # asm loads of its own, or through the shared helpers of conv32_wino_dev.h
+    return re.search(r'asm volatile\("global_load_dword', text) or '#include "conv32_wino_dev.h"' in text
+  files = [os.path.abspath(f) for f in sys.argv[1:]] or [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip"))) if hand_waited(f)]
   bad = 0
   for f in files:
     with tempfile.TemporaryDirectory() as td:
@@ -107,8 +185,10 @@ def main():
     for name, lines in kernels.items():
       if not any(x[1].startswith("global_load") for x in lines):
         continue
-      hz = check_kernel(name, lines)
-      print("%-28s %-60s %s" % (os.path.basename(f), name[:60], "ok" if not hz else "%d HAZARD(S)" % len(hz)))
+      linear = os.path.basename(f) in LINEAR_ONLY
+      hz = check_kernel_linear(name, lines) if linear else check_kernel(name, lines)
+      print("%-28s %-60s %s%s" % (os.path.basename(f), name[:60], "ok" if not hz else "%d HAZARD(S)" % len(hz),
+                                  " (program order only)" if linear else ""))
       for no, l, r in hz[:6]:
         print("      line %d: %s   <- in-flight %s" % (no, l[:90], r[:8]))
       bad += len(hz)

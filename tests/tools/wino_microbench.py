@@ -27,7 +27,7 @@ for dil in (() if ONLY_BWD else (1, 2, 4, 8)):
   shape = ops.conv_shape_2d(dil)
   wp = ops.pack_weights(w, shape, False)
   for skip in (True, False):
-    for name, wt, parts in (("act", wp, lib.as_conv32_act_parts()), ("wino", ww, lib.as_conv32_wino_parts())):
+    for name, wt, parts, fg in (("act", wp, lib.as_conv32_act_parts(), None), ("wino", ww, lib.as_conv32_wino_parts(), None)):
       stats = ops.StatParts(parts, DEV)
       def run():
         nat.call("as_conv32_%s_fwd" % name, nat.ptr(z_prev), nat.ptr(a_pp) if skip else None, nat.ptr(st.scale), nat.ptr(st.shift),
@@ -39,8 +39,25 @@ for dil in (() if ONLY_BWD else (1, 2, 4, 8)):
       for _ in range(20): run()
       e1.record(); torch.cuda.synchronize()
       us = e0.elapsed_time(e1) * 1e3 / 20
-      print("B%d d%d %-5s %-4s %8.1f us  %6.1f TFLOP/s algorithmic (%.3f of 157.3)" % (B, dil, "skip" if skip else "plain", name, us,
+      print("B%d d%d %-5s %-4s%s %8.1f us  %6.1f TFLOP/s algorithmic (%.3f of 157.3)" % (B, dil, "skip" if skip else "plain", name, "" if fg is None else " g%d" % fg, us,
             flops / us * 1e-6, flops / us * 1e-6 / 157.3), flush=True)
+
+# ---- inference block (as_conv32_wino_eval) ----
+if not ONLY_BWD:
+  e_out = ops.pcl_zeros(g, DEV)
+  for dil in (1, 2, 4, 8):
+    shape = ops.conv_shape_2d(dil)
+    for fg in (1,):
+      def run():
+        nat.call("as_conv32_wino_eval", nat.ptr(z_prev), g, shape, nat.ptr(ww), nat.ptr(b), nat.ptr(st.scale), nat.ptr(st.shift), 0.2, 1,
+                 nat.ptr(e_out), nat.stream())
+      for _ in range(3): run()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(20): run()
+      e1.record(); torch.cuda.synchronize()
+      us = e0.elapsed_time(e1) * 1e3 / 20
+      print("B%d d%d inference block %8.1f us" % (B, dil, us), flush=True)
 
 # ---- backward: as_conv32_bwd_fused against as_conv32_wino_bwd (data gradient + weight gradient launches) ----
 g_a, zn = a_pp, z_prev
@@ -65,12 +82,18 @@ for dil in (1, 2, 4, 8):
     nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
              nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(gz), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 1, nat.ptr(nws), nat.ptr(fws), nat.stream())
-  for name, run in ((("wino", run_wino),) if ONLY_BWD else (("fused", run_fused), ("wino", run_wino))):
+  gens = [int(v) for v in os.environ.get("WMB_GEN", "2").split(",")]      # data-gradient kernel generation(s): "1,2" times both
+  legs = [("wino g%d" % gn, run_wino, gn) for gn in gens]
+  if not ONLY_BWD:
+    legs = [("fused", run_fused, None)] + legs
+  for name, run, gn in legs:
+    if gn is not None:
+      lib.as_conv32_wino_bwd_generation(gn)
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
-    print("B%d d%d backward %-5s %8.1f us (incl. the slab reduce)  %6.1f TFLOP/s algorithmic (%.3f of 157.3)" % (
+    print("B%d d%d backward %-7s %8.1f us (incl. the slab reduce)  %6.1f TFLOP/s algorithmic (%.3f of 157.3)" % (
         B, dil, name, us, 2 * flops / us * 1e-6, 2 * flops / us * 1e-6 / 157.3), flush=True)
