@@ -137,19 +137,12 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
   __syncthreads();
 
   // ---- row conversion: a row is staged d + 64 + d voxels wide (round 4: it was 8 + 64 + 8 whatever the dilation — 1.25 x the
-  // operand tensors from HBM where a tile only reaches d voxels beyond its segment); a PAIR of rows is 2 * RC 16-byte chunks,
-  // RC = 8 * (64 + 2d): chunk f = t + 256k, f < RC row A else row B, up to five per thread (the fifth: 32 / 64 / 128 / 256
-  // threads at d = 1 / 2 / 4 / 8).  Staged voxel v = V0 + (chunk / 8) in the 80-voxel frame the LDS image keeps.
+  // operand tensors from HBM where a tile only reaches d voxels beyond its segment), a pair of rows per step, up to five 16-byte
+  // chunks per thread (the fifth: 32 / 64 / 128 / 256 threads at d = 1 / 2 / 4 / 8); addressing: WnPair (conv32_wino_dev.h)
+  using P = WnPair<256, L>;
   const int t = threadIdx.x;
-  constexpr int NV = 64 + 2 * d, V0 = 8 - d, RC = 8 * NV;
-  // (t2: an opaque copy of the thread index per use — see conv32_wino_dgrad.hip: keeps the per-chunk offsets out of registers
-  //  that would live across the matrix phase)
-  auto chunk = [&](int t2, int k, bool& active, bool& isb, int& fr) {
-    const int f = t2 + 256 * k;
-    active = 256 * (k + 1) <= 2 * RC || f < 2 * RC;
-    isb = 256 * k >= RC || (256 * (k + 1) > RC && f >= RC);
-    fr = isb ? f - RC : f;
-  };
+  P pr;
+  pr.init(t, 0);
 
   // ---- operand gather: this lane's tile li, input column m -> staged voxel 8 + c0 + (m-1) d; chunk 4h + q ----
   int op_off[4];
@@ -195,20 +188,24 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
     const int px0 = x0 - 8 + p.g.pw;
 
     f32x4 pz[5], pa[5];
+    static_assert(P::K == 5, "five chunks per thread and row pair");
+    const bool edge = x0 < d || x0 + WN_SEG + d > W;        // (uniform) a halo column of this segment lies outside the image
     auto fetch_one = [&](int ja, const float* src, f32x4 (&pv)[5]) {     // rows ja, ja + 1; outside the image: any valid row
       const int ya = min(max(r0 + ja * d, 0), H - 1), yb = min(max(r0 + (ja + 1) * d, 0), H - 1);
-      const long offa = ((img + ya + p.g.ph) * Wp + px0) * 32;
-      const unsigned delta = (unsigned)((yb - ya) * Wp * 128);           // byte distance row A -> row B (clamped rows: >= 0)
-      int t2 = t;
-      asm volatile("" : "+v"(t2));
+      const float* base = src + ((img + ya + p.g.ph) * Wp + px0 + P::V0) * 32;     // row A's first staged voxel
+      const long delta_f = (long)(yb - ya) * Wp * 32;                    // row A -> row B in floats (clamped rows: >= 0)
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
-        bool active, isb; int fr;
-        chunk(t2, k, active, isb, fr);
         // EVERY lane issues all five loads (the counted waits below rest on that): a lane without a fifth chunk re-reads the
         // pair's last one
-        const int frc = active ? fr : RC - 1;
-        wn_load4(pv[k], src + offa, (unsigned)((V0 * 8 + frc) * 16) + (isb ? delta : 0u));
+        if (P::all_a(k)) {
+          wn_load4(pv[k], base + 256 * 4 * k, pr.t16);
+        } else if (P::all_b(k)) {
+          const unsigned vo = P::full(k) ? pr.t16 : (pr.t <= P::CL ? pr.t16 : (unsigned)(P::CL * 16));
+          wn_load4(pv[k], base + (256 * k - P::RC) * 4 + delta_f, vo);
+        } else {                                           // the chunk that straddles the two rows: threads t >= TS are in row B
+          wn_load4(pv[k], base + (256 * k - P::RC) * 4, pr.t16 + (pr.t >= P::TS ? (unsigned)(delta_f * 4) : (unsigned)(P::RC * 16)));
+        }
       }
     };
     auto fetch_into = [&](int ja, f32x4 (&pz)[5], f32x4 (&pa)[5]) {
@@ -225,21 +222,19 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
       } else if constexpr (!EVAL) {
         sc = *reinterpret_cast<const f32x4*>(tab); sh = *reinterpret_cast<const f32x4*>(tab + 32);
       }
-      const int ya_c = min(max(r0 + ja * d, 0), H - 1), yb_c = min(max(r0 + (ja + 1) * d, 0), H - 1);
-      const long offa = ((img + ya_c + p.g.ph) * Wp + px0) * 32;       // (an own row is never a clamped one)
-      const unsigned delta = (unsigned)((yb_c - ya_c) * Wp * 128);
-      int t2 = t;
-      asm volatile("" : "+v"(t2));
+      // per row of the pair (uniform): inside the image?  one of this piece's own rows (by-product)?  ring slot, output row
+      const int y_a = r0 + ja * d, y_b = r0 + (ja + 1) * d;
+      const bool in_a = y_a >= 0 && y_a < H, in_b = y_b >= 0 && y_b < H;
+      const bool own_a = ja >= j0 && ja < j1, own_b = ja + 1 >= j0 && ja + 1 < j1;
+      const int ya_c = min(max(y_a, 0), H - 1), yb_c = min(max(y_b, 0), H - 1);
+      float* out_a = p.a_out + ((img + ya_c + p.g.ph) * Wp + px0 + P::V0) * 32;     // (an own row is never a clamped one)
+      const long delta_f = (long)(yb_c - ya_c) * Wp * 32;
+      char* ring_a = smem + ((ja + 1) & 3) * WN_ROW_BYTES;
+      char* ring_b = smem + ((ja + 2) & 3) * WN_ROW_BYTES;
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
-        bool active, isb; int fr;
-        chunk(t2, k, active, isb, fr);
-        if (!active) continue;
-        const int jj = isb ? ja + 1 : ja;
-        const int y = r0 + jj * d;
-        const bool row_in = y >= 0 && y < H;
-        const int v = V0 + (fr >> 3);
-        const int xx = x0 - 8 + v;
+        const bool strad = !P::all_a(k) && !P::all_b(k);
+        const bool rowb = pr.in_b(k);                       // (per lane only for the straddling chunk)
         f32x4 yv;
         if constexpr (BWD) {                                // stage 3 of the BatchNorm backward (conv32_bwd.hip's arithmetic)
           const f32x4 ga = pa[k], zz = pz[k];
@@ -258,11 +253,25 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
           yv.z = fmaxf(yv.z, ys.z); yv.w = fmaxf(yv.w, ys.w);
           if (SKIP) yv += pa[k];
         }
-        const bool halo = v < 8 || v >= 72;                // (only halo voxels can lie outside the image)
-        if (!row_in || (!EVAL && halo && !(xx >= 0 && xx < W))) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * WN_ROW_BYTES + wn_addr<L>(v, t2 & 7)) = yv;
-        const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
-        if (!EVAL && own && !halo) wn_store4(p.a_out + offa, (unsigned)((V0 * 8 + fr) * 16) + (isb ? delta : 0u), yv);
+        // halo voxels: only they can lie outside the image (then they read as zero padding), and they are not part of the
+        // by-product; which chunks can hold any is known at compile time
+        bool halo = false;
+        if (P::may_halo(k, false) || P::may_halo(k, true)) {
+          const int vq = pr.vq(k, rowb);
+          halo = vq < d || vq >= WN_SEG + d;
+          if (!EVAL && edge && halo) {
+            const int xx = x0 - d + vq;
+            if (!(xx >= 0 && xx < W)) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        if (!(rowb ? in_b : in_a)) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool act = pr.active(k);
+        if (act) *reinterpret_cast<f32x4*>((rowb ? ring_b : ring_a) + (strad ? (rowb ? pr.lds_b(k) : pr.lds_a(k)) : (P::all_b(k) ? pr.lds_b(k) : pr.lds_a(k)))) = yv;
+        if (!EVAL && act && (rowb ? own_b : own_a) && !halo) {
+          if (P::all_a(k)) wn_store4(out_a + 256 * 4 * k, pr.t16, yv);
+          else if (P::all_b(k)) wn_store4(out_a + (256 * k - P::RC) * 4 + delta_f, pr.t16, yv);
+          else wn_store4(out_a + (256 * k - P::RC) * 4, pr.t16 + (rowb ? (unsigned)(delta_f * 4) : (unsigned)(P::RC * 16)), yv);
+        }
       }
     };
     auto wait_all = [&](f32x4 (&pz)[5], f32x4 (&pa)[5]) {

@@ -29,3 +29,47 @@ template <int L> __device__ inline int wn_swz(int v) {
 }
 template <int L> __device__ inline int wn_addr(int v, int chunk) { return wn_pos<L>(v) * 128 + ((chunk ^ wn_swz<L>(v)) << 4); }
 
+
+// ---- row-pair addressing of the conversions ----
+// A conversion team of NT threads (256: all four waves of conv32_wino.hip; 128: the two inner waves of conv32_wino_dgrad.hip)
+// turns a PAIR of rows, d + 64 + d voxels each, into LDS ring rows: chunk f = t + NT k of the pair's 2 * RC 16-byte chunks
+// (RC = 8 NV per row), f < RC row A, else row B.  Everything a chunk's addresses depend on is linear in t, so a thread keeps
+// 1 + 2 PER loop-invariant registers — its byte offset t * 16 and the LDS offsets of its first row-A / row-B chunks per swizzle
+// phase (the swizzle repeats every 32 voxels) — and reaches chunk k through compile-time immediates and scalar base adds.
+// (Recomputing voxel, position, swizzle and offsets per chunk and tile was ~25 integer instructions per chunk: with the
+// vector ALU adding to the matrix time on a SIMD, a fifth of the forward kernel's run time.)
+template <int NT, int L> struct WnPair {
+  static constexpr int d = 1 << L, NV = 64 + 2 * d, V0 = 8 - d, RC = 8 * NV;
+  static constexpr int K = (2 * RC + NT - 1) / NT;        // chunks per thread and pair
+  static constexpr int STEP = NT / 8;                      // voxels from a thread's chunk k to its chunk k + 1
+  static constexpr int PER = 32 / STEP;                    // chunks per swizzle period: 1 or 2
+  static constexpr int KS = RC / NT;                       // the chunk index that straddles the two rows (if any)
+  static constexpr bool STRADDLE = (RC % NT) != 0;
+  static constexpr int TS = RC - NT * KS;                  // ... threads t >= TS of it are in row B
+  static constexpr int CL = 2 * RC - 1 - NT * (K - 1);     // thread whose last chunk is the pair's last chunk
+  __host__ __device__ static constexpr bool all_a(int k) { return NT * (k + 1) <= RC; }
+  __host__ __device__ static constexpr bool all_b(int k) { return NT * k >= RC; }
+  __host__ __device__ static constexpr bool full(int k) { return NT * (k + 1) <= 2 * RC; }
+  __host__ __device__ static constexpr int kb(int ph) { int k = RC / NT; while (k % PER != ph) ++k; return k; }
+  // can chunk k hold halo voxels (row-relative voxel vq < d or vq >= 64 + d)?  vq spans [STEP k - (B ? NV : 0), + STEP)
+  __host__ __device__ static constexpr bool may_halo(int k, bool rowb) {
+    const int lo = STEP * k - (rowb ? NV : 0), hi = lo + STEP - 1;
+    return (lo < d && hi >= 0) || (hi >= 64 + d && lo < NV);
+  }
+  int t;                                                   // thread of the team
+  unsigned t16;                                            // t * 16
+  int la[PER], lb[PER];                                    // LDS offsets in a ring row: chunk (k = ph) of row A, chunk kb(ph) of row B
+  __device__ inline void init(int t_, int lds_bias) {
+    t = t_; t16 = (unsigned)t_ * 16u;
+#pragma unroll
+    for (int ph = 0; ph < PER; ++ph) {
+      la[ph] = wn_addr<L>(V0 + (t_ >> 3) + STEP * ph, t_ & 7) - lds_bias;
+      lb[ph] = wn_addr<L>(V0 + (t_ >> 3) + STEP * kb(ph) - NV, t_ & 7) - lds_bias;
+    }
+  }
+  __device__ inline int lds_a(int k) const { return la[k % PER] + (k - k % PER) * STEP * 128; }
+  __device__ inline int lds_b(int k) const { return lb[k % PER] + (k - kb(k % PER)) * STEP * 128; }
+  __device__ inline bool in_b(int k) const { return all_b(k) || (!all_a(k) && t >= TS); }       // per lane only for k == KS
+  __device__ inline bool active(int k) const { return full(k) || t <= CL; }
+  __device__ inline int vq(int k, bool rowb) const { return (t >> 3) + STEP * k - (rowb ? NV : 0); }   // staged voxel 0..NV-1
+};

@@ -110,9 +110,12 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
   constexpr int rb = ROLE == 0 ? 2 : (ROLE == 1 ? 2 : (ROLE == 2 ? 1 : 3));
   constexpr bool SG_PLUS = ROLE == 1;
 
-  // ---- inner waves: conversion geometry.  Chunk f = tid2 + 128 k of a row pair: f < RC row A, else row B ----
+  // ---- inner waves: the conversion team of 128 threads; addressing: WnPair (conv32_wino_dev.h) ----
+  using P = WnPair<128, L>;
+  static_assert(P::K == K && P::RC == G::RC, "geometry");
   const int tid2 = (ROLE - 1) * 64 + lane;                 // 0..127 over waves 1, 2
-  const int cq = tid2 & 7;                                  // 16-byte chunk of the voxel (constant over k: 128 and RC divide by 8)
+  P pr;
+  pr.init(INNER ? tid2 : lane, G::V0 * 128);
   // ---- outer waves: this wave finishes output row oi of every tile, both column parities ----
   constexpr int oi = ROLE == 3 ? 1 : 0;
   const unsigned io_off = (unsigned)(wn_c0<L>(4 * h) * 128 + 4 * li);
@@ -141,49 +144,48 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
 
     // ================= inner waves: fetch and convert a row pair (ja, ja + 1) =================
     f32x4 pz[K], pa[K];
-    long pair_off = 0;                                      // float offset of row A's first staged voxel
-    unsigned pair_delta = 0;                                // byte distance row A -> row B (rows outside the image are clamped)
-    auto chunk = [&](int t2, int k, bool& active, bool& isb, int& fr) {
-      const int f = t2 + 128 * k;
-      active = 128 * (k + 1) <= 2 * G::RC || f < 2 * G::RC;
-      isb = 128 * k >= G::RC || (128 * (k + 1) > G::RC && f >= G::RC);
-      fr = isb ? f - G::RC : f;
-    };
+    long pair_off = 0;                                      // float offset of row A's first staged voxel of the pair in flight
+    long pair_delta = 0;                                    // row A -> row B in floats (rows outside the image are clamped: >= 0)
+    const bool edge = x0 < d || x0 + 64 + d > W;            // (uniform) a halo column of this segment lies outside the image
     auto pair_rows = [&](int ja) {
       const int ya = min(max(r0 + ja * d, 0), H - 1), yb = min(max(r0 + (ja + 1) * d, 0), H - 1);
       pair_off = ((img + ya + p.g.ph) * Wp + px0) * 32;
-      pair_delta = (unsigned)((yb - ya) * Wp * 128);
+      pair_delta = (long)(yb - ya) * Wp * 32;
     };
-    // (t2: an opaque copy of the thread index per use — hipcc otherwise hoists the 3 K per-chunk offsets of the conversion out
-    //  of the tile loop, into registers that then live across the matrix phase: 16-36 spills)
-    auto fetch_one = [&](const float* src, f32x4 (&pv)[K]) {
-      int t2 = tid2;
-      asm volatile("" : "+v"(t2));
+    auto fetch_one = [&](const float* base, f32x4 (&pv)[K]) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        bool active, isb; int fr;
-        chunk(t2, k, active, isb, fr);
-        if (active) wn_load4(pv[k], src + pair_off, (unsigned)(fr * 16) + (isb ? pair_delta : 0u));
+        if (P::all_a(k)) {
+          wn_load4(pv[k], base + 128 * 4 * k, pr.t16);
+        } else if (P::all_b(k)) {
+          if (pr.active(k)) wn_load4(pv[k], base + (128 * k - P::RC) * 4 + pair_delta, pr.t16);
+        } else {                                           // the chunk that straddles the two rows: threads t >= TS are in row B
+          wn_load4(pv[k], base + (128 * k - P::RC) * 4, pr.t16 + (pr.t >= P::TS ? (unsigned)(pair_delta * 4) : (unsigned)(P::RC * 16)));
+        }
       }
     };
     auto convert = [&](int ja, f32x4 (&pz)[K], f32x4 (&pa)[K]) {           // -> ring slots (ja + 1) & 3, (ja + 2) & 3
-      const float* tab = reinterpret_cast<const float*>(smem + G::COEF_OFF) + cq * 4;
+      const float* tab = reinterpret_cast<const float*>(smem + G::COEF_OFF) + (tid2 & 7) * 4;
       const f32x4 k1 = *reinterpret_cast<const f32x4*>(tab), k2 = *reinterpret_cast<const f32x4*>(tab + 32);
       const f32x4 k3 = *reinterpret_cast<const f32x4*>(tab + 64), sc = *reinterpret_cast<const f32x4*>(tab + 96);
       const f32x4 sh = *reinterpret_cast<const f32x4*>(tab + 128), bmu = *reinterpret_cast<const f32x4*>(tab + 160);
-      int t2 = tid2;
-      asm volatile("" : "+v"(t2));
-      const int cq = t2 & 7;
+      // per row of the pair (uniform): inside the image?  one of this piece's own rows?  ring slot, raw slot, by-product row
+      const int y_a = r0 + ja * d, y_b = r0 + (ja + 1) * d;
+      const bool in_a = y_a >= 0 && y_a < H, in_b = y_b >= 0 && y_b < H;
+      const bool own_a = ja >= j0 && ja < j1, own_b = ja + 1 >= j0 && ja + 1 < j1;
+      char* ring_a = smem + ((ja + 1) & 3) * G::ROWB;
+      char* ring_b = smem + ((ja + 2) & 3) * G::ROWB;
+      // raw g_a row for the skip connection: odd comb rows slot 0, even rows slot 1 + (row / 2) % 2; voxel vq - d of the slot
+      auto raw_slot = [&](int jj) { return (jj & 1) ? 0 : 1 + ((jj >> 1) & 1); };
+      const bool raw_a = own_a && (G::RAW_EVEN || (ja & 1)), raw_b = own_b && (G::RAW_EVEN || ((ja + 1) & 1));
+      char* rawp_a = smem + G::RAW_OFF + raw_slot(ja) * 8192 - d * 128;
+      char* rawp_b = smem + G::RAW_OFF + raw_slot(ja + 1) * 8192 - d * 128 - G::NV * 128;
+      float* out_a = p.g_z + pair_off;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        bool active, isb; int fr;
-        chunk(t2, k, active, isb, fr);
-        if (!active) continue;
-        const int jj = isb ? ja + 1 : ja;
-        const int y = r0 + jj * d;
-        const bool row_in = y >= 0 && y < H;
-        const int vq = fr >> 3;                             // staged voxel 0..NV-1; column x0 - d + vq
-        const int xx = x0 - d + vq;
+        const bool strad = !P::all_a(k) && !P::all_b(k);
+        const bool rowb = pr.in_b(k);                       // (per lane only for the straddling chunk)
+        const bool act = pr.active(k);
         // stage 3 of the BatchNorm backward (conv32_wino.hip MODE 2 / conv32_bwd.hip's arithmetic)
         const f32x4 ga = pa[k], zz = pz[k];
         const f32x4 yy = zz * sc + sh;
@@ -192,17 +194,27 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
         gy.x = yy.x > 0.f ? ga.x : gl.x; gy.y = yy.y > 0.f ? ga.y : gl.y;
         gy.z = yy.z > 0.f ? ga.z : gl.z; gy.w = yy.w > 0.f ? ga.w : gl.w;
         f32x4 yv = (gy - k1 - (zz - bmu) * k2) * k3;
-        const bool halo = vq < d || vq >= 64 + d;           // (only halo voxels can lie outside the image)
-        if (!row_in || (halo && !(xx >= 0 && xx < W))) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(smem + ((jj + 1) & 3) * G::ROWB + wn_addr<L>(vq + G::V0, cq) - G::V0 * 128) = yv;
-        const bool own = jj >= j0 && jj < j1;              // this piece writes the by-product of its own rows only
-        if (own && !halo) {
-          wn_store4(p.g_z + pair_off, (unsigned)(fr * 16) + (isb ? pair_delta : 0u), yv);
-          if (G::RAW_EVEN || (jj & 1)) {                    // the raw row for the skip connection: odd rows slot 0, even 1 / 2
-            const int slot = (jj & 1) ? 0 : 1 + ((jj >> 1) & 1);
-            *reinterpret_cast<f32x4*>(smem + G::RAW_OFF + slot * 8192 + (vq - d) * 128 + cq * 16) = ga;
+        // halo voxels: only they can lie outside the image (zero padding), and they have no by-product and no raw copy; which
+        // chunks can hold any is known at compile time
+        bool halo = false;
+        if (P::may_halo(k, false) || P::may_halo(k, true)) {
+          const int vq = pr.vq(k, rowb);
+          halo = vq < d || vq >= 64 + d;
+          if (edge && halo) {
+            const int xx = x0 - d + vq;
+            if (!(xx >= 0 && xx < W)) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
+        if (!(rowb ? in_b : in_a)) yv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (act) *reinterpret_cast<f32x4*>((rowb ? ring_b : ring_a) + (strad ? (rowb ? pr.lds_b(k) : pr.lds_a(k)) : (P::all_b(k) ? pr.lds_b(k) : pr.lds_a(k)))) = yv;
+        if (act && (rowb ? own_b : own_a) && !halo) {
+          if (P::all_a(k)) wn_store4(out_a + 128 * 4 * k, pr.t16, yv);
+          else if (P::all_b(k)) wn_store4(out_a + (128 * k - P::RC) * 4 + pair_delta, pr.t16, yv);
+          else wn_store4(out_a + (128 * k - P::RC) * 4, pr.t16 + (rowb ? (unsigned)(pair_delta * 4) : (unsigned)(P::RC * 16)), yv);
+          // (the raw row's voxel is (t >> 3) + 16 k [- NV] - d: linear in t as well)
+          if (rowb ? raw_b : raw_a) *reinterpret_cast<f32x4*>((rowb ? rawp_b : rawp_a) + 16 * k * 128 + pr.t16) = ga;
+        }
+        if (k & 1) __builtin_amdgcn_sched_barrier(0);      // (two chunks at a time: bounded register appetite)
       }
     };
     auto wait_all = [&](f32x4 (&pv)[K]) {                   // every load so far is home (in-order retirement)
@@ -227,11 +239,11 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
 #pragma unroll
       for (int k = 0; k < K; ++k) { pz[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; pa[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       pair_rows(j0 - 1);
-      fetch_one(p.z, pz); fetch_one(p.g_a, pa);
+      fetch_one(p.z + pair_off, pz); fetch_one(p.g_a + pair_off, pa);
       wait_all(pz); touch(pa);
       convert(j0 - 1, pz, pa);
       pair_rows(j0 + 1);
-      fetch_one(p.z, pz); fetch_one(p.g_a, pa);
+      fetch_one(p.z + pair_off, pz); fetch_one(p.g_a + pair_off, pa);
       wait_all(pz); touch(pa);
       convert(j0 + 1, pz, pa);
     }
@@ -240,7 +252,7 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
     for (int j = j0; j < j1; j += 2) {
       const bool more = j + 2 < j1;                        // (the last tile of a piece converts nothing)
       if constexpr (INNER) {
-        if (more) { pair_rows(j + 3); fetch_one(p.z, pz); }  // in flight during the matrix phase (g_a follows it)
+        if (more) { pair_rows(j + 3); fetch_one(p.z + pair_off, pz); }  // in flight during the matrix phase (g_a follows it)
       }
       const char* row_a = smem + ((j + ra) & 3) * G::ROWB;   // input row m of the tile = comb row j-1+m = slot (j+m) & 3
       const char* row_b = smem + ((j + rb) & 3) * G::ROWB;
@@ -299,7 +311,7 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
           *reinterpret_cast<f32x4*>(xw + gq * 1024) = (f32x4){T0[4 * gq], T0[4 * gq + 1], T0[4 * gq + 2], T0[4 * gq + 3]};
           *reinterpret_cast<f32x4*>(xw + 4096 + gq * 1024) = (f32x4){T1[4 * gq], T1[4 * gq + 1], T1[4 * gq + 2], T1[4 * gq + 3]};
         }
-        if (more) fetch_one(p.g_a, pa);                    // (the accumulators are dead: registers to spare)
+        if (more) fetch_one(p.g_a + pair_off, pa);                  // (the accumulators are dead: registers to spare)
         __syncthreads();                                   // B1: the T tiles are in place; nobody reads rows j-1, j any more
         if (more) {
           wait_all(pz); touch(pa);

@@ -28,6 +28,7 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv32_wino_kernel<1, 0>": 4 * vox * 128,              # minimal filtering: z_prev, a_prevprev read; a_prev, z written
        "conv32_wino_kernel<0, 0>": 3 * vox * 128,              # ... no skip input
        "conv32_wino_kernel<2, 0>": 5 * vox * 128,              # g_a, z, z_next read; g_z (by-product), g_x written
+       "conv32_wino_dgrad_kernel<0>": 5 * vox * 128,           # second generation of the data gradient (conv32_wino_dgrad.hip)
        "conv32_wino_wgrad_kernel<0>": 2 * vox * 128,           # x, g_z read
        "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128,
        "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128,

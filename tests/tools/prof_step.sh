@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): tests/tools/prof_step.sh <tag> [bench.py arguments, default --no-graph]
-#   -> gpurun_out/ss_<tag>.txt, timeline_<tag>.txt
+#   -> gpurun_out/ss_<tag>.txt, timeline_<tag>.txt      (PAIRS=<pairs per step> when --batch is given: star_kernels.py needs it)
 tag=${1:-x}
 shift
 extra=${@:---no-graph}
@@ -10,7 +10,7 @@ trace=$(find gpurun_out/prof_$tag -name "e_kernel_trace.csv" | head -1)
 python tests/tools/steady_state.py $trace 10 "$tag steady state ($extra)" > gpurun_out/ss_$tag.txt
 python tests/tools/step_timeline.py $trace fastest > gpurun_out/timeline_$tag.txt
 python tests/tools/forward_window.py $trace 10 > gpurun_out/fw_$tag.txt
-python tests/tools/star_kernels.py $trace 10 > gpurun_out/star_$tag.txt
+python tests/tools/star_kernels.py $trace 10 ${PAIRS:-4} > gpurun_out/star_$tag.txt
 cp $(find gpurun_out/prof_$tag -name "e_kernel_stats.csv" | head -1) gpurun_out/ks_$tag.csv
 rm -rf gpurun_out/prof_$tag
 tail -1 gpurun_out/be.log | cut -c1-120
