@@ -219,6 +219,158 @@ __global__ __launch_bounds__(256, NK > 8 ? 1 : 2) void agg_tail_kernel(TailArgs 
   }
 }
 
+// ---- second generation (round 4): no LDS staging, no barrier in the plane loop -----------------------------------------------
+// What the kernel above costs at 4 pairs (40 us for 24 MB; 95 / 211 us at 16 / 32 pairs — it does not saturate, so it is not
+// the launch size): a workgroup stages a RUN of 34 + 2 Wp = 194 voxels per plane for its 32 positions (6 x the bytes through
+// L2: 4.13 x on the HBM counters), every plane is a barrier with ONE wave per SIMD to cover it (240 workgroups at 4 pairs), and
+// the staged image is read back with 180 k bank conflicts per launch.  Here every thread fetches the nine tap chunks of ITS
+// position straight from L2 / L1 — a wave instruction is 8 voxels x 128 B = one contiguous KB, the three column-shifted loads
+// of a row overlap 7/8 in L1 — three planes in flight per thread (the kernel runs one workgroup per CU, i.e. one wave per SIMD:
+// 512 registers), activates them in registers (nine chunks instead of eight: the same vector work), and projects with the same
+// packed FMAs in the same order: bit-identical logits.  The four waves of a workgroup never wait for each other.  Workgroups
+// that share an XCD (block ids congruent mod 8) take CONSECUTIVE tiles, so the rows two tiles share are fetched into one L2.
+// NPOS = positions per workgroup (8 lanes each): 32, or 16 when 32 would leave CUs without a workgroup
+template <int IN, bool OUT, int NPOS>
+__global__ __launch_bounds__(8 * NPOS, 1) void agg_tail_direct_kernel(TailArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [BatchNorm merge scratch][logits TAIL_MAXD x 32 floats][weights 27 x 32 floats]
+  float* lg = reinterpret_cast<float*>(smem + BN_MERGE_SCRATCH_BYTES);
+  float* sw = lg + TAIL_MAXD * NPOS;
+  const int Wp = p.g.Wp, D = p.g.D;
+  int col;
+  {                                                       // XCD x takes the tiles [start_x, start_x + count_x): a bijection
+    const int n = (int)gridDim.x, xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+    col = xcd * (n >> 3) + min(xcd, n & 7) + q;
+  }
+  const int b = col / p.tiles_per_plane, t = col - b * p.tiles_per_plane;
+  const int first = p.g.ph * Wp + p.g.pw;
+  const int pos0 = min(first + NPOS * t, first + p.npos - NPOS);
+  const long plane_vox = (long)Wp * p.g.Hp;
+  const int c4 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int pos = pos0 + pl;
+  const int yp = (int)__umulhi((unsigned)pos, p.wp_magic), xp = pos - yp * Wp;
+  const bool interior = xp >= p.g.pw && xp < p.g.pw + p.g.W;          // rows are interior by construction
+  const int y = yp - p.g.ph, x = xp - p.g.pw;
+  // tap t9 of this position is an interior voxel (gets the activation; the others are the zero padding that was loaded)
+  unsigned tmask = 0u;
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int ps = pos + (t9 / 3 - 1) * Wp + (t9 % 3 - 1);
+    const int yy = (int)__umulhi((unsigned)ps, p.wp_magic), xx = ps - yy * Wp;
+    tmask |= ((xx >= p.g.pw && xx < p.g.pw + p.g.W && yy >= p.g.ph && yy < p.g.ph + p.g.H) ? 1u : 0u) << t9;
+  }
+  const long base = ((long)b * p.g.Dp * plane_vox + pos) * 32 + 4 * c4;      // + q * plane_vox * 32
+  auto fetch = [&](f32x4 (&r)[9], int q) {              // padded plane min(q, D+1) (D+1: the zero halo plane); branch-free
+    const float* src = p.x + base + (long)min(q, D + 1) * plane_vox * 32;
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) r[t9] = *reinterpret_cast<const f32x4*>(src + ((t9 / 3 - 1) * Wp + (t9 % 3 - 1)) * 32);
+  };
+  f32x4 r0[9], r1[9], r2[9];
+  fetch(r0, 1); fetch(r1, 2); fetch(r2, 3);
+
+  f32x4 in_sc = {0.f, 0.f, 0.f, 0.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
+  if (IN == 1) {
+    in_sc = *reinterpret_cast<const f32x4*>(p.in_scale + 4 * c4);
+    in_sh = *reinterpret_cast<const f32x4*>(p.in_shift + 4 * c4);
+  }
+  if (IN == 2) {
+    const float* tab = bn_merge_partials<16, NPOS / 4>(p.in_bn, smem, blockIdx.x == 0);
+    in_sc = *reinterpret_cast<const f32x4*>(tab + 4 * c4);
+    in_sh = *reinterpret_cast<const f32x4*>(tab + 32 + 4 * c4);
+  }
+  for (int i = threadIdx.x; i < 27 * 32; i += 8 * NPOS) { const int tp = i >> 5, c = i & 31; sw[i] = p.w[c * 27 + tp]; }
+  __syncthreads();                                       // sw is complete
+  f32x2 wr[27][2];
+#pragma unroll
+  for (int tp = 0; tp < 27; ++tp) {
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(sw + tp * 32 + 4 * c4);
+    wr[tp][0] = (f32x2){q4.x, q4.y}; wr[tp][1] = (f32x2){q4.z, q4.w};
+  }
+  const float bias = p.bias ? p.bias[0] : 0.f;
+  float s1 = bias, s2 = 0.f;                             // s1: logit d = q (has bias + P0), s2: logit d = q-1 (+ P1)
+
+  auto plane = [&](f32x4 (&r)[9], int q) {
+    const unsigned tm = q <= D ? tmask : 0u;             // the halo plane beyond D: zeros, no activation
+    f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+    f32x4 centre = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      f32x4 a4 = r[t9];
+      if (IN != 0) {
+        f32x4 a;
+        a.x = fmaf(a4.x, in_sc.x, in_sh.x); a.y = fmaf(a4.y, in_sc.y, in_sh.y);
+        a.z = fmaf(a4.z, in_sc.z, in_sh.z); a.w = fmaf(a4.w, in_sc.w, in_sh.w);
+        a.x = fmaxf(a.x, a.x * p.slope); a.y = fmaxf(a.y, a.y * p.slope);
+        a.z = fmaxf(a.z, a.z * p.slope); a.w = fmaxf(a.w, a.w * p.slope);
+        a4 = ((tm >> t9) & 1u) ? a : a4;
+      }
+      if (t9 == 4) centre = a4;
+      const f32x2 lo = {a4.x, a4.y}, hi = {a4.z, a4.w};
+      p0 = __builtin_elementwise_fma(lo, wr[t9][0], p0); p0 = __builtin_elementwise_fma(hi, wr[t9][1], p0);
+      p1 = __builtin_elementwise_fma(lo, wr[9 + t9][0], p1); p1 = __builtin_elementwise_fma(hi, wr[9 + t9][1], p1);
+      p2 = __builtin_elementwise_fma(lo, wr[18 + t9][0], p2); p2 = __builtin_elementwise_fma(hi, wr[18 + t9][1], p2);
+    }
+    // by-product: the activated voxel of this thread's own position — ONE unconditional store per thread and plane (planes
+    // beyond D write the zeros they loaded onto the zero halo plane; halo columns inside the tile likewise)
+    if (OUT) *reinterpret_cast<f32x4*>(p.a_out + base + (long)min(q, D + 1) * plane_vox * 32) = centre;
+    float q0 = p0.x + p0.y, q1 = p1.x + p1.y, q2 = p2.x + p2.y;
+    q0 += __shfl_xor(q0, 1, 64); q1 += __shfl_xor(q1, 1, 64); q2 += __shfl_xor(q2, 1, 64);
+    q0 += __shfl_xor(q0, 2, 64); q1 += __shfl_xor(q1, 2, 64); q2 += __shfl_xor(q2, 2, 64);
+    q0 += __shfl_xor(q0, 4, 64); q1 += __shfl_xor(q1, 4, 64); q2 += __shfl_xor(q2, 4, 64);
+    const float done = s2 + q2;
+    s2 = s1 + q1;
+    s1 = bias + q0;
+    if (q >= 2 && q - 2 < D && c4 == 0) lg[(q - 2) * NPOS + pl] = done;
+  };
+  for (int q = 1; q <= D + 1; q += 3) {                   // planes 1 .. D+1 (and up to two more passes over the zero plane)
+    plane(r0, q); fetch(r0, q + 3);
+    plane(r1, q + 1); fetch(r1, q + 4);
+    plane(r2, q + 2); fetch(r2, q + 5);
+  }
+  __syncthreads();
+
+  // ---- soft-argmax, arg-max, FCS: lane j of a position holds d = j, j+8, j+16, j+24 (as above) ----
+  float l[4];
+  float m1 = -INFINITY, m2 = -INFINITY, sum = 0.f;
+  int am = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = c4 + 8 * k;
+    l[k] = d < D ? lg[d * NPOS + pl] : -INFINITY;
+    if (d < D && interior) p.logits[(((long)b * D + d) * p.g.H + y) * p.g.W + x] = l[k];
+    if (d < D) {
+      sum += l[k];
+      if (l[k] > m1) { m2 = m1; m1 = l[k]; am = d; }
+      else if (l[k] > m2) { m2 = l[k]; }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    const float om1 = __shfl_xor(m1, o, 64), om2 = __shfl_xor(m2, o, 64), osum = __shfl_xor(sum, o, 64);
+    const int oam = __shfl_xor(am, o, 64);
+    sum += osum;
+    const float lo = fminf(m1, om1);
+    m2 = fmaxf(lo, fmaxf(m2, om2));
+    if (om1 > m1 || (om1 == m1 && oam < am)) { m1 = om1; am = oam; }
+  }
+  float e[4], se = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { e[k] = (c4 + 8 * k) < D ? expf(l[k] - m1) : 0.f; se += e[k]; }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) se += __shfl_xor(se, o, 64);
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc += (e[k] / se) * (float)(c4 + 8 * k);
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) acc += __shfl_xor(acc, o, 64);
+  if (c4 == 0 && interior) {
+    const long i = ((long)b * p.g.H + y) * p.g.W + x;
+    p.pred[i] = acc;
+    if (p.argmax) p.argmax[i] = am;
+    if (p.fcs) p.fcs[i] = (D > 2) ? m1 - (sum - m1 - m2) / (float)(D - 2) : 0.f;
+  }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------
 static int tail_run(const as_pcl* g) { return 34 + 2 * (g->W + 2 * g->pw); }
 #define TAIL_TABLE_BYTES (27 * 128)
@@ -244,7 +396,24 @@ static int tail_launch_t(const TailArgs& a, int grid, int lds_bytes, hipStream_t
   return AS_OK;
 }
 template <int IN, bool OUT>
+static int tail_launch_direct(const TailArgs& a0, hipStream_t st) {
+  // 16 positions per workgroup while 32 would give fewer than two workgroups per CU (4 pairs at 24 x 78: 240 of 32)
+  TailArgs a = a0;
+  const int B = a.g.B;
+  const bool small = (long)B * as_div_up(a.npos, 32) < 512 && a.npos >= 16;
+  const int npos = small ? 16 : 32;
+  a.tiles_per_plane = as_div_up(a.npos, npos);
+  const int grid = B * a.tiles_per_plane;
+  const int lds = BN_MERGE_SCRATCH_BYTES + TAIL_MAXD * npos * 4 + TAIL_TABLE_BYTES;
+  if (small) hipLaunchKernelGGL((agg_tail_direct_kernel<IN, OUT, 16>), dim3(grid), dim3(128), lds, st, a);
+  else hipLaunchKernelGGL((agg_tail_direct_kernel<IN, OUT, 32>), dim3(grid), dim3(256), lds, st, a);
+  return AS_OK;
+}
+template <int IN, bool OUT>
 static int tail_launch_nk(const TailArgs& a, int grid, int lds_bytes, hipStream_t st) {
+#ifndef TAIL_FIRST_GENERATION                             // (A/B builds: EXTRA=-DTAIL_FIRST_GENERATION)
+  return tail_launch_direct<IN, OUT>(a, st);
+#endif
   const int nk = (a.run + 31) / 32;
   if (nk <= 6) return tail_launch_t<IN, 6, OUT>(a, grid, lds_bytes, st);
   if (nk <= 8) return tail_launch_t<IN, 8, OUT>(a, grid, lds_bytes, st);

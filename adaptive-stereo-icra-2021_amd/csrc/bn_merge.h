@@ -25,25 +25,25 @@ struct BnMergeDev {
 
 #define BN_MERGE_SCRATCH_BYTES (8 * 32 * 3 * 8 + 64 * 4)      // [8][32][3] doubles + scale[32] + shift[32]
 
-// All 256 threads of the workgroup call (it contains two barriers).  On return tab[0..31] = scale, tab[32..63] = shift,
+// All 32 * SLICES threads of the workgroup call (it contains two barriers): 256 by default, 128 with SLICES = 4.  On return tab[0..31] = scale, tab[32..63] = shift,
 // where tab = (float*)(scratch + 6144).  `publish`: this workgroup writes the layer state and the running statistics.
 // ONE pass over the partials (a consumer waits for this: the two-pass form costs two dependent rounds of loads more):
 // with a pivot K (the first partial's mean) the sums  S0 = sum n_i,  S1 = sum n_i (mean_i - K),
 // S2 = sum [ M2_i + n_i (mean_i - K)^2 ]  give  mean = K + S1/S0  and  M2 = S2 - S1^2/S0  — algebraically the two-pass
 // result, and in fp64 (the terms are fp32 data, the pivot is within the data's range) equal to it to ~1e-15 relative.
-template <int BATCH>      // partials per thread whose loads are in flight together (3 x BATCH registers)
+template <int BATCH, int SLICES = 8>      // BATCH: partials per thread whose loads are in flight together (3 x BATCH registers)
 __device__ inline float* bn_merge_partials(const BnMergeDev& m, char* scratch, bool publish) {
   double* red = reinterpret_cast<double*>(scratch);            // [8][32][3]
   float* tab = reinterpret_cast<float*>(scratch + 8 * 32 * 3 * 8);
   const int c = threadIdx.x & 31, slc = threadIdx.x >> 5;
-  const int per_slice = (m.nparts + 7) >> 3;
+  const int per_slice = (m.nparts + SLICES - 1) / SLICES;
   const double K = (double)m.stat_mean[c];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int j0 = 0; j0 < per_slice; j0 += BATCH) {
     float pn[BATCH], pm[BATCH], pq[BATCH];
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {                       // every load of the round in flight together
-      const int i = slc + 8 * (j0 + j);
+      const int i = slc + SLICES * (j0 + j);
       const bool ok = i < m.nparts;
       const int ii = ok ? i : 0;
       pn[j] = ok ? m.stat_cnt[ii] : 0.f;
@@ -61,7 +61,7 @@ __device__ inline float* bn_merge_partials(const BnMergeDev& m, char* scratch, b
   __syncthreads();
   if (slc == 0) {
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    for (int j = 0; j < 8; ++j) { const double* r = red + (j * 32 + c) * 3; t0 += r[0]; t1 += r[1]; t2 += r[2]; }
+    for (int j = 0; j < SLICES; ++j) { const double* r = red + (j * 32 + c) * 3; t0 += r[0]; t1 += r[1]; t2 += r[2]; }
     const double count = t0;
     const double mean = K + t1 / count;
     const double m2 = fmax(t2 - t1 * t1 / count, 0.0);

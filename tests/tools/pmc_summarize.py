@@ -34,7 +34,9 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128,
        "agg3d_kernel<0, 2, false>": 2 * vox3 * 128 + 27 * 4096, "agg3d_kernel<0, 0, false>": 2 * vox3 * 128 + 27 * 4096,
        "agg3d_kernel<2, 0, false>": 3 * vox3 * 128 + 27 * 4096,      # raw operand read, activated by-product and output written
-       "agg_tail_kernel<2, 8, true>": 2 * vox3 * 128 + vox3 * 4}
+       "agg_tail_kernel<2, 8, true>": 2 * vox3 * 128 + vox3 * 4,
+       "agg_tail_direct_kernel<2, true, 16>": 2 * vox3 * 128 + vox3 * 4,      # second generation of the tail (direct loads)
+       "agg_tail_direct_kernel<2, true, 32>": 2 * vox3 * 128 + vox3 * 4}
 out = {"shape": "2-D 3x3 stride 1, 32->32, %d pair(s) x 375x1242 (one full-resolution refinement layer); 3-D rows: 12x24x78 per pair" % B,
        "pairs_per_launch": B, "algorithmic_flops_per_launch": flops,
        "command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 tests/tools/pmc_conv.py   (separate passes: SQ_* ; FETCH_SIZE ; WRITE_SIZE GRBM_GUI_ACTIVE)",

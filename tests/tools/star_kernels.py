@@ -16,10 +16,10 @@ table = [
   ("cost_volume_fwd", "a2 fwd", 2 * F + V, None), ("cost_volume_bwd", "a2 bwd", V + 2 * F, None),
   ("conv32_fwd_kernel<27>", "a3 conv3d fwd/dgrad (direct-load)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
   ("conv3d_lds_kernel", "a3 conv3d fwd/dgrad (LDS)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
-  ("agg3d_kernel<0, 0>", "a3 layer 1: conv3d + moments (rolling window)", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
-  ("agg3d_kernel<2, 0>", "a3 layers 2-4: BN merge + act in LDS + conv3d + moments", 3 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
-  ("agg3d_kernel<0, 1>", "a3 eval layer: conv3d + folded BN + LReLU", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
-  ("agg3d_kernel<0, 2>", "a3 conv3d data gradient (rolling window)", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("agg3d_kernel<0, 0,", "a3 layer 1: conv3d + moments (rolling window)", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("agg3d_kernel<2, 0,", "a3 layers 2-4: BN merge + act in LDS + conv3d + moments", 3 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("agg3d_kernel<0, 1,", "a3 eval layer: conv3d + folded BN + LReLU", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("agg3d_kernel<0, 2,", "a3 conv3d data gradient (rolling window)", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
   ("agg_tail_kernel", "a4+a5+a8 fused tail (+ layer-4 BN/LReLU, by-product)", 2 * V + Lg + 3 * P, None),
   ("conv3d_wgrad_lds_kernel", "a3 conv3d wgrad (LDS)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
   ("conv32to1_fwd_kernel", "a4 conv3d_alone fwd", V + Lg, None),
