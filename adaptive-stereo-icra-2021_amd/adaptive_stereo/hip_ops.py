@@ -203,6 +203,17 @@ def set_head_proj(enabled):
   return prev
 
 
+_REFINE_OUT = True       # the refinement's output layer on csrc/refine_out.hip (False: bn_act_fwd + conv32to1_2d_fwd_kernel)
+
+
+def set_refine_out(enabled):
+  """Output layer of the refinement (with the last block's BatchNorm + LeakyReLU + skip on the way in) as one launch, or as
+  the two launches of rounds 1-3 (parity tests compare both); returns the previous setting."""
+  global _REFINE_OUT
+  prev, _REFINE_OUT = _REFINE_OUT, bool(enabled)
+  return prev
+
+
 def set_fwd_act(enabled):
   global _FWD_ACT
   prev, _FWD_ACT = _FWD_ACT, bool(enabled)
@@ -1377,6 +1388,7 @@ class EdgeRefineFn(torch.autograd.Function):
       POOL.put(z0, g); z0 = None
 
     xs, zs, sts = [a0], [], []
+    tail_fused = None
     if fused_act:
       # every layer forms its own operand: layer l reads z_{l-1} (+ a_{l-2}), leaves a_{l-1} behind as a by-product and
       # writes z_l; only the last layer's output needs a BatchNorm + LeakyReLU pass of its own
@@ -1389,7 +1401,10 @@ class EdgeRefineFn(torch.autograd.Function):
                                           rm, rv)
         xs.append(a_prev); zs.append(z); sts.append(st)
         z_prev, st_prev = z, st
-      xs.append(bn_act(z_prev, st_prev, g, residual=xs[-1]))
+      if _REFINE_OUT and lib.as_refine_out_ok(g) == 1:
+        tail_fused = (z_prev, xs[-1], st_prev)            # the last block's activation rides on the output layer (below)
+      else:
+        xs.append(bn_act(z_prev, st_prev, g, residual=xs[-1]))
     else:
       for l, dil in enumerate(REFINE_DILATIONS):
         wl, bl, gamma, beta = params[4 + 4 * l:8 + 4 * l]
@@ -1401,7 +1416,18 @@ class EdgeRefineFn(torch.autograd.Function):
 
     w_out, b_out = params[28], params[29]
     out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-    call("as_conv32to1_fwd", ptr(xs[-1]), g, s33, ptr(w_out), ptr(b_out), ptr(up), 1, ptr(out), stream())
+    if tail_fused is not None:
+      # a6 = lrelu(BN(z6)) + a5 formed while conv2d_out stages its rows, written once for the backward pass (csrc/refine_out.hip)
+      z6, a5, st6 = tail_fused
+      a6 = POOL.get(g, dev)
+      call("as_refine_out_fwd", ptr(z6), ptr(a5), ptr(st6.scale), ptr(st6.shift), LEAKY_SLOPE, ptr(a6), g, ptr(w_out), ptr(b_out),
+           ptr(up), 1, ptr(out), stream())
+      xs.append(a6)
+    elif _REFINE_OUT and lib.as_refine_out_ok(g) == 1:
+      call("as_refine_out_fwd", ptr(xs[-1]), None, None, None, LEAKY_SLOPE, None, g, ptr(w_out), ptr(b_out), ptr(up), 1, ptr(out),
+           stream())
+    else:
+      call("as_conv32to1_fwd", ptr(xs[-1]), g, s33, ptr(w_out), ptr(b_out), ptr(up), 1, ptr(out), stream())
 
     if need_bwd:
       ctx.g, ctx.g4, ctx.train = g, g4, bool(train)

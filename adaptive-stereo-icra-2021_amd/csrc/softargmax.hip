@@ -369,38 +369,66 @@ __global__ __launch_bounds__(256) void conv32to1_2d_dgrad_kernel(Thin2dBwdArgs p
 }
 
 // g_w[c][t] = sum_u a[u][c] g_out[u - off_t];  g_bias = sum g_out.  One partial slab per workgroup.
+// Round 4: the next chunk's operands — four 16-byte activation loads and up to two gradient-map values per thread — are
+// requested BEFORE the current chunk's 144 FMAs instead of behind the barrier that opens it (every chunk then paid a whole HBM
+// round trip: 81 us for 245 MB at 4 pairs), and the staged gradient rows alternate between two LDS buffers: one barrier per chunk.
 __global__ __launch_bounds__(256) void conv32to1_2d_wgrad_kernel(Thin2dBwdArgs p) {
-  __shared__ float sg[3][132];
+  __shared__ float sg[2][3][132];
   __shared__ float red[32][33];
   const int c4 = threadIdx.x & 7, vl = threadIdx.x >> 3;
   f32x4 acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float gsum = 0.f;
-  for (int ch = blockIdx.x; ch < p.nchunks; ch += gridDim.x) {
+  // this thread's staging jobs: i = tid, tid + 256 of the 3 x 130 gradient values; its four float4 of the activation chunk
+  const int i0 = threadIdx.x, i1 = threadIdx.x + 256;
+  const int r0 = i0 / 130, q0 = i0 - r0 * 130, r1 = i1 / 130, q1 = i1 - r1 * 130;
+  auto request = [&](int ch, f32x4 (&a4)[4], float& g0, float& g1) {
     const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
     const int y = rowi % p.g.H, b = rowi / p.g.H, x0 = cx * 128;
     const int nf4 = min(128, p.g.W - x0) * 8;
-    __syncthreads();
-    thin_stage_g(p, sg, b, y, x0);
-    __syncthreads();
     const float* src = p.a + (((long)b * p.g.Hp + (y + p.g.ph)) * p.g.Wp + (x0 + p.g.pw)) * 32;
-    f32x4 a4[4];
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       const int f = threadIdx.x + 256 * k4;
-      if (f < nf4) a4[k4] = *reinterpret_cast<const f32x4*>(src + f * 4);
+      a4[k4] = *reinterpret_cast<const f32x4*>(src + min(f, nf4 - 1) * 4);      // (beyond the chunk: re-read, ignored)
+    }
+    auto gval = [&](int r, int c) {
+      const int yy = y - 1 + r, xx = x0 - 1 + c;
+      const bool in = yy >= 0 && yy < p.g.H && xx >= 0 && xx < p.g.W;
+      const float v = p.g_out[((long)b * p.g.H + min(max(yy, 0), p.g.H - 1)) * p.g.W + min(max(xx, 0), p.g.W - 1)];
+      return in ? v : 0.f;
+    };
+    g0 = gval(r0, q0);
+    g1 = i1 < 3 * 130 ? gval(r1, q1) : 0.f;
+  };
+  f32x4 a4[2][4];
+  float g0[2], g1[2];
+  int ch = blockIdx.x, it = 0;
+  if (ch < p.nchunks) request(ch, a4[0], g0[0], g1[0]);
+  for (; ch < p.nchunks; ch += gridDim.x, it ^= 1) {
+    const int rowi = ch / p.chunks_per_row, cx = ch - rowi * p.chunks_per_row;
+    const int x0 = cx * 128;
+    const int nf4 = min(128, p.g.W - x0) * 8;
+    float (*sgc)[132] = sg[it];
+    sgc[r0][q0] = g0[it];
+    if (i1 < 3 * 130) sgc[r1][q1] = g1[it];
+    __syncthreads();                                       // (the other buffer's readers passed this barrier a chunk ago)
+    if (ch + (int)gridDim.x < p.nchunks) {
+      if (it == 0) request(ch + gridDim.x, a4[1], g0[1], g1[1]);
+      else request(ch + gridDim.x, a4[0], g0[0], g1[0]);
     }
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       const int f = threadIdx.x + 256 * k4;
       if (f < nf4) {
         const int vx = f >> 3;
-        if (c4 == 0) gsum += sg[1][vx + 1];
+        const f32x4 av = it == 0 ? a4[0][k4] : a4[1][k4];
+        if (c4 == 0) gsum += sgc[1][vx + 1];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += sg[2 - ky][vx + 2 - kx] * a4[k4];
+          for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += sgc[2 - ky][vx + 2 - kx] * av;
       }
     }
   }

@@ -199,6 +199,18 @@ int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, cons
                        float* g_x, float* dW, float* db, int accumulate, float* next_bn_workspace,
                        float* workspace, void* stream);
 
+/* ---- the refinement's output layer with the last BasicBlock's activation on the way in (csrc/refine_out.hip;
+ * stereo_net.py:44-51, 102, 116-121):  out = relu?(conv2d_out(a) + bias + add_src)  where
+ *   scale != NULL:  a = lrelu(x * scale + shift) (+ skip) — x is the block's pre-activation, scale / shift its BatchNorm as an
+ *                   affine; a is also written to a_out (the backward pass and nothing else reads it)
+ *   scale == NULL:  a = x (already activated: inference); skip, shift, a_out must be NULL
+ *   x, skip, a_out  PCL tensors of geometry g (as_refine_out_ok(g) == 1: 2-D, halo >= 1);  w [32][9], bias [1] or NULL
+ *   add_src, out    dense [B][H][W] */
+int as_refine_out_ok(const as_pcl* g);
+int as_refine_out_fwd(const float* x, const float* skip, const float* scale, const float* shift, float slope, float* a_out,
+                      const as_pcl* g, const float* w, const float* bias, const float* add_src, int relu, float* out,
+                      void* stream);
+
 /* ---- a3, second generation: one 3x3x3 stride-1 32->32 aggregation layer (stereo_net.py:21-30,155-161,185-186) or its data
  * gradient, walking down the disparity axis with a rolling window of planes in LDS (csrc/agg3d.hip).
  *   x, z, a_out      PCL tensors of geometry g (halo 1 in d, h, w; as_agg3d_ok(g) == 1)

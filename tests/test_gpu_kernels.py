@@ -464,6 +464,54 @@ def test_conv32to1_2d_fused_tail(B, H, W):
   close(g_w, w.grad, 2e-6 * n ** 0.5, 1e-5, "tail wgrad"); close(g_b, b.grad, 2e-6 * n ** 0.5, 1e-5, "tail bias grad")
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 9, 13), (2, 37, 53), (3, 33, 126), (2, 65, 127), (1, 96, 253), (2, 375, 1242)])
+def test_refinement_output_layer_with_the_last_activation_on_the_way_in(B, H, W):
+  """as_refine_out_fwd (csrc/refine_out.hip): relu(up + Conv2d(32,1,3,p=1)(a)) with a = lrelu(z * scale + shift) + skip formed
+  while the rows are staged — against torch on the CPU, and against the two launches it replaces (as_bn_act_fwd, then
+  as_conv32to1_fwd): the by-product a bit for bit (the backward pass reads it), nothing written into its halo; and the plain
+  form (a given, inference) against as_conv32to1_fwd.  Widths of one strip, one strip + 1, two strips + 1, the KITTI size;
+  heights that do not divide by the 32-row strips."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  lib = nat.load()
+  assert lib.as_refine_out_ok(g) == 1
+  shape = ops.conv_shape_2d(1)
+  z = rnd(B, 32, H, W, seed=1); skip = rnd(B, 32, H, W, seed=6)
+  w = rnd(1, 32, 3, 3, seed=2, scale=0.2); b = rnd(1, seed=3, scale=0.1); up = rnd(B, 1, H, W, seed=4)
+  st = ops.BnState(DEV)
+  st.scale.copy_(rnd(32, seed=7).abs().to(DEV) + 0.5); st.shift.copy_(rnd(32, seed=8).to(DEV) * 0.3)
+  sc, sh = st.scale.cpu().view(1, 32, 1, 1), st.shift.cpu().view(1, 32, 1, 1)
+  a_ref = F.leaky_relu(z * sc + sh, 0.2) + skip
+  ref = F.relu(up + F.conv2d(a_ref.double(), w.double(), b.double(), padding=1).float())
+  zb, sb = ops.ncdhw_to_pcl(z.unsqueeze(2).to(DEV), g), ops.ncdhw_to_pcl(skip.unsqueeze(2).to(DEV), g)
+  wd, bd, upd = w.to(DEV).contiguous(), b.to(DEV), up.to(DEV)
+  # the two launches
+  a_two = ops.bn_act(zb, st, g, residual=sb, out=ops.pcl_zeros(g, DEV))
+  out_two = torch.empty(B, 1, H, W, device=DEV)
+  nat.call("as_conv32to1_fwd", nat.ptr(a_two), g, shape, nat.ptr(wd), nat.ptr(bd), nat.ptr(upd), 1, nat.ptr(out_two), nat.stream())
+  # one launch
+  a_one, out_one = ops.pcl_zeros(g, DEV), torch.empty(B, 1, H, W, device=DEV)
+  nat.call("as_refine_out_fwd", nat.ptr(zb), nat.ptr(sb), nat.ptr(st.scale), nat.ptr(st.shift), 0.2, nat.ptr(a_one), g, nat.ptr(wd),
+           nat.ptr(bd), nat.ptr(upd), 1, nat.ptr(out_one), nat.stream())
+  assert bool(torch.equal(a_one, a_two)), "by-product differs from as_bn_act_fwd (or the halo was written)"
+  scale = float(ref.abs().max())
+  e_one, e_two = float((out_one.cpu() - ref).abs().max()), float((out_two.cpu() - ref).abs().max())
+  assert e_one <= max(2.0 * e_two, 2e-6 * scale), (e_one, e_two, scale)
+  # no skip connection; no add_src, no ReLU
+  a_ns, out_ns = ops.pcl_zeros(g, DEV), torch.empty(B, 1, H, W, device=DEV)
+  nat.call("as_refine_out_fwd", nat.ptr(zb), None, nat.ptr(st.scale), nat.ptr(st.shift), 0.2, nat.ptr(a_ns), g, nat.ptr(wd),
+           None, None, 0, nat.ptr(out_ns), nat.stream())
+  a_ns_ref = F.leaky_relu(z * sc + sh, 0.2)
+  close(ops.pcl_to_ncdhw(a_ns, g)[:, :, 0], a_ns_ref, 2e-6, 1e-6, "activation without skip")
+  close(out_ns, F.conv2d(a_ns_ref.double(), w.double(), None, padding=1).float(), 4e-6 * scale, 1e-5, "plain output")
+  # inference form: a given
+  out_inf = torch.empty(B, 1, H, W, device=DEV)
+  nat.call("as_refine_out_fwd", nat.ptr(a_two), None, None, None, 0.2, None, g, nat.ptr(wd), nat.ptr(bd), nat.ptr(upd), 1,
+           nat.ptr(out_inf), nat.stream())
+  assert bool(torch.equal(out_inf, out_one)), "the inference form must give the fused form's bits (same staged values)"
+  from conftest import parity_note
+  parity_note("refine_out[B%d %dx%d]" % (B, H, W), max_err_vs_fp64=e_one, two_launch_max_err_vs_fp64=e_two, by_product_bit_identical=True)
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 9, 12), (2, 21, 30), (1, 47, 156), (1, 188, 621)])
 def test_conv32_dgrad_stride2(B, H, W):
   """Data gradient of Conv2d(32,32,5,stride=2,padding=2): four parity phases of a transposed conv."""

@@ -7,7 +7,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 fwd = rows[adam[-1] + 1:]
 # an inference ends with the refinement's 32->1 output convolution; keep the last `steps` of them
-ends = [i for i, r in enumerate(fwd) if 'conv32to1_2d_fwd_kernel' in r['Kernel_Name']]
+ends = [i for i, r in enumerate(fwd) if 'conv32to1_2d_fwd_kernel' in r['Kernel_Name'] or 'refine_out_kernel' in r['Kernel_Name']]
 first = ends[-steps - 1] + 1
 win = fwd[first:ends[-1] + 1]
 t0, t1 = int(win[0]['Start_Timestamp']), int(win[-1]['End_Timestamp'])
