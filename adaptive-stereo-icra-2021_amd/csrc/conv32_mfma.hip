@@ -32,8 +32,18 @@
 #include "conv32_bwd.h"
 #include "conv32_act.h"
 #include "conv32_wino.h"
+#include "conv32_s2.h"
 
 static bool wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
+
+// The 5x5 stride-2 layers of the feature head on csrc/conv32_s2.hip (1, default) or on the generic direct-load kernels (0):
+// same bits either way (the parity tests compare them); returns the previous setting.
+static int g_conv32_s2 = 1;
+extern "C" int as_conv32_s2_enable(int on) {
+  const int prev = g_conv32_s2;
+  if (on == 0 || on == 1) g_conv32_s2 = on;
+  return prev;
+}
 
 struct ConvArgs {
   const float* x;
@@ -668,6 +678,13 @@ extern "C" int as_conv32_dgrad_s2_packed(const float* gz, const as_pcl* ggz, con
                "as_conv32_dgrad_s2: gz extent is not that of a 5x5 stride-2 pad-2 convolution of gx's extent");
   AS_CHECK_ARG(ggz->ph >= 1 && ggz->pw >= 1, "as_conv32_dgrad_s2: gz needs a zero halo of 1");
   hipStream_t st = (hipStream_t)stream;
+  if (g_conv32_s2 && conv32_s2_dgrad_applicable(ggz, ggx)) {
+    as_prof_mark(AS_PROF_CONV32, st, 1, 0.0);
+    if (int e = conv32_s2_dgrad_launch(gz, ggz, packed, gx, ggx, stream)) return e;
+    as_prof_mark(AS_PROF_CONV32, st, 0, 2.0 * (double)ggx->B * ggz->H * ggz->W * 1024.0 * 25.0);
+    AS_CHECK_LAUNCH("as_conv32_dgrad_s2(staged)");
+    return AS_OK;
+  }
   const int Wp = ggz->W + 2 * ggz->pw;
   const float* wp = workspace;
   DgradS2Args args;
@@ -1061,6 +1078,17 @@ extern "C" int as_conv32_fwd(const float* x, const as_pcl* gin, const float* pac
   if (conv3d_lds_applicable(gin, gout, s))
     return conv3d_lds_launch(x, gin, packed_w, bias, z, gout, epilogue, ep_scale, ep_shift, slope, residual,
                              stat_mean, stat_m2, stat_cnt, stream);
+  const int64_t M_all = (int64_t)gout->B * gout->D * gout->H * gout->W;
+  if (epilogue == 0 && residual == nullptr && stat_mean == nullptr && g_conv32_s2 && conv32_s2_fwd_applicable(gin, gout, s) &&
+      !conv32_splitk_applies(25, M_all)) {
+    // the strided head of the feature towers on maps that fill the chip: coalesced row staging (csrc/conv32_s2.hip)
+    hipStream_t st2 = (hipStream_t)stream;
+    as_prof_mark(0, st2, 1, 0.0);
+    if (int e = conv32_s2_fwd_launch(x, gin, packed_w, bias, z, gout, stream)) return e;
+    as_prof_mark(0, st2, 0, 2.0 * (double)M_all * 1024.0 * 25.0);
+    AS_CHECK_LAUNCH("as_conv32_fwd(5x5 stride 2)");
+    return AS_OK;
+  }
   ConvArgs a;
   a.x = x; a.wp = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = residual;

@@ -199,6 +199,12 @@ int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, cons
                        float* g_x, float* dW, float* db, int accumulate, float* next_bn_workspace,
                        float* workspace, void* stream);
 
+/* ---- the 5x5 stride-2 32->32 layers of the feature head (stereo_net.py:59-72): as_conv32_fwd and as_conv32_dgrad_s2(_packed)
+ * run them on csrc/conv32_s2.hip (coalesced row staging through wave-private LDS) when the map fills the chip; 0 switches back to
+ * the generic direct-load kernels (same bits: the parity tests compare them).  Returns the previous setting; any other argument
+ * only queries */
+int as_conv32_s2_enable(int on);
+
 /* ---- the refinement's output layer with the last BasicBlock's activation on the way in (csrc/refine_out.hip;
  * stereo_net.py:44-51, 102, 116-121):  out = relu?(conv2d_out(a) + bias + add_src)  where
  *   scale != NULL:  a = lrelu(x * scale + shift) (+ skip) — x is the block's pre-activation, scale / shift its BatchNorm as an
