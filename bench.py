@@ -427,9 +427,9 @@ def main():
   # conv32_lds family.  For a minimal-filtering kernel `achieved` still counts the ALGORITHMIC FLOPs of the layer (SURVEY 8d:
   # 2 x voxels x 32 x 32 x 9, what the direct form executes), `executed` what the matrix pipe actually does (4/9 of them).
   NAMES = {
-      24: ("conv32_wino_kernel<2, L>", "conv32_wino_kernel<2, 0>", 5,
+      24: ("conv32_wino_dgrad_kernel<L> (dilation 1, 2, 4) / conv32_wino_kernel<2, 3> (dilation 8)", "conv32_wino_dgrad_kernel<0>", 5,
            "data gradient of a full-resolution layer by minimal filtering F(2x2,3x3): stage 3 of the BatchNorm backward on the way "
-           "in (g_z written once), skip connection, next BatchNorm's sums"),
+           "in (g_z written once), skip connection from raw g_a rows kept in LDS, next BatchNorm's sums"),
       25: ("conv32_wino_wgrad_kernel<L>", "conv32_wino_wgrad_kernel<0>", 2,
            "weight / bias gradient of a full-resolution layer by minimal filtering F(3x3,2x2) from x and g_z (LDS-DMA rows)"),
       26: ("conv32_wino_kernel<0|1, L>", "conv32_wino_kernel<1, 0>", 4,
@@ -456,7 +456,7 @@ def main():
     rec = None
     # the newest committed PMC file wins (rocprofv3 --pmc passes cannot run inside this timed process: the counters come
     # from tests/tools/pmc_run.sh runs of the same kernels at 1, 2 and 4 pairs per launch, committed under profiles/)
-    for name in ("r03_pmc_by_pairs.json", "r02_pmc_by_pairs.json"):
+    for name in ("r04_pmc_by_pairs.json", "r03_pmc_by_pairs.json", "r02_pmc_by_pairs.json"):
       by_pairs = os.path.join(REPO, "profiles", name)
       if os.path.exists(by_pairs):
         table = json.load(open(by_pairs))
@@ -479,8 +479,9 @@ def main():
       if dom_id == -1:
         if "conv32_lds_kernel<0, false>" in ks and "conv32_lds_kernel<3, true>" in ks:
           traffic = int((ks["conv32_lds_kernel<0, false>"]["hbm_bytes_per_launch"] + ks["conv32_lds_kernel<3, true>"]["hbm_bytes_per_launch"]) / 2 * scale)
-      elif NAMES[dom_id][1] in ks:
-        traffic = int(ks[NAMES[dom_id][1]]["hbm_bytes_per_launch"] * scale)
+      elif NAMES[dom_id][1] in ks or (dom_id == 24 and "conv32_wino_kernel<2, 0>" in ks):
+        key_ = NAMES[dom_id][1] if NAMES[dom_id][1] in ks else "conv32_wino_kernel<2, 0>"      # (files older than round 4)
+        traffic = int(ks[key_]["hbm_bytes_per_launch"] * scale)
       traffic_detail = {"pairs_per_launch": rec.get("pairs_per_launch"),
                         "full_resolution_layers": {NAMES[i][1]: pmc_row(NAMES[i][1]) for i in NAMES if NAMES[i][1] in ks},
                         "forward": pmc_row("conv32_lds_kernel<0, false>"),

@@ -537,11 +537,13 @@ def test_conv32_dgrad_stride2(B, H, W):
 def test_strided_head_on_staged_rows_equals_the_generic_kernels(B, H, W):
   """Conv2d(32,32,5,stride=2,padding=2) forward and data gradient on csrc/conv32_s2.hip (coalesced row segments through
   wave-private LDS) against the generic direct-load kernels of conv32_mfma.hip (as_conv32_s2_enable(0)): bit for bit — the taps
-  and the channels are summed in the same order —, nothing written into a halo, and against torch on the CPU.  The bench
-  workload's two levels (8 images of 188 x 621 and 94 x 311), the full-resolution level of a k = 3 tower, odd extents."""
+  and the channels are summed in the same order —, nothing written into a halo; forward, data gradient and the weight gradient
+  (generic kernel in both settings: a staged-row variant was measured and not kept, profiles/r04_l_*) against torch on the
+  CPU.  The bench workload's two levels (8 images of 188 x 621 and 94 x 311), the full-resolution level of
+  a k = 3 tower, odd extents; the output halo is 1 where the tower's last level has 1."""
   shape = ConvShape(1, 5, 5, 0, 2, 2, 1, 2)
   Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-  gin, gout = Pcl(B, 1, H, W, 0, 2, 2), Pcl(B, 1, Ho, Wo, 0, 2, 2)
+  gin, gout = Pcl(B, 1, H, W, 0, 2, 2), Pcl(B, 1, Ho, Wo, 0, 1 + (H & 1), 1 + (H & 1))
   lib = nat.load()
   x = rnd(B, 32, H, W, seed=1); w = rnd(32, 32, 5, 5, seed=2, scale=0.035); b = rnd(32, seed=3, scale=0.1)
   gz = rnd(B, 32, Ho, Wo, seed=4)
@@ -557,17 +559,23 @@ def test_strided_head_on_staged_rows_equals_the_generic_kernels(B, H, W):
       z = ops.conv32(xb, gin, wp, bd, gout, shape, out=ops.pcl_zeros(gout, DEV))
       gx = ops.pcl_zeros(gin, DEV)
       nat.call("as_conv32_dgrad_s2", nat.ptr(gzb), gout, nat.ptr(wd), nat.ptr(gx), gin, nat.ptr(ws), nat.stream())
+      dW, db = ops.conv32_wgrad(xb, gin, gzb, gout, shape)
       torch.cuda.synchronize()
-      res[on] = (z, gx)
+      res[on] = (z, gx, dW, db)
   finally:
     lib.as_conv32_s2_enable(prev)
   for name, a, c in (("forward", res[0][0], res[1][0]), ("data gradient", res[0][1], res[1][1])):
     assert bool(torch.equal(a, c)), "%s: staged rows differ from the generic kernel in %d elements" % (name, int((a != c).sum()))
-  xr = x.clone().requires_grad_(True)
-  z_ref = F.conv2d(xr, w, b, stride=2, padding=2)
+  xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+  z_ref = F.conv2d(xr, wr, b, stride=2, padding=2)
   z_ref.backward(gz)
   close(ops.pcl_to_ncdhw(res[1][0], gout)[:, :, 0], z_ref, 3e-5, 1e-5, "stride-2 forward")
   close(ops.pcl_to_ncdhw(res[1][1], gin)[:, :, 0], xr.grad, 3e-5, 1e-5, "stride-2 data gradient")
+  scale = float(wr.grad.abs().max())
+  for on in (0, 1):
+    close(res[on][2] / scale, wr.grad / scale, 5e-5, 0.0, "stride-2 weight gradient (s2 switch: %d)" % on)
+    close(res[on][3] / scale, gz.double().sum((0, 2, 3)) / scale, 5e-5, 0.0, "stride-2 bias gradient (%d)" % on)
+  assert bool(torch.equal(res[1][2], res[0][2])), "the s2 switch must not change the weight gradient"
 
 
 @pytest.mark.parametrize("B,H,W,dil", [(2, 9, 131, 1), (1, 20, 300, 2)])

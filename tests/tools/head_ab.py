@@ -1,4 +1,4 @@
-"""Strided head of the feature towers at the bench workload: as_conv32_fwd (5x5 stride 2) and as_conv32_dgrad_s2 with
+"""Strided head of the feature towers at the bench workload: as_conv32_fwd (5x5 stride 2), as_conv32_dgrad_s2 and as_conv32_wgrad with
 as_conv32_s2_enable(0 / 1), HIP-event timing.  usage: python tests/tools/head_ab.py [images, default 8]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,12 +25,13 @@ for (H, W) in ((188, 621), (94, 311)):
   for on in (0, 1):
     lib.as_conv32_s2_enable(on)
     for name, run in (("forward", lambda: ops.conv32(xb, gin, wp, b, gout, shape, out=z)),
-                      ("data gradient", lambda: nat.call("as_conv32_dgrad_s2_packed", nat.ptr(gzb), gout, nat.ptr(ws), nat.ptr(gx), gin, nat.stream()))):
+                      ("data gradient", lambda: nat.call("as_conv32_dgrad_s2_packed", nat.ptr(gzb), gout, nat.ptr(ws), nat.ptr(gx), gin, nat.stream())),
+                      ("weight grad. (+ reduce)", lambda: ops.conv32_wgrad(xb, gin, gzb, gout, shape))):
       for _ in range(3): run()
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       e0.record()
       for _ in range(20): run()
       e1.record(); torch.cuda.synchronize()
       us = e0.elapsed_time(e1) * 1e3 / 20
-      print("%d x %dx%d -> %dx%d  %-13s %s %8.1f us  %6.1f TFLOP/s (%.3f of 157.3)" % (B, H, W, Ho, Wo, name, "staged " if on else "generic", us,
+      print("%d x %dx%d -> %dx%d  %-23s %s %8.1f us  %6.1f TFLOP/s (%.3f of 157.3)" % (B, H, W, Ho, Wo, name, "staged " if on else "generic", us,
             flops / us * 1e-6, flops / us * 1e-6 / 157.3), flush=True)
