@@ -324,10 +324,17 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
         const int xc = 2 * (s0 + u) + h;
         const bool ok = xc < W;
         const int xcl = ok ? xc : W - 1;
+#ifdef WG_EXP_NOLOAD                           // diagnostic build (tests/tools/head_exp.sh): results are wrong, only the time counts
+        const float g0 = (float)(xcl + lane);
+        bv[u] = ok ? g0 : 0.f;
+#pragma unroll
+        for (int g = 0; g < TG; ++g) av[u][g] = (float)(xcl * xs + toff[g]);
+#else
         const float g0 = gr[xcl * 32];
         bv[u] = ok ? g0 : 0.f;
 #pragma unroll
         for (int g = 0; g < TG; ++g) av[u][g] = xr[xcl * xs + toff[g]];
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);      // all loads of the group are issued before its first MFMA
 #pragma unroll
@@ -335,7 +342,11 @@ __global__ __launch_bounds__(256) void conv32_wgrad_kernel(WgradArgs p) {
         bsum += bv[u];
 #pragma unroll
         for (int g = 0; g < TG; ++g)
+#ifdef WG_EXP_NOMFMA
+          acc[g][0] += av[u][g] * bv[u];
+#else
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][g], bv[u], acc[g], 0, 0, 0);
+#endif
       }
     }
   }
