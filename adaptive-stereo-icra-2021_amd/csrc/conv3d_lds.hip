@@ -225,7 +225,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lds_kernel(Wgrad3dLdsArgs
   const int h = lane >> 5, li = lane & 31;
   const unsigned lane16 = (unsigned)lane * 16u;
   const int Wp = p.g.Wp;
-  const int chunk = blockIdx.x / 3, kd = blockIdx.x - 3 * chunk;
+  // XCD-aware (chunk, kd) assignment (block ids congruent mod 8 share an XCD and its 4-MB L2): an XCD owns a contiguous range
+  // of chunks — at any time its workgroups walk ADJACENT tiles, whose runs overlap by a row above and below — and all three kd
+  // of a chunk, which read the same G run and (one plane = tiles_per_plane chunks apart) the same X runs.  With blockIdx = 3 *
+  // chunk + kd the three landed on three XCDs and every run was fetched from the fabric by each: 5.0x the algorithmic bytes
+  // on the counters (profiles/r04_pmc_by_pairs.json).  Placement affects speed and traffic only.
+  // Tiles: `full` rounds of tile = chunk + k * nchunks, and the remaining tiles one each to the chunks that are dispatched FIRST
+  // on every XCD (they land on different CUs: no CU then hosts two workgroups with an extra tile — the launch is matrix-bound, a
+  // CU's time is the sum of its two workgroups' tiles; with the extra tiles on chunks 0..rem-1 = one XCD's neighbours: 55 us for 50).
+  int chunk, kd, extra_tile = -1;
+  const int full = p.ntiles / p.nchunks;
+  {
+    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+    const int per_xcd = (p.nchunks + 7) >> 3;
+    kd = q % 3;
+    chunk = xcd * per_xcd + q / 3;
+    if (chunk >= p.nchunks || q / 3 >= per_xcd) return;            // padding blocks (uniform per workgroup)
+    const int j = (q / 3) * 8 + xcd;
+    if (j < p.ntiles - full * p.nchunks) extra_tile = full * p.nchunks + j;
+  }
   const long plane_vox = (long)Wp * p.g.Hp;
   const int first = p.g.ph * Wp + p.g.pw;
   const int last_group = (int)plane_vox - 8;                       // last 8-voxel group that lies inside a plane
@@ -244,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lds_kernel(Wgrad3dLdsArgs
 #pragma unroll
   for (int t = 0; t < 9; ++t) xaddr[t] = xbuf + (32 * wave + h + (t / 3) * Wp + (t % 3)) * 128 + li * 4;
 
-  for (int tile = chunk; tile < p.ntiles; tile += p.nchunks) {
+  for (int k = 0; k < full + (extra_tile >= 0 ? 1 : 0); ++k) {
+    const int tile = k < full ? chunk + k * p.nchunks : extra_tile;
     const int plane = tile / p.tiles_per_plane, tt = tile - plane * p.tiles_per_plane;
     const int b = plane / p.g.D, d = plane - b * p.g.D;
     const int pos0 = first + 128 * tt;
@@ -327,7 +346,8 @@ bool conv3d_wgrad_lds_applicable(const as_pcl* gin, const as_pcl* gout, const as
 
 int conv3d_wgrad_lds_slabs(const as_pcl* gout) {
   const int ntiles = conv3d_lds_grid(gout);
-  return ntiles < 170 ? ntiles : 170;                      // 510 workgroups: two per CU
+  return ntiles < 168 ? ntiles : 168;                      // 21 chunks x 3 kd = 63 workgroups per XCD: one round of two per CU
+                                                           // (22 per XCD = 66 workgroups on 64 slots: a second round, 82 us for 50)
 }
 
 int conv3d_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
@@ -349,7 +369,7 @@ int conv3d_wgrad_lds_launch(const float* x, const as_pcl* gin, const float* gz, 
     if (e != hipSuccess) { as_set_error("as_conv32_wgrad(3-D LDS): %s", hipGetErrorString(e)); return AS_ERR_LAUNCH; }
     attr_set.set();
   }
-  hipLaunchKernelGGL(conv3d_wgrad_lds_kernel, dim3(3 * a.nchunks), dim3(256), lds_bytes, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv3d_wgrad_lds_kernel, dim3(8 * ((a.nchunks + 7) / 8) * 3), dim3(256), lds_bytes, (hipStream_t)stream, a);
   AS_CHECK_LAUNCH("as_conv32_wgrad(3-D LDS)");
   return AS_OK;
 }
