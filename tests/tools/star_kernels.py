@@ -20,7 +20,8 @@ table = [
   ("agg3d_kernel<2, 0,", "a3 layers 2-4: BN merge + act in LDS + conv3d + moments", 3 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
   ("agg3d_kernel<0, 1,", "a3 eval layer: conv3d + folded BN + LReLU", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
   ("agg3d_kernel<0, 2,", "a3 conv3d data gradient (rolling window)", 2 * V, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
-  ("agg_tail_kernel", "a4+a5+a8 fused tail (+ layer-4 BN/LReLU, by-product)", 2 * V + Lg + 3 * P, None),
+  ("agg_tail_kernel", "a4+a5+a8 fused tail, LDS-staged (+ layer-4 BN/LReLU, by-product)", 2 * V + Lg + 3 * P, None),
+  ("agg_tail_direct_kernel", "a4+a5+a8 fused tail (+ layer-4 BN/LReLU, by-product)", 2 * V + Lg + 3 * P, None),
   ("conv3d_wgrad_lds_kernel", "a3 conv3d wgrad (LDS)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
   ("conv32to1_fwd_kernel", "a4 conv3d_alone fwd", V + Lg, None),
   ("conv32to1_dgrad_kernel", "a4 dgrad", Lg + V, None), ("conv32to1_wgrad_kernel<27>", "a4 wgrad", V + Lg, None),
