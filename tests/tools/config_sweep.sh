@@ -6,7 +6,7 @@ run() {  # name height width k maxdisp batch
 import json,sys
 try:
   d=json.loads(sys.stdin.read())
-  print('%-28s pairs/GPU %d: adapt %7.1f pairs/s (%6.2f ms/step)   forward %7.1f pairs/s (%5.2f ms)   roofline kernel %5.1f TFLOP/s' % ('$1', $6, d['value'], d['ms_per_step'], d['fwd_pairs_per_s'], d['fwd_ms_per_step'], d['roofline']['achieved']))
+  print('%-28s pairs/GPU %d: adapt %7.1f pairs/s (%6.2f ms/step)   forward %7.1f pairs/s (%5.2f ms)   dominant kernel %6.1f %s = %.2f of its bound (%s)' % ('$1', $6, d['value'], d['ms_per_step'], d['fwd_pairs_per_s'], d['fwd_ms_per_step'], d['roofline']['achieved'], d['roofline']['unit'], d['roofline']['frac'], d['roofline']['bound']))
 except Exception as e:
   print('%-28s pairs/GPU %d: FAILED (%s)' % ('$1', $6, e))"
 }
