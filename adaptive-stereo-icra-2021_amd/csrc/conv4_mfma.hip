@@ -483,6 +483,10 @@ __global__ __launch_bounds__(256) void conv4_wgrad_rows_kernel(Wgrad4RowsArgs p)
 //   * the nine per-tap projections h[t][p] = sum_co g_z[p][co] * w_proj[t][co] (all the 32->1 data gradient that follows
 //     needs of g_z) on the vector ALUs, two threads per pixel;
 // 32 accumulator registers per lane, many workgroups per CU: the latency hides behind other workgroups.
+// Round 4, measured inside a step (tests/tools/exp_step.sh): 154 us with the projections, 107 us without them
+// (EXTRA=-DW4M_EXP_NOPROJ); the same projections as 16 MFMAs per wave and chunk (M = 32 pixels, N = 9 of 32 columns, K = co,
+// the result through a wave-private LDS patch to 128-byte stores) passed the parity tests and took 149 us: the matrix form
+// executes 32/9 of the products, no faster than 144 FMAs + 36 LDS reads per thread.  Not kept.
 #define W4M_PITCH 36                              // floats per pixel of the g_z tile
 #define W4M_GZ_BYTES (128 * W4M_PITCH * 4)        // 18,432
 #define W4M_X_OFF W4M_GZ_BYTES                    // three input rows of 130 pixels x 4 channels
@@ -560,7 +564,11 @@ __global__ __launch_bounds__(256, 4) void conv4_wgrad_mfma_kernel(Wgrad4RowsArgs
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc0, 0, 0, 0);
       acc8 += x8 * bv;
     }
+#ifdef W4M_EXP_NOPROJ                                   // diagnostic build (tests/tools/exp_step.sh): results are wrong
+    if (false) {
+#else
     if (PROJ) {
+#endif
       // two threads per pixel (16 channels each), nine projections, one shuffle to combine
       const int px = t >> 1, q = t & 1;
       const float* gp = gzt + px * W4M_PITCH + 16 * q;
