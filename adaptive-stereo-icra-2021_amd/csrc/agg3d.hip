@@ -187,10 +187,14 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
     in_sh = *reinterpret_cast<const f32x4*>(p.in_shift + 4 * cg);
   }
   if (IN == 2) {            // while the first three planes are in flight
+#ifdef AGG_EXP_NOMERGE      // diagnostic builds (tests/tools/exp_step.sh): results are wrong, only the time means something
+    in_sc = (f32x4){1.f, 1.f, 1.f, 1.f};
+#else
     const float* tab = bn_merge_partials<32>(p.in_bn, ring + ((d0 + 3) & 3) * p.slot_bytes, blockIdx.x == 0);   // plane d0+3's slot: no DMA target yet
     in_sc = *reinterpret_cast<const f32x4*>(tab + 4 * cg);
     in_sh = *reinterpret_cast<const f32x4*>(tab + 32 + 4 * cg);
     __syncthreads();        // every thread has its affine before plane d0+3 is requested into the scratch's slot
+#endif
   }
   unsigned ao[STRIP ? 12 : 1];                       // strip form: byte offset of chunk k's voxel in its plane (by-product)
   if (IN != 0) {
@@ -217,6 +221,9 @@ __global__ __launch_bounds__(256, 1) void agg3d_kernel(Agg3dArgs p) {
   // thread owns, so the twelve writes are unconditional too.
   char* dump = ring + 4 * p.slot_bytes + threadIdx.x * 16;
   auto activate = [&](int q) {                       // padded plane q, resident in slot q & 3
+#ifdef AGG_EXP_NOACT
+    return;
+#endif
     if (q < p.g.pd || q >= p.g.pd + p.g.D) return;   // a halo plane: zeros stay zeros
     char* slot = ring + (q & 3) * p.slot_bytes;
     const bool own = p.a_out != nullptr && q - p.g.pd >= d0 && q - p.g.pd < d1;
