@@ -64,12 +64,18 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_fwd_kernel(S2Args p) {
   // 2 x0 - 2 + v; LDS: half v & 1, entry v >> 1
   const int sv = lane >> 3, sq = lane & 7;
   const int s_half = (sv & 1) * S2F_HALF;
-  // input row 2y + ky - 2, first staged column 2 x0 - 2 (padded coordinates: + ph, + pw; the halo of 2 covers both)
-  const float* src0 = p.x + ((((long)b * p.gin.Hp + (2 * y - 2 + p.gin.ph)) * p.gin.Wp + (2 * x0 - 2 + p.gin.pw)) * 32) + lane * 4;
+  // input row 2y + ky - 2, first staged column 2 x0 - 2 (padded coordinates: + ph, + pw; the halo of 2 covers both).  The
+  // last segment of a row runs past the row's padded end: those voxels only feed outputs that are not stored, and they are
+  // CLAMPED to the row's last (halo) voxel — the last padded row of the last image has nothing behind it to read.
+  const float* src0 = p.x + ((((long)b * p.gin.Hp + (2 * y - 2 + p.gin.ph)) * p.gin.Wp + (2 * x0 - 2 + p.gin.pw)) * 32) + sq * 4;
+  const int vlim = p.gin.Wp - 1 - (2 * x0 - 2 + p.gin.pw);
+  int voff[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) voff[i] = min(8 * i + sv, vlim) * 32;
   auto fetch = [&](f32x4 (&r)[9], int ky) {
     const float* src = src0 + (long)ky * p.gin.Wp * 32;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r[i] = *reinterpret_cast<const f32x4*>(src + i * 256);
+    for (int i = 0; i < 9; ++i) r[i] = *reinterpret_cast<const f32x4*>(src + voff[i]);
   };
   auto stage = [&](const f32x4 (&r)[9], char* dst) {
 #pragma unroll
@@ -124,9 +130,8 @@ bool conv32_s2_fwd_applicable(const as_pcl* gin, const as_pcl* gout, const as_co
   if (gin->D != 1 || gout->D != 1 || gin->pd != 0 || gin->B != gout->B) return false;
   if (gout->H != (gin->H - 1) / 2 + 1 || gout->W != (gin->W - 1) / 2 + 1) return false;
   // the staged rows 2y-2 .. 2y+2 and columns 2x0-2 .. 2x0+69 must lie inside the padded tensor: a halo of 2 covers the rows
-  // and the left edge; on the right the last segment may run past its row's end — into the next padded row, which the bottom
-  // halo provides for the last row
-  if (gin->ph < 2 || gin->pw < 2 || (long)gin->ph * (gin->W + 2 * gin->pw) < 80) return false;
+  // and the left edge; on the right the kernel clamps to the row's last voxel
+  if (gin->ph < 2 || gin->pw < 2) return false;
   return (long)gout->B * gout->H * ((gout->W + 31) / 32) >= 1024;       // below: the split-K / generic kernels
 }
 
@@ -163,12 +168,17 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_dgrad_kernel(S2Args p) {
 
   // stage gz rows y'-1, y', y'+1, coarse columns x0 - 1 + v, v = 0..39 (the halo of 1 covers rows and the left edge)
   const int sv = lane >> 3, sq = lane & 7;
-  const float* src0 = p.x + ((((long)b * p.gin.Hp + (yc - 1 + p.gin.ph)) * p.gin.Wp + (x0 - 1 + p.gin.pw)) * 32) + lane * 4;
+  // (voxels past the row's padded end — the last segment — are clamped to its last voxel, as in the forward kernel)
+  const float* src0 = p.x + ((((long)b * p.gin.Hp + (yc - 1 + p.gin.ph)) * p.gin.Wp + (x0 - 1 + p.gin.pw)) * 32) + sq * 4;
+  const int vlim = p.gin.Wp - 1 - (x0 - 1 + p.gin.pw);
+  int voff[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) voff[i] = min(8 * i + sv, vlim) * 32;
   f32x4 r[3][5];
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) r[dy][i] = *reinterpret_cast<const f32x4*>(src0 + (long)dy * p.gin.Wp * 32 + i * 256);
+    for (int i = 0; i < 5; ++i) r[dy][i] = *reinterpret_cast<const f32x4*>(src0 + (long)dy * p.gin.Wp * 32 + voff[i]);
   const float* wb = p.wp + lane * 4;
   f32x4 bw[2][4];
   s2_loadw(bw[0], wb);
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_dgrad_kernel(S2Args p) {
 bool conv32_s2_dgrad_applicable(const as_pcl* ggz, const as_pcl* ggx) {
   if (ggz->D != 1 || ggx->D != 1 || ggz->B != ggx->B || ggz->pd != 0) return false;
   if (ggz->H != (ggx->H - 1) / 2 + 1 || ggz->W != (ggx->W - 1) / 2 + 1) return false;
-  if (ggz->ph < 1 || ggz->pw < 1 || (long)ggz->ph * (ggz->W + 2 * ggz->pw) < 48) return false;
+  if (ggz->ph < 1 || ggz->pw < 1) return false;          // rows y'-1 .. y'+1 and the left edge; the right edge is clamped
   return (long)ggz->B * ggz->H * ((ggz->W + 31) / 32) >= 1024;
 }
 
