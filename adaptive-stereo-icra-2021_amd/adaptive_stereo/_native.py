@@ -114,6 +114,7 @@ _SIGNATURES = {
   "as_conv32_wino_bwd": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
   "as_conv32_s2_enable": (c_int, [c_int]),
+  "as_conv4_s2_enable": (c_int, [c_int]),
   "as_refine_out_ok": (c_int, [_P(Pcl)]),
   "as_refine_out_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_float, c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_conv32_bwd_fused_ok": (c_int, [_P(Pcl), _P(Pcl), _P(ConvShape)]),

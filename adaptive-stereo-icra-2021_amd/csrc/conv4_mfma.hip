@@ -43,16 +43,25 @@ __global__ __launch_bounds__(256) void conv4_fwd_kernel(Conv4Args p) {
     float b0[NT > 0 ? NT : 1], b1[NT > 0 ? NT : 1];
 #pragma unroll
     for (int tp = 0; tp < NT; ++tp) {
+#ifdef C4F_EXP_NOLOAD                                   // diagnostic builds (tests/tools/exp_step.sh): results are wrong
+      q[tp] = (f32x4){(float)p.tap_off[tp], (float)lane, 1.f, 2.f};
+      b0[tp] = (float)(tp + lane); b1[tp] = (float)(tp - lane);
+#else
       q[tp] = *reinterpret_cast<const f32x4*>(xa + (long)p.tap_off[tp] * 4);
       b0[tp] = p.wp[(tp * 2 + 0) * 64 + lane];
       b1[tp] = p.wp[(tp * 2 + 1) * 64 + lane];
+#endif
     }
 #pragma unroll
     for (int tp = 0; tp < NT; ++tp) {
       const float a0 = h ? q[tp].y : q[tp].x;
       const float a1 = h ? q[tp].w : q[tp].z;
+#ifdef C4F_EXP_NOMFMA
+      acc[0] += a0 * b0[tp]; acc[1] += a1 * b1[tp];
+#else
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[tp], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[tp], acc, 0, 0, 0);
+#endif
     }
   } else {
     for (int tp = 0; tp < p.ntaps; ++tp) {
@@ -68,6 +77,104 @@ __global__ __launch_bounds__(256) void conv4_fwd_kernel(Conv4Args p) {
   TileStats ts;
   conv_epilogue(acc, p.ep, out_vox, valid, min(128, p.M - (int)blockIdx.x * 128), red, bmean, &ts);
   stats_write(p.ep, blockIdx.x, ts);
+}
+
+
+// ---- 5x5 stride-2 instance on staged rows (the feature towers' first layer, downsample[0]: stereo_net.py:61-69) ----------
+// conv4_fwd_kernel<25> gives a wave ONE tile: 25 sixteen-byte gathers per lane (stride 32 B: half of every line fetched twice
+// over), 50 weight loads, 50 MFMAs, 16 stores, exit.  Diagnostic builds inside a step (tests/tools/exp_step.sh, round 4): 93 us as
+// built, 71 without the loads, 56 without the MFMAs, 25 without both — loads and matrix work do not overlap (25 + 45 + 31 = 101).
+// Here a wave is persistent (its 50 weight fragments stay in registers) and fetches ROWS: per tile and ky the 72 pixels
+// 2 x0 - 2 .. 2 x0 + 69 of input row 2y + ky - 2 as one full and one eight-lane 16-byte load (10 instead of 25 load instructions),
+// written into the wave's private LDS split by column parity with the channel order (c0, c2, c1, c3): tap kx reads entry
+// li + kx/2 of half kx & 1 as ONE ds_read_b64 = (c_h, c_2+h), the two k-slices of its two MFMAs.  The next tile's rows are
+// requested before this tile's matrix phase (the registers are free once the rows sit in LDS).  No barrier; taps and channels
+// in conv4_fwd_kernel<25>'s order: bit-identical outputs.  Pixels past a row's padded end are clamped (they feed unstored outputs).
+typedef float c4_f32x2 __attribute__((ext_vector_type(2)));
+#define C4S_HALF (36 * 16)                    // bytes of one parity half of a staged row: entries 0..35
+#define C4S_ROW (2 * C4S_HALF)                // 1,152
+#define C4S_WAVE (5 * C4S_ROW)                // 5,760 B per wave
+
+struct Conv4S2Args {
+  const float* x4;
+  const float* wp;        // [tap][j][h][co] (conv4_pack_kernel)
+  const float* bias;
+  float* z;
+  PclDev gin, gout;
+  int nseg, ntiles;
+};
+
+__global__ __launch_bounds__(256, 2) void conv4_s2_fwd_kernel(Conv4S2Args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * C4S_WAVE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, li = lane & 31;
+  char* buf = smem + wave * C4S_WAVE;
+  float b0[25], b1[25];
+#pragma unroll
+  for (int tp = 0; tp < 25; ++tp) { b0[tp] = p.wp[(tp * 2 + 0) * 64 + lane]; b1[tp] = p.wp[(tp * 2 + 1) * 64 + lane]; }
+  const float bias_v = p.bias ? p.bias[li] : 0.f;
+  // staging: load A brings pixel `lane`, load B pixel 64 + (lane & 7); LDS slot: half v & 1, entry v >> 1
+  const int va = lane, vb = 64 + (lane & 7);
+  char* dst_a = buf + (va & 1) * C4S_HALF + (va >> 1) * 16;
+  char* dst_b = buf + (vb & 1) * C4S_HALF + (vb >> 1) * 16;
+  const char* rd = buf + li * 16 + 8 * h;                  // + row * C4S_ROW + (kx & 1) * C4S_HALF + (kx >> 1) * 16
+  const int nwaves = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  f32x4 ra[5], rb[5];
+  auto request = [&](int t) {
+    const int seg = t % p.nseg, row = t / p.nseg;
+    const int y = row % p.gout.H, b = row / p.gout.H;
+    const int c0 = 2 * seg * 32 - 2 + p.gin.pw;           // first staged column (padded coordinates)
+    const int vlim = p.gin.Wp - 1 - c0;
+    const float* src = p.x4 + (((long)b * p.gin.Hp + (2 * y - 2 + p.gin.ph)) * p.gin.Wp + c0) * 4;
+    const int oa = min(va, vlim) * 4, ob = min(vb, vlim) * 4;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      ra[ky] = *reinterpret_cast<const f32x4*>(src + (long)ky * p.gin.Wp * 4 + oa);
+      rb[ky] = *reinterpret_cast<const f32x4*>(src + (long)ky * p.gin.Wp * 4 + ob);
+    }
+  };
+  if (tile < p.ntiles) request(tile);
+  for (; tile < p.ntiles; tile += nwaves) {
+    const int seg = tile % p.nseg, row = tile / p.nseg;
+    const int y = row % p.gout.H, b = row / p.gout.H;
+    const int x0 = seg * 32;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      *reinterpret_cast<f32x4*>(dst_a + ky * C4S_ROW) = (f32x4){ra[ky].x, ra[ky].z, ra[ky].y, ra[ky].w};
+      *reinterpret_cast<f32x4*>(dst_b + ky * C4S_ROW) = (f32x4){rb[ky].x, rb[ky].z, rb[ky].y, rb[ky].w};
+    }
+    if (tile + nwaves < p.ntiles) request(tile + nwaves);  // in flight under this tile's matrix phase and stores
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias_v;
+#pragma unroll
+    for (int tp = 0; tp < 25; ++tp) {
+      const int ky = tp / 5, kx = tp % 5;
+      const c4_f32x2 a = *reinterpret_cast<const c4_f32x2*>(rd + ky * C4S_ROW + (kx & 1) * C4S_HALF + (kx >> 1) * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[tp], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1[tp], acc, 0, 0, 0);
+    }
+    float* outp = p.z + ((((long)b * p.gout.Hp + (y + p.gout.ph)) * p.gout.Wp + (x0 + p.gout.pw)) * 32) + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int xo = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (x0 + xo < p.gout.W) outp[xo * 32] = acc[r];
+    }
+  }
+}
+
+static bool conv4_s2_applicable(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
+  if (s->kh != 5 || s->kw != 5 || s->stride != 2 || s->dil != 1 || s->pad_h != 2 || s->pad_w != 2) return false;
+  if (gin->ph < 2 || gin->pw < 2) return false;            // rows 2y-2 .. 2y+2 and the left edge; the right edge is clamped
+  return (long)gout->B * gout->H * ((gout->W + 31) / 32) >= 4096;
+}
+
+static bool g_conv4_s2 = true;
+extern "C" int as_conv4_s2_enable(int on) {                // 0 / 1; anything else only reads.  Returns the previous setting.
+  const int prev = g_conv4_s2 ? 1 : 0;
+  if (on == 0 || on == 1) g_conv4_s2 = on == 1;
+  return prev;
 }
 
 // ---- 3x3 stride-1 instance over row segments (the refinement's 4->32 input layer, full resolution) -------------
@@ -269,7 +376,7 @@ struct Wgrad4Args {
 };
 
 template <int NB>
-#define W4_SEG_STEPS 64                       // multiple of the 8-step load groups
+#define W4_SEG_STEPS 32                       // multiple of the 8-step load groups
 __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [3][NB*16][64] + [4][32]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -308,11 +415,19 @@ __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
         const int xc = 2 * (s0 + u) + h;
         const bool ok = xc < W;
         const int xcl = ok ? xc : W - 1;
+#ifdef C4W_EXP_NOLOAD                                   // diagnostic builds (tests/tools/exp_step.sh): results are wrong
+        const float g0 = (float)(xcl + lane);
+#else
         const float g0 = gr[xcl * 32];
+#endif
         bv[u] = ok ? g0 : 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
+#ifdef C4W_EXP_NOLOAD
+          const float a0 = (float)(xcl * p.stride * 4 + koff[nb]);
+#else
           const float a0 = xr[xcl * p.stride * 4 + koff[nb]];
+#endif
           av[u][nb] = kok[nb] ? a0 : 0.f;
         }
       }
@@ -322,7 +437,11 @@ __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
         bsum += bv[u];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
+#ifdef C4W_EXP_NOMFMA
+          acc[nb][0] += av[u][nb] * bv[u];
+#else
           acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][nb], bv[u], acc[nb], 0, 0, 0);
+#endif
       }
     }
   }
@@ -754,6 +873,14 @@ extern "C" int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* pac
     AS_CHECK_LAUNCH("as_conv4_fwd(rows)");
     return AS_OK;
   }
+  if (g_conv4_s2 && epilogue == 0 && !stat_mean && conv4_s2_applicable(gin, gout, s)) {
+    Conv4S2Args q;
+    q.x4 = x4; q.wp = packed_w; q.bias = bias; q.z = z; q.gin = as_make_dev(gin); q.gout = as_make_dev(gout);
+    q.nseg = (gout->W + 31) / 32; q.ntiles = gout->B * gout->H * q.nseg;
+    hipLaunchKernelGGL(conv4_s2_fwd_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, q);   // two workgroups per CU (180 registers; three with 168 and two spilled: 78 us against 75)
+    AS_CHECK_LAUNCH("as_conv4_fwd(5x5 stride 2, staged rows)");
+    return AS_OK;
+  }
   Conv4Args a;
   a.x4 = x4; a.wp = packed_w;
   a.ep.bias = bias; a.ep.z = z; a.ep.ep_scale = ep_scale; a.ep.ep_shift = ep_shift; a.ep.residual = nullptr;
@@ -770,16 +897,20 @@ extern "C" int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* pac
   return AS_OK;
 }
 
-// A wave's unit of work is one 128-pixel segment of one output row (64 steps of a pixel pair); a workgroup takes
-// `rpc` consecutive units (at least one per wave).  Whole rows per wave left three quarters of the chip idle on a
-// single image: 188 rows = 188 waves for 1024 SIMDs, each with a 311-step dependent chain.
+// A wave's unit of work is one 64-pixel segment of one output row (32 steps of a pixel pair); a workgroup takes
+// `rpc` consecutive units, a multiple of four (its waves take every fourth).  Whole rows per wave left three quarters of the
+// chip idle on a single image: 188 rows = 188 waves for 1024 SIMDs, each with a 311-step dependent chain.  The launch is ONE
+// round of resident workgroups: with 64-step units and 1024 wanted chunks the 5x5 layer at the bench workload was 940
+// workgroups of two units per wave on 768 slots (157 registers: three workgroups per CU) — a second round for a fifth of the
+// work: 82 us for the matrix instructions alone where 49 are nominal (tests/tools/exp_step.sh, -DC4W_EXP_NOLOAD).
 static int plan4_segments(const as_pcl* gout) { return (((gout->W + 1) >> 1) + W4_SEG_STEPS - 1) / W4_SEG_STEPS; }
 static void plan4(const as_pcl* gout, const as_conv_shape* s, int* nb, int* rpc, int* nchunks) {
   const int T = s->kh * s->kw;
   *nb = (4 * T + 31) / 32;
   const int units = gout->B * gout->H * plan4_segments(gout);
-  int want = 1024;
-  int r = (units + want - 1) / want;
+  const int slots = *nb >= 3 ? 768 : 1024;                 // resident workgroups (accumulator blocks decide the register count)
+  int r = (units + slots - 1) / slots;
+  r = (r + 3) / 4 * 4;
   if (r < 4) r = 4;
   *rpc = r;
   *nchunks = (units + r - 1) / r;

@@ -204,6 +204,10 @@ int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, cons
  * the generic direct-load kernels (same bits: the parity tests compare them).  Returns the previous setting; any other argument
  * only queries */
 int as_conv32_s2_enable(int on);
+/* the same switch for the towers' FIRST layer, nn.Conv2d(3, 32, 5, stride=2, padding=2) (stereo_net.py:61-69): as_conv4_fwd runs
+ * it on conv4_s2_fwd_kernel (persistent waves, rows staged through wave-private LDS) when the epilogue is plain and the map fills
+ * the chip; bit-identical to conv4_fwd_kernel<25> */
+int as_conv4_s2_enable(int on);
 
 /* ---- the refinement's output layer with the last BasicBlock's activation on the way in (csrc/refine_out.hip;
  * stereo_net.py:44-51, 102, 116-121):  out = relu?(conv2d_out(a) + bias + add_src)  where

@@ -348,6 +348,40 @@ def test_sumsq_and_adam_step():
 
 
 # ----------------------------------------------------------------------------- thin-input conv (Cin <= 4)
+@pytest.mark.parametrize("B,H,W", [(8, 375, 1242), (2, 540, 960), (3, 301, 515)])
+def test_first_head_layer_on_staged_rows_equals_the_one_tile_kernel(B, H, W):
+  """downsample[0] = Conv2d(3, 32, 5, stride=2, padding=2) (stereo_net.py:61-69) on conv4_s2_fwd_kernel (persistent waves,
+  rows staged through wave-private LDS) against conv4_fwd_kernel<25> (as_conv4_s2_enable(0)): bit for bit — taps and channels
+  in the same order —, nothing written into the output's halo, and against torch on the CPU.  The bench workload (8 images of
+  375 x 1242), SceneFlow size, odd extents with a ragged last segment (W_out = 258 = 8 x 32 + 2)."""
+  shape = ConvShape(1, 5, 5, 0, 2, 2, 1, 2)
+  Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+  g4, gout = Pcl(B, 1, H, W, 0, 2, 2), Pcl(B, 1, Ho, Wo, 0, 2, 2)
+  lib = nat.load()
+  x = rnd(B, 3, H, W, seed=1); w = rnd(32, 3, 5, 5, seed=2, scale=0.115); b = rnd(32, seed=3, scale=0.1)
+  x4 = torch.zeros(lib.as_pcl4_numel(g4), device=DEV)
+  nat.call("as_pack_in4", None, nat.ptr(x.to(DEV)), 3, nat.ptr(x4), g4, nat.stream())
+  wd, bd = w.to(DEV), b.to(DEV)
+  wp = torch.empty(25 * 128, device=DEV)
+  nat.call("as_conv4_pack_weights", nat.ptr(wd), 3, nat.ptr(wp), shape, nat.stream())
+  res = {}
+  prev = lib.as_conv4_s2_enable(2)
+  try:
+    for on in (0, 1):
+      lib.as_conv4_s2_enable(on)
+      z = ops.pcl_zeros(gout, DEV)
+      nat.call("as_conv4_fwd", nat.ptr(x4), g4, nat.ptr(wp), nat.ptr(bd), nat.ptr(z), gout, shape, 0, None, None, 0.2,
+               None, None, None, nat.stream())
+      torch.cuda.synchronize()
+      res[on] = z
+  finally:
+    lib.as_conv4_s2_enable(prev)
+  assert bool(torch.equal(res[0], res[1])), "staged rows differ from the one-tile kernel in %d elements" % int((res[0] != res[1]).sum())
+  full = ops.pcl_view(res[1], gout).clone(); ops.pcl_interior(full, gout).zero_()
+  assert float(full.abs().max()) == 0.0, "the staged-row kernel wrote into the halo"
+  close(ops.pcl_to_ncdhw(res[1], gout)[:, :, 0], F.conv2d(x, w, b, stride=2, padding=2), 2e-5, 1e-5, "first head layer")
+
+
 @pytest.mark.parametrize("B,H,W,Cin,k,stride,pad", [(1, 9, 13, 4, 3, 1, 1), (2, 37, 53, 4, 3, 1, 1),
                                                     (2, 20, 131, 4, 3, 1, 1), (1, 7, 32, 4, 3, 1, 1),
                                                     (1, 21, 30, 3, 5, 2, 2), (2, 75, 131, 3, 5, 2, 2)])
