@@ -214,6 +214,17 @@ def set_refine_out(enabled):
   return prev
 
 
+def set_head_staged(enabled):
+  """The strided head of the feature towers on the staged-row kernels (csrc/conv32_s2.hip, conv4_s2_* in csrc/conv4_mfma.hip) or
+  on the generic gather kernels: the library's two switches together (the parity tests compare both routes kernel by kernel;
+  tests/tools/ab_switch.py times them); returns the previous setting."""
+  lib = nat.load()
+  prev = lib.as_conv32_s2_enable(2) == 1 and lib.as_conv4_s2_enable(2) == 1
+  lib.as_conv32_s2_enable(1 if enabled else 0)
+  lib.as_conv4_s2_enable(1 if enabled else 0)
+  return prev
+
+
 def set_fwd_act(enabled):
   global _FWD_ACT
   prev, _FWD_ACT = _FWD_ACT, bool(enabled)

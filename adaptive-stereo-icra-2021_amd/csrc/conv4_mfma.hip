@@ -474,6 +474,158 @@ __global__ __launch_bounds__(256) void conv4_wgrad_kernel(Wgrad4Args p) {
   }
 }
 
+
+// ---- weight gradient of the 5x5 stride-2 first layer with the input rows staged in LDS -----------------------------------
+// conv4_wgrad_kernel<4> fetches every A operand with a gather of its own: four dword loads per lane and pixel pair, 128 load
+// instructions per 32-step unit for data that 25 taps share; with three waves per SIMD their latency is not covered — diagnostic
+// builds inside a step (tests/tools/exp_step.sh): 105 us as built, 76 with the operands made up in registers.  Here a wave copies
+// the five input rows of its unit — 132 pixels of 16 bytes each, columns 4 s0 - 2 .. 4 s0 + 129 of rows 2y - 2 .. 2y + 2 — into a
+// private LDS image with 11 coalesced loads (the NEXT unit's rows are requested as soon as this unit's sit in LDS) and reads the
+// A operands with ds_read_b32 at a per-lane constant + an immediate; G stays a coalesced 256-byte load per step, one group of
+// eight steps ahead.  Same units, same slabs, same reduction as conv4_wgrad_kernel<4>; the sums over a unit run in the same
+// order, so the slabs are bit-identical to it.
+#define C4W_ROW_PX 132
+#define C4W_WAVE_BYTES (5 * C4W_ROW_PX * 16)          // 10,560
+
+__global__ __launch_bounds__(256, 2) void conv4_s2_wgrad_kernel(Wgrad4Args p) {
+  constexpr int NB = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // rows: [4 waves][5][132][4]; later [3][NB*16][64] + [4][32]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, li = lane & 31;
+  const int chunk = blockIdx.x;
+  const int W = p.gout.W, H = p.gout.H;
+  const int r0 = chunk * p.rows_per_chunk;
+  const int r1 = min(p.rows, r0 + p.rows_per_chunk);
+  char* rows = reinterpret_cast<char*>(lds) + wave * C4W_WAVE_BYTES;
+
+  f32x16 acc[NB];
+  unsigned aoff[NB];     // byte offset of this lane's (tap, channel) of step 0 in the staged image: ((ky*132 + kx)*4 + c)*4 + 32 h
+  bool kok[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const int k = nb * 32 + li;
+    kok[nb] = k < 100;
+    const int t = kok[nb] ? (k >> 2) : 0;
+    aoff[nb] = (unsigned)((((t / 5) * C4W_ROW_PX + (t % 5)) * 4 + (k & 3)) * 4 + 32 * h);
+  }
+  float bsum = 0.f;
+  const int nsteps = (W + 1) >> 1;
+  // staging jobs of a lane: pixels lane and 64 + lane of each of the five rows; pixels 128..131 of row (lane >> 2) % 5 in one
+  // more load (lanes 20..63 repeat rows 0..: same data, same destination)
+  f32x4 ra[5], rb[5], rc;
+  const int cky = (lane >> 2) % 5, cpx = 128 + (lane & 3);
+  auto request = [&](int unit) {
+    const int row = unit / p.nseg, seg = unit - row * p.nseg;
+    const int y = row % H, b = row / H;
+    const int c0 = 4 * seg * W4_SEG_STEPS - 2 + p.gin.pw;                 // first staged column (padded coordinates)
+    const int vlim = p.gin.Wp - 1 - c0;                                   // (past the row's padded end: clamped, feeds masked steps)
+    const float* src = p.x4 + (((long)b * p.gin.Hp + (2 * y - 2 + p.gin.ph)) * p.gin.Wp + c0) * 4;
+    const int oa = min(lane, vlim) * 4, ob = min(64 + lane, vlim) * 4, oc = min(cpx, vlim) * 4;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      const float* s = src + (long)ky * p.gin.Wp * 4;
+      ra[ky] = *reinterpret_cast<const f32x4*>(s + oa);
+      rb[ky] = *reinterpret_cast<const f32x4*>(s + ob);
+    }
+    rc = *reinterpret_cast<const f32x4*>(src + (long)cky * p.gin.Wp * 4 + oc);
+  };
+  // G of a whole unit (32 steps) in registers, the next unit's requested with its rows: everything a unit needs was asked for
+  // a unit (128 MFMAs) earlier.  (With three waves per SIMD and G one group of eight steps ahead the kernel took 103-120 us —
+  // 120 when the next rows were requested in front of the G loads: loads retire in order, every unit then began with the rows'
+  // round trip — against 105 for the gather kernel and 76 for its matrix instructions alone.)
+  float g0[W4_SEG_STEPS], g1[W4_SEG_STEPS];
+  auto request_g = [&](float (&g)[W4_SEG_STEPS], int unit) {
+    const int row = unit / p.nseg, seg = unit - row * p.nseg;
+    const int y = row % H, b = row / H;
+    const float* gr = p.gz + p.gout.vox(b, 0, y, 0) * 32 + li;
+#pragma unroll
+    for (int u = 0; u < W4_SEG_STEPS; ++u) {
+      const int s = seg * W4_SEG_STEPS + u, xc = 2 * s + h;
+      g[u] = gr[((s < nsteps && xc < W) ? xc : W - 1) * 32];
+    }
+  };
+  auto multiply = [&](const float (&g)[W4_SEG_STEPS], int unit) {
+    const int seg = unit % p.nseg;
+    // the A operands of step sl + 1 are read from LDS before the MFMAs of step sl (hipcc otherwise waits for every ds_read
+    // right in front of the MFMA that uses it)
+    float an[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) an[nb] = *reinterpret_cast<const float*>(rows + aoff[nb]);
+#pragma unroll
+    for (int sl = 0; sl < W4_SEG_STEPS; ++sl) {           // step sl: pixels 2 sl + h, staged column 4 sl + 2 h + kx
+      const int s = seg * W4_SEG_STEPS + sl;
+      const float gv = (s < nsteps && 2 * s + h < W) ? g[sl] : 0.f;
+      float ac[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) ac[nb] = kok[nb] ? an[nb] : 0.f;
+      if (sl + 1 < W4_SEG_STEPS) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) an[nb] = *reinterpret_cast<const float*>(rows + aoff[nb] + 64 * (sl + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bsum += gv;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[nb], gv, acc[nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      *reinterpret_cast<f32x4*>(rows + (ky * C4W_ROW_PX + lane) * 16) = ra[ky];
+      *reinterpret_cast<f32x4*>(rows + (ky * C4W_ROW_PX + 64 + lane) * 16) = rb[ky];
+    }
+    *reinterpret_cast<f32x4*>(rows + (cky * C4W_ROW_PX + cpx) * 16) = rc;
+  };
+  int unit = r0 + wave;
+  if (unit < r1) { request_g(g0, unit); request(unit); }
+  while (unit < r1) {
+    stage();
+    if (unit + 4 < r1) { request_g(g1, unit + 4); request(unit + 4); }
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(g0, unit);
+    __builtin_amdgcn_sched_barrier(0);
+    unit += 4;
+    if (unit >= r1) break;
+    stage();
+    if (unit + 4 < r1) { request_g(g0, unit + 4); request(unit + 4); }
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(g1, unit);
+    __builtin_amdgcn_sched_barrier(0);
+    unit += 4;
+  }
+  __syncthreads();                                        // every wave is done with its rows: the slabs may overwrite them
+  float* slab = lds;
+  float* dbs = lds + 3 * NB * 16 * 64;
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (h == 0) dbs[wave * 32 + li] = bsum;
+  if (wave > 0) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) slab[((wave - 1) * NB * 16 + nb * 16 + r) * 64 + lane] = acc[nb][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float* out = p.partial + ((long)chunk * NB + nb) * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[nb][r];
+        v += slab[(0 * NB * 16 + nb * 16 + r) * 64 + lane];
+        v += slab[(1 * NB * 16 + nb * 16 + r) * 64 + lane];
+        v += slab[(2 * NB * 16 + nb * 16 + r) * 64 + lane];
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        out[i * 32 + li] = v;
+      }
+    }
+    if (h == 0) p.partial_db[chunk * 32 + li] = dbs[li] + dbs[32 + li] + dbs[64 + li] + dbs[96 + li];
+  }
+}
+
 // ---- weight gradient, 3x3 stride-1 instance, on the vector ALUs ---------------------------------------------
 // With K = 36 useful rows out of 64 and two pixels per v_mfma_f32_32x32x2_f32 the matrix core needs 64 cycles
 // per pixel here; the plain FMA formulation needs 1152 FMAs per pixel = 18 wave-cycles per pixel-SIMD and no
@@ -904,11 +1056,15 @@ extern "C" int as_conv4_fwd(const float* x4, const as_pcl* gin, const float* pac
 // workgroups of two units per wave on 768 slots (157 registers: three workgroups per CU) — a second round for a fifth of the
 // work: 82 us for the matrix instructions alone where 49 are nominal (tests/tools/exp_step.sh, -DC4W_EXP_NOLOAD).
 static int plan4_segments(const as_pcl* gout) { return (((gout->W + 1) >> 1) + W4_SEG_STEPS - 1) / W4_SEG_STEPS; }
-static void plan4(const as_pcl* gout, const as_conv_shape* s, int* nb, int* rpc, int* nchunks) {
+static bool plan4_staged_shape(const as_conv_shape* s) {     // the 5x5 stride-2 first layer (conv4_s2_wgrad_kernel)
+  return s->kh == 5 && s->kw == 5 && s->stride == 2 && s->dil == 1 && s->pad_h == 2 && s->pad_w == 2;
+}
+static void plan4(const as_pcl* gout, const as_conv_shape* s, bool staged, int* nb, int* rpc, int* nchunks) {
   const int T = s->kh * s->kw;
   *nb = (4 * T + 31) / 32;
   const int units = gout->B * gout->H * plan4_segments(gout);
-  const int slots = *nb >= 3 ? 768 : 1024;                 // resident workgroups (accumulator blocks decide the register count)
+  // resident workgroups (the register count decides): the staged-row kernel runs two per CU
+  const int slots = staged ? 512 : (*nb >= 3 ? 768 : 1024);
   int r = (units + slots - 1) / slots;
   r = (r + 3) / 4 * 4;
   if (r < 4) r = 4;
@@ -919,8 +1075,13 @@ static void plan4(const as_pcl* gout, const as_conv_shape* s, int* nb, int* rpc,
 extern "C" int64_t as_conv4_wgrad_workspace(const as_pcl* gout, const as_conv_shape* s) {
   if (!gout || !s || !as_pcl_ok(gout)) return -1;
   int nb, rpc, nchunks;
-  plan4(gout, s, &nb, &rpc, &nchunks);
+  plan4(gout, s, false, &nb, &rpc, &nchunks);               // (the larger of the two plans: as_conv4_s2_enable may change in between)
   int64_t need = (int64_t)nchunks * nb * 1024 + (int64_t)nchunks * 32;
+  if (plan4_staged_shape(s)) {
+    plan4(gout, s, true, &nb, &rpc, &nchunks);
+    const int64_t n2 = (int64_t)nchunks * nb * 1024 + (int64_t)nchunks * 32;
+    if (n2 > need) need = n2;
+  }
   const int64_t rows_need = (int64_t)conv4_wgrad_rows_grid(gout) * (2048 + 32);     // the 3x3 stride-1 instance
   if (s->kh == 3 && s->kw == 3 && s->stride == 1 && rows_need > need) need = rows_need;
   return need;
@@ -1020,7 +1181,8 @@ extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* g
     return conv4_wgrad_rows_launch(x4, gin, gz, gout, Cin, dW, db, accumulate, workspace, false, nullptr, nullptr, nullptr,
                                    nullptr, nullptr, 0.f, nullptr, stream);
   int nb, rpc, nchunks;
-  plan4(gout, s, &nb, &rpc, &nchunks);
+  const bool staged = g_conv4_s2 && plan4_staged_shape(s) && gin->ph >= 2 && gin->pw >= 2;
+  plan4(gout, s, staged, &nb, &rpc, &nchunks);
   AS_CHECK_ARG(nb >= 1 && nb <= 4, "as_conv4_wgrad: kernel too large");
   Wgrad4Args a;
   a.x4 = x4; a.gz = gz; a.partial = workspace; a.partial_db = workspace + (int64_t)nchunks * nb * 1024;
@@ -1029,6 +1191,11 @@ extern "C" int as_conv4_wgrad(const float* x4, const as_pcl* gin, const float* g
   a.rows = gout->B * gout->H * a.nseg; a.rows_per_chunk = rpc; a.stride = s->stride;
   a.ntaps = fill_taps4(gin, s, a.tap_off);
   hipStream_t st = (hipStream_t)stream;
+  if (staged) {
+    // (the 5x5 stride-2 first layer of the feature towers: input rows staged in LDS)
+    const size_t lds = (size_t)(3 * 4 * 16 * 64 + 4 * 32) * sizeof(float);      // >= 4 * C4W_WAVE_BYTES
+    hipLaunchKernelGGL(conv4_s2_wgrad_kernel, dim3(nchunks), dim3(256), lds, st, a);
+  } else
   switch (nb) {
     case 1: launch4<1>(a, nchunks, st); break;
     case 2: launch4<2>(a, nchunks, st); break;

@@ -351,9 +351,11 @@ def test_sumsq_and_adam_step():
 @pytest.mark.parametrize("B,H,W", [(8, 375, 1242), (2, 540, 960), (3, 301, 515)])
 def test_first_head_layer_on_staged_rows_equals_the_one_tile_kernel(B, H, W):
   """downsample[0] = Conv2d(3, 32, 5, stride=2, padding=2) (stereo_net.py:61-69) on conv4_s2_fwd_kernel (persistent waves,
-  rows staged through wave-private LDS) against conv4_fwd_kernel<25> (as_conv4_s2_enable(0)): bit for bit — taps and channels
-  in the same order —, nothing written into the output's halo, and against torch on the CPU.  The bench workload (8 images of
-  375 x 1242), SceneFlow size, odd extents with a ragged last segment (W_out = 258 = 8 x 32 + 2)."""
+  rows staged through wave-private LDS) and its weight gradient on conv4_s2_wgrad_kernel (input rows staged in LDS) against
+  conv4_fwd_kernel<25> / conv4_wgrad_kernel<4> (as_conv4_s2_enable(0)): the forward bit for bit — taps and channels in the same
+  order —, nothing written into the output's halo; the weight gradient (the same products in differently cut chunks) to 2e-5 of
+  its largest entry; everything against torch on the CPU.  The bench workload (8 images of 375 x 1242),
+  SceneFlow size, odd extents with a ragged last segment (W_out = 258 = 8 x 32 + 2)."""
   shape = ConvShape(1, 5, 5, 0, 2, 2, 1, 2)
   Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
   g4, gout = Pcl(B, 1, H, W, 0, 2, 2), Pcl(B, 1, Ho, Wo, 0, 2, 2)
@@ -364,6 +366,8 @@ def test_first_head_layer_on_staged_rows_equals_the_one_tile_kernel(B, H, W):
   wd, bd = w.to(DEV), b.to(DEV)
   wp = torch.empty(25 * 128, device=DEV)
   nat.call("as_conv4_pack_weights", nat.ptr(wd), 3, nat.ptr(wp), shape, nat.stream())
+  gz = rnd(B, 32, Ho, Wo, seed=4)
+  gzb = ops.ncdhw_to_pcl(gz.unsqueeze(2).to(DEV), gout)
   res = {}
   prev = lib.as_conv4_s2_enable(2)
   try:
@@ -372,14 +376,26 @@ def test_first_head_layer_on_staged_rows_equals_the_one_tile_kernel(B, H, W):
       z = ops.pcl_zeros(gout, DEV)
       nat.call("as_conv4_fwd", nat.ptr(x4), g4, nat.ptr(wp), nat.ptr(bd), nat.ptr(z), gout, shape, 0, None, None, 0.2,
                None, None, None, nat.stream())
+      ws = torch.empty(lib.as_conv4_wgrad_workspace(gout, shape), device=DEV)
+      dW, db = torch.empty(32, 3, 5, 5, device=DEV), torch.empty(32, device=DEV)
+      nat.call("as_conv4_wgrad", nat.ptr(x4), g4, nat.ptr(gzb), gout, shape, 3, nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.stream())
       torch.cuda.synchronize()
-      res[on] = z
+      res[on] = (z, dW, db)
   finally:
     lib.as_conv4_s2_enable(prev)
-  assert bool(torch.equal(res[0], res[1])), "staged rows differ from the one-tile kernel in %d elements" % int((res[0] != res[1]).sum())
-  full = ops.pcl_view(res[1], gout).clone(); ops.pcl_interior(full, gout).zero_()
+  assert bool(torch.equal(res[0][0], res[1][0])), "staged rows differ from the one-tile kernel in %d elements" % int((res[0][0] != res[1][0]).sum())
+  full = ops.pcl_view(res[1][0], gout).clone(); ops.pcl_interior(full, gout).zero_()
   assert float(full.abs().max()) == 0.0, "the staged-row kernel wrote into the halo"
-  close(ops.pcl_to_ncdhw(res[1], gout)[:, :, 0], F.conv2d(x, w, b, stride=2, padding=2), 2e-5, 1e-5, "first head layer")
+  xr = x.clone(); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+  z_ref = F.conv2d(xr, wr, br, stride=2, padding=2)
+  z_ref.backward(gz)
+  close(ops.pcl_to_ncdhw(res[1][0], gout)[:, :, 0], z_ref, 2e-5, 1e-5, "first head layer")
+  scale = float(wr.grad.abs().max())
+  # (the two weight-gradient kernels cut the launch into different chunks: the same products, summed in different groups)
+  close(res[1][1] / scale, res[0][1] / scale, 2e-5, 0.0, "first head layer: weight gradient, staged rows against the gather kernel")
+  close(res[1][2] / scale, res[0][2] / scale, 2e-5, 0.0, "first head layer: bias gradient, staged rows against the gather kernel")
+  close(res[1][1] / scale, wr.grad / scale, 5e-5, 0.0, "first head layer: weight gradient")
+  close(res[1][2] / scale, br.grad / scale, 5e-5, 0.0, "first head layer: bias gradient")
 
 
 @pytest.mark.parametrize("B,H,W,Cin,k,stride,pad", [(1, 9, 13, 4, 3, 1, 1), (2, 37, 53, 4, 3, 1, 1),

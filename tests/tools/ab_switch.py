@@ -1,5 +1,5 @@
 """Same-box A/B of a route switch of hip_ops (set_winograd, set_defer_reduce, set_tail_bnsums, set_head_proj, set_fwd_act, set_bwd_fused,
-set_agg3d, set_agg_tail): alternates on / off three times each and prints ms/step of the graph-replayed adaptation step.
+set_agg3d, set_agg_tail, set_head_staged, set_refine_out): alternates on / off three times each and prints ms/step of the graph-replayed adaptation step.
 Box-to-box variation is +-2 %; a 1 % effect only shows on one box, interleaved.  (The switches themselves are exercised by the
 parity tests; timing them is this tool's business, not an environment variable's.)
 
