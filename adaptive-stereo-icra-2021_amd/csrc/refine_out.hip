@@ -17,7 +17,16 @@
 #include "as_common.h"
 
 #define RO_COLS 126                      // output columns of a strip (128 staged voxels)
-#define RO_ROWS 32                       // output rows of a strip
+// output rows of a strip, per flavour (two more rows are staged): measured inside a step and the inference pass with 16 / 24 /
+// 32 / 47 rows (tests/tools/exp_step.sh refine_out.hip refine_out "-DRO_ROWS_ACT=.. -DRO_ROWS_PLAIN=.."): with the activation on
+// the way in 160 / 163 / 155 / 183 us, without it (the inference flavour: half the bytes per row, so the launch wants more
+// workgroups) 66 / 75 / 79 / 110 us, and 71 / 62.5 with 8 / 12 rows
+#ifndef RO_ROWS_ACT
+#define RO_ROWS_ACT 32
+#endif
+#ifndef RO_ROWS_PLAIN
+#define RO_ROWS_PLAIN 12
+#endif
 #define RO_PW 132                        // pitch of a projection row in LDS (floats)
 
 struct RefineOutArgs {
@@ -47,7 +56,8 @@ __global__ __launch_bounds__(256) void refine_out_kernel(RefineOutArgs p) {
   const int strip = blk % p.nstrips;
   const int b = blk / p.nstrips;
   const int x0 = seg * RO_COLS;
-  const int ya = strip * RO_ROWS, yb = min(H, ya + RO_ROWS);
+  constexpr int ROWS = ACT ? RO_ROWS_ACT : RO_ROWS_PLAIN;
+  const int ya = strip * ROWS, yb = min(H, ya + ROWS);
 
   // B operand: w[ci][tap] for ci = 16h + 4q + e, column = tap li (columns 9..31 are zero)
   float Bw[16];
@@ -171,7 +181,7 @@ extern "C" int as_refine_out_fwd(const float* x, const float* skip, const float*
   RefineOutArgs a;
   a.x = x; a.skip = skip; a.scale = scale; a.shift = shift; a.a_out = a_out; a.w = w; a.bias = bias; a.add_src = add_src;
   a.out = out; a.g = as_make_dev(g); a.relu = relu; a.slope = slope;
-  a.nseg = as_div_up(g->W, RO_COLS); a.nstrips = as_div_up(g->H, RO_ROWS);
+  a.nseg = as_div_up(g->W, RO_COLS); a.nstrips = as_div_up(g->H, scale ? RO_ROWS_ACT : RO_ROWS_PLAIN);
   const int grid = g->B * a.nseg * a.nstrips;
   if (scale) hipLaunchKernelGGL(refine_out_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(refine_out_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
