@@ -26,7 +26,9 @@
 #define TR_STAGE_VOX (3 * TR_COLS)          // 102 voxels
 #define TR_OP_FLOATS (TR_STAGE_VOX * 32)    // 3264 floats
 #define TR_JOBS (TR_STAGE_VOX * 8)          // 816 sixteen-byte chunks
+#ifndef TR_GPER_MAX
 #define TR_GPER_MAX 128                 // 2 groups x 128 workgroups = one per CU (the backward kernel holds 450 registers: no second workgroup fits a CU; 144 per group ran 50 % slower)
+#endif
 
 struct TrunkGeom {
   PclDev g;
