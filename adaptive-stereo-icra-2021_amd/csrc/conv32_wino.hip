@@ -37,6 +37,12 @@
 #include "conv_epilogue.h"
 #include "conv32_wino.h"
 #include "conv32_wino_dev.h"
+#ifndef WN_OLD_T
+#define WN_OLD_T 0
+#endif
+#ifndef WN_OLD_Y
+#define WN_OLD_Y 0
+#endif
 
 #define WN_SEG 64
 #define WN_W 80                          // staged voxels per row: 8 + 64 + 8
@@ -154,6 +160,9 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
   const float sg = wave == 1 ? 1.f : -1.f;
   // epilogue: this wave finishes output (oi, oj) of every tile
   const int oi = wave >> 1, oj = wave & 1;
+  // sign of the second and third term of this wave's output row (wave-uniform: kept in a scalar register)
+  const float sgy = __uint_as_float(__builtin_amdgcn_readfirstlane(oi == 0 ? 0x3f800000u : 0xbf800000u));
+  const f32x4 sgy4 = {sgy, sgy, sgy, sgy};
   const unsigned io_off = (unsigned)((wn_c0<L>(4 * h) + oj * d) * 128 + 4 * li);
   const unsigned io_off2 = io_off + 4096u;                  // rows 8..15 of the accumulator layout: tiles +16 = 32 columns
   float st_c = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;      // BatchNorm moments of this lane's channel: shifted sums
@@ -338,7 +347,11 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
           f32x4 Rt[4];
 #pragma unroll
           for (int m = 0; m < 4; ++m) Rt[m] = xa[m] + sg * xb[m];
-          V[0] = Rt[0] - Rt[2]; V[1] = Rt[1] + Rt[2]; V[2] = Rt[2] - Rt[1]; V[3] = Rt[1] - Rt[3];
+          // (packed differences: -4 % on the forward, -1.5 % on the inference block; the data gradient's instantiation, at the
+          //  256-register limit already, pays for the register pairs with 8-10 spilled registers: +2 %, so not there)
+          V[0] = wn_sub4_if<!BWD>(Rt[0], Rt[2]); V[1] = Rt[1] + Rt[2]; V[2] = wn_sub4_if<!BWD>(Rt[2], Rt[1]);
+          V[3] = wn_sub4_if<!BWD>(Rt[1], Rt[3]);
+          if constexpr (!BWD) wn_before_mfma();
         }
         __builtin_amdgcn_sched_barrier(0);
         if (q + 1 < 4) {                                   // the next chunk's operands: in flight under this chunk's MFMAs
@@ -349,13 +362,29 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
           }
         }
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].x * R[c][4 * q + 0];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].x, R[c][4 * q + 0], acc[c], 0, 0, 0);
+#endif
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].y * R[c][4 * q + 1];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].y, R[c][4 * q + 1], acc[c], 0, 0, 0);
+#endif
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].z * R[c][4 * q + 2];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].z, R[c][4 * q + 2], acc[c], 0, 0, 0);
+#endif
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].w * R[c][4 * q + 3];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].w, R[c][4 * q + 3], acc[c], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       WN_T(2);
@@ -365,14 +394,23 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           f32x4 t0, t1;
-          t0.x = (acc[0][4 * gq + 0] + acc[1][4 * gq + 0]) + acc[2][4 * gq + 0];
-          t0.y = (acc[0][4 * gq + 1] + acc[1][4 * gq + 1]) + acc[2][4 * gq + 1];
-          t0.z = (acc[0][4 * gq + 2] + acc[1][4 * gq + 2]) + acc[2][4 * gq + 2];
-          t0.w = (acc[0][4 * gq + 3] + acc[1][4 * gq + 3]) + acc[2][4 * gq + 3];
-          t1.x = (acc[1][4 * gq + 0] - acc[2][4 * gq + 0]) - acc[3][4 * gq + 0];
-          t1.y = (acc[1][4 * gq + 1] - acc[2][4 * gq + 1]) - acc[3][4 * gq + 1];
-          t1.z = (acc[1][4 * gq + 2] - acc[2][4 * gq + 2]) - acc[3][4 * gq + 2];
-          t1.w = (acc[1][4 * gq + 3] - acc[2][4 * gq + 3]) - acc[3][4 * gq + 3];
+          if constexpr (BWD || WN_OLD_T) {                 // (element by element, as it was: this instantiation has no register to spare)
+            t0.x = (acc[0][4 * gq + 0] + acc[1][4 * gq + 0]) + acc[2][4 * gq + 0];
+            t0.y = (acc[0][4 * gq + 1] + acc[1][4 * gq + 1]) + acc[2][4 * gq + 1];
+            t0.z = (acc[0][4 * gq + 2] + acc[1][4 * gq + 2]) + acc[2][4 * gq + 2];
+            t0.w = (acc[0][4 * gq + 3] + acc[1][4 * gq + 3]) + acc[2][4 * gq + 3];
+            t1.x = (acc[1][4 * gq + 0] - acc[2][4 * gq + 0]) - acc[3][4 * gq + 0];
+            t1.y = (acc[1][4 * gq + 1] - acc[2][4 * gq + 1]) - acc[3][4 * gq + 1];
+            t1.z = (acc[1][4 * gq + 2] - acc[2][4 * gq + 2]) - acc[3][4 * gq + 2];
+            t1.w = (acc[1][4 * gq + 3] - acc[2][4 * gq + 3]) - acc[3][4 * gq + 3];
+          } else {
+            if (gq == 0) wn_after_mfma();                  // (the matrix phase ended at a sched_barrier right above)
+            f32x4 a4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a4[c] = (f32x4){acc[c][4 * gq + 0], acc[c][4 * gq + 1], acc[c][4 * gq + 2], acc[c][4 * gq + 3]};
+            t0 = (a4[0] + a4[1]) + a4[2];
+            t1 = wn_sub4(wn_sub4(a4[1], a4[2]), a4[3]);
+          }
           *reinterpret_cast<f32x4*>(xw + gq * 1024) = t0;
           *reinterpret_cast<f32x4*>(xw + 4096 + gq * 1024) = t1;
         }
@@ -407,7 +445,11 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
           const f32x4 u0 = *reinterpret_cast<const f32x4*>(xr + gq * 1024);
           const f32x4 u1 = *reinterpret_cast<const f32x4*>(xr + 8192 + gq * 1024);
           const f32x4 u2 = *reinterpret_cast<const f32x4*>(xr + 16384 + gq * 1024);
-          const f32x4 yv = oi == 0 ? (u0 + u1) + u2 : (u0 - u1) - u2;
+          // (u0 + u1) + u2 for the first output row, (u0 - u1) - u2 for the second: one fma per term with s = +-1 (the same
+          // roundings as the add / subtract, no select between two results)
+          f32x4 yv;
+          if constexpr (BWD || WN_OLD_Y) yv = oi == 0 ? (u0 + u1) + u2 : (u0 - u1) - u2;
+          else yv = __builtin_elementwise_fma(u2, sgy4, __builtin_elementwise_fma(u1, sgy4, u0));
           Y[4 * gq + 0] = yv.x + bias_v; Y[4 * gq + 1] = yv.y + bias_v; Y[4 * gq + 2] = yv.z + bias_v; Y[4 * gq + 3] = yv.w + bias_v;
         }
       }

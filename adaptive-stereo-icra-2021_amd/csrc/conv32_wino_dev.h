@@ -38,6 +38,54 @@ template <int L> __device__ inline int wn_addr(int v, int chunk) { return wn_pos
 // phase (the swizzle repeats every 32 voxels) — and reaches chunk k through compile-time immediates and scalar base adds.
 // (Recomputing voxel, position, swizzle and offsets per chunk and tile was ~25 integer instructions per chunk: with the
 // vector ALU adding to the matrix time on a SIMD, a fifth of the forward kernel's run time.)
+// a - b on two packed instructions.  hipcc (ROCm 7.2) turns a vector ADD into v_pk_add_f32 but a vector SUBTRACTION — also
+// a + (-b) and fma(b, -1, a) — into one v_sub_f32 per element; the minimal-filtering transforms are signed sums, half of them
+// differences, and every vector instruction of a wave costs the SIMD's matrix pipe ~5 cycles.  The neg
+// modifiers make it the same IEEE operation: bit-identical results.
+// HAZARDS.  hipcc pads its own instructions for the matrix pipe's data hazards; it cannot see into inline asm (the trap of
+// DESIGN 4, "a second trap of the same kind").  Two rules for every use of these helpers, both enforced at the call sites:
+//   * operands that are MFMA RESULTS: wn_after_mfma() first (a 16-pass MFMA's destination may be read by a vector
+//     instruction 18 wait states later at the earliest) — the first version read accumulators straight away: two launches of
+//     the same kernel differed (test_conv32_forward_by_minimal_filtering);
+//   * results that FEED an MFMA: wn_before_mfma() behind the last of them — two wait states are required (measured:
+//     tests/tools/scratch/pk_to_mfma_hazard.hip; 0 and 1 give wrong sums on every run, 2 and more never); the first build
+//     (plain asm, no guard) had the last transform of a tile one instruction in front of the MFMA that read it in the MODE 0
+//     instantiations: two launches of the same kernel differed (test_conv32_forward_by_minimal_filtering[4-97-700-1-False]).
+// The asm statements are volatile: they keep their order relative to those two.  tests/tools/check_async_loads.py checks both
+// rules on the ISA of every kernel (and its self-test builds with -DWN_TEST_NO_HAZARD_GUARD, which must be flagged).
+typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
+#ifdef WN_TEST_NO_HAZARD_GUARD     // (only for tests/tools/check_async_loads.py's self-test: the scan must flag this build)
+__device__ __forceinline__ void wn_after_mfma() {}
+#else
+__device__ __forceinline__ void wn_after_mfma() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+#endif
+#ifdef WN_TEST_NO_HAZARD_GUARD
+__device__ __forceinline__ void wn_before_mfma() {}
+#else
+__device__ __forceinline__ void wn_before_mfma() { asm volatile("s_nop 7" ::: "memory"); }
+#endif
+__device__ __forceinline__ wn_f32x2 wn_sub2(wn_f32x2 a, wn_f32x2 b) {
+  wn_f32x2 r;
+#ifdef WN_TEST_NO_HAZARD_GUARD     // (the first build's form, for the scanner's self-test)
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+#else
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+#endif
+  return r;
+}
+__device__ __forceinline__ f32x4 wn_sub4(f32x4 a, f32x4 b) {
+#ifdef WN_NO_PK_SUB
+  return a - b;
+#else
+  const wn_f32x2 lo = wn_sub2((wn_f32x2){a.x, a.y}, (wn_f32x2){b.x, b.y}), hi = wn_sub2((wn_f32x2){a.z, a.w}, (wn_f32x2){b.z, b.w});
+  return (f32x4){lo.x, lo.y, hi.x, hi.y};
+#endif
+}
+template <bool PACKED> __device__ __forceinline__ f32x4 wn_sub4_if(f32x4 a, f32x4 b) {
+  if constexpr (PACKED) return wn_sub4(a, b);
+  else return a - b;
+}
+
 template <int NT, int L> struct WnPair {
   static constexpr int d = 1 << L, NV = 64 + 2 * d, V0 = 8 - d, RC = 8 * NV;
   static constexpr int K = (2 * RC + NT - 1) / NT;        // chunks per thread and pair

@@ -285,13 +285,29 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
           }
         }
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].x * R[c][4 * q + 0];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].x, R[c][4 * q + 0], acc[c], 0, 0, 0);
+#endif
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].y * R[c][4 * q + 1];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].y, R[c][4 * q + 1], acc[c], 0, 0, 0);
+#endif
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].z * R[c][4 * q + 2];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].z, R[c][4 * q + 2], acc[c], 0, 0, 0);
+#endif
 #pragma unroll
+#ifdef WN_EXP_NOMFMA
+        for (int c = 0; c < 4; ++c) acc[c][0] += V[c].w * R[c][4 * q + 3];   // (diagnostic build: no matrix instructions; results are wrong)
+#else
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c].w, R[c][4 * q + 3], acc[c], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       // T[jc] = (M[r] A)[jc]: A^T = [1 1 1 0; 0 1 -1 -1]

@@ -45,6 +45,7 @@ struct WgradWinoArgs {
 };
 
 typedef __attribute__((address_space(3))) void* ww_lds_t;
+typedef float ww_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ inline void ww_dma_1kb(const float* sbase, unsigned voff, unsigned m0) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
@@ -72,7 +73,7 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
   // this wave's row of the transformed tiles: R = x[ra] + sg * x[rb]  (B^T rows: x0-x2, x1+x2, x2-x1, x3-x1)
   constexpr int ra = RW == 0 ? 0 : (RW == 1 ? 1 : (RW == 2 ? 2 : 3));
   constexpr int rb = RW == 0 ? 2 : (RW == 1 ? 2 : 1);
-  constexpr float sg = RW == 1 ? 1.f : -1.f;
+  [[maybe_unused]] constexpr float sg = RW == 1 ? 1.f : -1.f;
   const int lane_off = li * 4 + h * (L == 0 ? WW_CHUNK : 128);
 
   f32x16 acc[4];
@@ -176,6 +177,7 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
           continue;
         }
 #endif
+#ifdef WW_SCALAR_TRANSFORMS
         float Gr[2];
 #pragma unroll
         for (int jc = 0; jc < 2; ++jc) {
@@ -188,6 +190,37 @@ __device__ __forceinline__ void conv32_wino_wgrad_role(const WgradWinoArgs& p, c
 #pragma unroll
         for (int m = 0; m < 4; ++m) Rt[m] = xa[s & 1][m] + sg * xb[s & 1][m];
         const float V[4] = {Rt[0] - Rt[2], Rt[1] + Rt[2], Rt[2] - Rt[1], Rt[3] - Rt[1]};
+#else
+        // The same signed sums on PACKED instructions (round 4): two values per v_pk_add_f32 with per-half negation and half
+        // selection (a - b = a + (-b): the same IEEE operation, bit-identical sums) — 6 vector instructions per 4 MFMAs instead
+        // of 12.  Inline asm, because hipcc turns every vector difference into one v_sub_f32 per element and splits packed
+        // instructions that it does emit next to MFMAs back into two; asm is NOT padded for the matrix pipe's hazards: two wait
+        // states behind the last of them (wn_before_mfma's rule: conv32_wino_dev.h; tests/tools/check_async_loads.py checks it).
+        const ww_f32x2 u0 = {g0[s & 1][0], g0[s & 1][1]}, u1 = {g1[s & 1][0], g1[s & 1][1]};
+        ww_f32x2 Gr, Gm, Rt01, Rt23, V01, V23;
+        if constexpr (RW == 0) Gr = u0;
+        else if constexpr (RW == 3) Gr = u1;
+        else if constexpr (RW == 1) { asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(Gr) : "v"(u0), "v"(u1)); bsum += Gr.x; bsum += Gr.y; }
+        else asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Gr) : "v"(u0), "v"(u1));
+        // (Gr0 + Gr1, Gr0 - Gr1): src0 = Gr.lo twice, src1 = Gr.hi twice, the high half negated
+        asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(Gm) : "v"(Gr));
+        const ww_f32x2 xa01 = {xa[s & 1][0], xa[s & 1][1]}, xa23 = {xa[s & 1][2], xa[s & 1][3]};
+        const ww_f32x2 xb01 = {xb[s & 1][0], xb[s & 1][1]}, xb23 = {xb[s & 1][2], xb[s & 1][3]};
+        if constexpr (RW == 1) {
+          asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(Rt01) : "v"(xa01), "v"(xb01));
+          asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(Rt23) : "v"(xa23), "v"(xb23));
+        } else {
+          asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Rt01) : "v"(xa01), "v"(xb01));
+          asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(Rt23) : "v"(xa23), "v"(xb23));
+        }
+        // (Rt0 - Rt2, Rt1 + Rt2): src1 = Rt2 twice, negated in the low half;  (Rt2 - Rt1, Rt3 - Rt1): src1 = Rt1 twice, negated
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(V01) : "v"(Rt01), "v"(Rt23));
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(V23) : "v"(Rt23), "v"(Rt01));
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                 // (hipcc otherwise moves an MFMA in between the asm statements: one wait state)
+        const float Gt[4] = {Gr.x, Gm.x, Gm.y, Gr.y};
+        const float V[4] = {V01.x, V01.y, V23.x, V23.y};
+#endif
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[c], Gt[c], acc[c], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);

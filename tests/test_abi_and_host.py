@@ -128,3 +128,9 @@ def test_hand_waited_loads_are_never_read_in_flight():
   r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
   assert "conv32_wino_kernel" in r.stdout and "HAZARD" not in r.stdout
+  # the matrix-pipe hazards around inline-asm vector instructions (round 4: the packed differences of conv32_wino_dev.h): the
+  # scan must FLAG the build without the hazard guards — the build that made two launches of one kernel differ
+  env = dict(os.environ, CHECK_EXTRA_FLAGS="-DWN_TEST_NO_HAZARD_GUARD")
+  wino = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptive-stereo-icra-2021_amd", "csrc", "conv32_wino.hip")
+  r2 = subprocess.run([sys.executable, tool, wino], capture_output=True, text=True, timeout=900, env=env)
+  assert r2.returncode == 1 and "MATRIX-PIPE DATA HAZARD" in r2.stdout, r2.stdout[-2000:]

@@ -160,6 +160,53 @@ LINEAR_ONLY = {
 }
 
 
+MFMA_RESULT_WAIT = 18      # wait states before a vector instruction may read the destination of a 16-pass MFMA
+VALU_TO_MFMA_WAIT = 2      # wait states between a vector instruction's write and an MFMA that reads the register
+
+
+def check_mfma_hazards(lines):
+  """Second check (round 4): vector instructions written in INLINE ASM (the packed differences of conv32_wino_dev.h) are not
+  padded by hipcc for the matrix pipe's data hazards — it pads its own instructions only.  Program order, per kernel, wait states
+  counted as hipcc's hazard recognizer counts them (an instruction = 1, s_nop N = N + 1):
+    * a vector instruction inside an asm block that reads a register an MFMA wrote fewer than MFMA_RESULT_WAIT wait states ago;
+    * an MFMA that reads a register a vector instruction inside an asm block wrote fewer than VALU_TO_MFMA_WAIT wait states ago
+      (the first packed-difference build had exactly this: the last transform of a tile right in front of its MFMAs — two
+      launches of one kernel differed).
+  Branches are walked in program order (ages only grow along a fall-through; the matrix phases are straight-line code)."""
+  mfma_age, asm_age, out, in_asm = {}, {}, [], False
+  for no, l in lines:
+    if l.endswith(":"):
+      continue
+    if l.startswith("#ASM"):
+      in_asm = l == "#ASMSTART"
+      continue
+    parts = l.split(None, 1)
+    op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+    step = int(args.strip()) + 1 if op == "s_nop" else 1
+    ops = args.split(",")
+    src = regs(",".join(ops[1:])) if len(ops) > 1 else set()
+    if in_asm and op.startswith("v_") and not op.startswith("v_mfma"):
+      young = sorted(r for r in src if mfma_age.get(r, 99) < MFMA_RESULT_WAIT)
+      if young:
+        out.append((no, l, young))
+    if op.startswith("v_mfma"):
+      young = sorted(r for r in src if asm_age.get(r, 99) < VALU_TO_MFMA_WAIT)
+      if young:
+        out.append((no, l, young))
+    for d in (mfma_age, asm_age):
+      for r in list(d):
+        d[r] += step
+        if d[r] >= 64:
+          del d[r]
+    if op.startswith("v_mfma") and ops:
+      for r in regs(ops[0]):
+        mfma_age[r] = 0
+    elif in_asm and op.startswith("v_") and ops:
+      for r in regs(ops[0]):
+        asm_age[r] = 0
+  return out
+
+
 def main():
   def hand_waited(f):
     text = open(f).read()                  # asm loads of its own, or through the shared helpers of conv32_wino_dev.h
@@ -169,7 +216,8 @@ def main():
   for f in files:
     with tempfile.TemporaryDirectory() as td:
       subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-inline-asm", "-I", CSRC, "-c", f,
-                             "-save-temps", "-o", os.path.join(td, "x.o")], cwd=td, stderr=subprocess.DEVNULL)
+                             "-save-temps", "-o", os.path.join(td, "x.o")] + os.environ.get("CHECK_EXTRA_FLAGS", "").split(),
+                            cwd=td, stderr=subprocess.DEVNULL)
       asm = glob.glob(os.path.join(td, "*gfx950*.s"))[0]
       text = open(asm).read().split("\n")
     kernels, cur, name = {}, None, None
@@ -180,7 +228,9 @@ def main():
         kernels[name] = cur
         continue
       s = l.strip()
-      if cur is not None and s and not s.startswith((";", "//")) and (not s.startswith(".") or s.endswith(":")):
+      if cur is not None and s.startswith(";;#ASM"):
+        cur.append((i, "#ASMSTART" if "START" in s else "#ASMEND"))
+      elif cur is not None and s and not s.startswith((";", "//")) and (not s.startswith(".") or s.endswith(":")):
         cur.append((i, s.split(";")[0].strip() if not s.endswith(":") else s))      # (labels kept: .LBB0_3:)
     for name, lines in kernels.items():
       if not any(x[1].startswith("global_load") for x in lines):
@@ -191,6 +241,12 @@ def main():
                                   " (program order only)" if linear else ""))
       for no, l, r in hz[:6]:
         print("      line %d: %s   <- in-flight %s" % (no, l[:90], r[:8]))
+      mh = check_mfma_hazards(lines) if any(x[1].startswith("v_mfma") for x in lines) else []
+      if mh:
+        print("%-28s %-60s %d MATRIX-PIPE DATA HAZARD(S) AROUND INLINE ASM" % ("", "", len(mh)))
+        for no, l, r in mh[:6]:
+          print("      line %d: %s   <- too young: v%s" % (no, l[:90], r[:8]))
+        hz = hz + mh
       bad += len(hz)
   return 1 if bad else 0
 
