@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256, WN_WGS_PER_CU(MODE)) void conv32_wino_kernel(W
 #pragma unroll
           for (int r = 0; r < 16; ++r) {                    // conv_epilogue's arithmetic (epilogue 1)
             float yv = Y[r] * ev_sc + ev_sh;
-            yv = yv > 0.f ? yv : yv * p.slope;
-            Y[r] = yv + res[r];
+            yv = fmaxf(yv, yv * p.slope);                   // 0 < slope < 1 (checked by the entry point): lrelu(y), the same bits,
+            Y[r] = yv + res[r];                             // two instructions instead of three
           }
         }
         {
