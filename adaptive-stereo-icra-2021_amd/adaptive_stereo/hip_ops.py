@@ -232,6 +232,16 @@ def set_fwd_act(enabled):
 
 
 _WINOGRAD_BWD = True       # (diagnostics: False keeps the direct fused backward while the forward uses minimal filtering)
+_WINOGRAD_BWD_ONE_LAUNCH = True   # both gradients of a layer in ONE launch (csrc/conv32_wino_bwd.hip); False: data gradient, then
+                                  # weight gradient, g_z through HBM in between (as_conv32_wino_bwd) — A/B runs and parity tests
+
+
+def set_winograd_bwd_one_launch(flag: bool):
+  """Switches the minimal-filtering backward of the full-resolution layers between the one-launch kernel and the two launches
+  it replaced (same g_x bit for bit, dW to summation order); returns the previous setting."""
+  global _WINOGRAD_BWD_ONE_LAUNCH
+  prev, _WINOGRAD_BWD_ONE_LAUNCH = _WINOGRAD_BWD_ONE_LAUNCH, bool(flag)
+  return prev
 
 
 def set_winograd(enabled, backward=None):
@@ -748,6 +758,16 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
       # pixel and gradient instead of 9; g_z makes one round trip through HBM between the two launches
       ww_t = pack_special(w, PACK_WINO_T, 16, 16 * 1024,
                           lambda w_, o_: call("as_conv32_wino_pack_weights", ptr(w_), ptr(o_), 1, stream()))
+      if _WINOGRAD_BWD_ONE_LAUNCH:
+        # ... in one launch (csrc/conv32_wino_bwd.hip): g_z stays in LDS between the data-gradient and the weight-gradient waves
+        wws = _empty(lib.as_conv32_wino_bwd_fused_workspace(), dev)
+        _keep_for_deferred_reduce(wws)
+        _rmw_wait(sw)
+        call("as_conv32_wino_bwd_fused", ptr(x), g, ptr(g_out), ptr(z), g, shape, ptr(ww_t), ptr(st.scale), ptr(st.shift),
+             ptr(st.mean), ptr(coef), LEAKY_SLOPE, ptr(next_z), ptr(next_st.scale), ptr(next_st.shift), ptr(next_st.mean),
+             ptr(g_x), ptr(sw), ptr(sb), 1, ptr(nws), ptr(wws), stream())
+        _rmw_done(sw)
+        return g_x, None, None, None, None, BnBwdSums(nws, lib.as_conv32_wino_bwd_fused_parts())
       wws = _empty(lib.as_conv32_wino_bwd_workspace(), dev)
       _keep_for_deferred_reduce(wws)
       g_z = POOL.get(g, dev)

@@ -27,7 +27,8 @@ enum {
   AS_PROF_UPSAMPLE_FWD = 14, AS_PROF_UPSAMPLE_BWD = 15, AS_PROF_WARP_FWD = 16, AS_PROF_WARP_BWD = 17,
   AS_PROF_LOSS_FWD = 18, AS_PROF_LOSS_BWD = 19, AS_PROF_OUTCONV_FWD = 20, AS_PROF_SOFTARGMAX_FWD = 21, AS_PROF_BWD_FUSED = 22, AS_PROF_CONV_ACT = 23,
   AS_PROF_WINO_DGRAD = 24, AS_PROF_WINO_WGRAD = 25, AS_PROF_WINO_FWD = 26,    // the minimal-filtering kernels (conv32_wino*.hip)
-  AS_PROF_IDS = 27
+  AS_PROF_WINO_BWD = 27,                                                       // ... both gradients in one launch (conv32_wino_bwd.hip)
+  AS_PROF_IDS = 28
 };
 
 #define AS_CHECK_ARG(cond, ...)            \

@@ -1042,6 +1042,39 @@ extern "C" int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float
   return as_conv32_wino_bwd_filter(x, g_z, gout, s, dW, db, accumulate, workspace, stream);
 }
 
+// The same backward in ONE launch (csrc/conv32_wino_bwd.hip): data gradient and weight gradient side by side in an 8-wave
+// workgroup per CU; g_z = stage 3 of the BatchNorm backward never leaves the chip (5 tensor passes instead of 7).  Arguments of
+// as_conv32_wino_bwd without g_z; g_x bit-identical to the two-launch form.
+extern "C" int as_conv32_wino_bwd_fused_parts(void) { return conv32_wino_bwd_fused_parts(); }
+extern "C" int64_t as_conv32_wino_bwd_fused_workspace(void) { return (int64_t)conv32_wino_bwd_fused_parts() * (9 * 1024 + 32); }
+extern "C" int as_conv32_wino_bwd_fused(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                                        const as_conv_shape* s, const float* wino_wt, const float* scale, const float* shift,
+                                        const float* mean, const float* coef, float slope, const float* next_z,
+                                        const float* next_scale, const float* next_shift, const float* next_mean, float* g_x,
+                                        float* dW, float* db, int accumulate, float* next_bn_workspace, float* workspace,
+                                        void* stream) {
+  if (int e = check_conv(gin, gout, s, "as_conv32_wino_bwd_fused")) return e;
+  AS_CHECK_ARG(x && g_a && z && wino_wt && scale && shift && mean && coef && next_z && next_scale && next_shift && next_mean &&
+               g_x && dW && next_bn_workspace && workspace, "as_conv32_wino_bwd_fused: null pointer");
+  AS_CHECK_ARG(conv32_wino_applicable(gin, gout, s), "as_conv32_wino_bwd_fused: configuration not supported (as_conv32_wino_ok() == 0)");
+  AS_CHECK_ARG(((uintptr_t)next_bn_workspace & 7) == 0, "as_conv32_wino_bwd_fused: the BatchNorm workspace must be 8-byte aligned");
+  AS_CHECK_ARG(slope > 0.f && slope < 1.f, "as_conv32_wino_bwd_fused: slope must lie in (0, 1)");
+  AS_CHECK_ARG(g_x != g_a && g_x != z && g_x != x && g_x != next_z, "as_conv32_wino_bwd_fused: g_x must not alias an input");
+  const int T = 9;
+  const int slabs = conv32_wino_bwd_fused_parts();
+  float* partial_db = workspace + (int64_t)slabs * T * 1024;
+  hipStream_t st = (hipStream_t)stream;
+  as_prof_mark(AS_PROF_WINO_BWD, st, 1, 0.0);
+  if (int e = conv32_wino_bwd_fused_launch(x, g_a, z, gout, s, wino_wt, scale, shift, mean, coef, slope, next_z, next_scale, next_shift,
+                                           next_mean, g_x, workspace, partial_db, reinterpret_cast<double*>(next_bn_workspace),
+                                           stream)) return e;
+  as_prof_mark(AS_PROF_WINO_BWD, st, 0, 2.0 * 2.0 * (double)gout->B * gout->H * gout->W * 1024.0 * T);   // dgrad + wgrad, direct form
+  AS_CHECK_LAUNCH("as_conv32_wino_bwd_fused");
+  wgrad_reduce(st, workspace, partial_db, slabs, T, dW, db, accumulate);
+  AS_CHECK_LAUNCH("as_conv32_wino_bwd_fused(reduce)");
+  return AS_OK;
+}
+
 // Convolution (data gradient) fused with stage 1 of the BatchNorm backward that consumes its output.
 extern "C" int as_conv32_bnbwd_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
   if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;

@@ -27,3 +27,11 @@ int conv32_wino_dgrad2_parts(void);
 int conv32_wino_wgrad_slabs(void);
 int conv32_wino_wgrad_launch(const float* x, const float* g_z, const as_pcl* g, const as_conv_shape* s, float* partial,
                              float* partial_db, void* stream);
+// The whole backward in ONE launch (conv32_wino_bwd.hip): both gradients side by side in an 8-wave workgroup per CU, g_z never
+// leaves the chip; partial / partial_db: conv32_wino_bwd_fused_parts() slabs, next_partial as many [64]-double partials
+int conv32_wino_bwd_fused_parts(void);
+int conv32_wino_bwd_fused_launch(const float* x, const float* g_a, const float* z, const as_pcl* g, const as_conv_shape* s,
+                                 const float* wino_wt, const float* scale, const float* shift, const float* mean, const float* coef,
+                                 float slope, const float* next_z, const float* next_scale, const float* next_shift,
+                                 const float* next_mean, float* g_x, float* partial, float* partial_db, double* next_partial,
+                                 void* stream);

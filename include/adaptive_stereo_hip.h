@@ -198,6 +198,20 @@ int as_conv32_wino_bwd(const float* x, const as_pcl* gin, const float* g_a, cons
                        const float* next_scale, const float* next_shift, const float* next_mean, float* g_z,
                        float* g_x, float* dW, float* db, int accumulate, float* next_bn_workspace,
                        float* workspace, void* stream);
+/* ---- the same backward in ONE launch (csrc/conv32_wino_bwd.hip): one 8-wave workgroup per CU, waves 0-3 the data gradient,
+ * waves 4-7 the weight gradient on the g_z rows the first four keep in LDS — g_z never goes to HBM (x, g_a, z, next_z read, g_x
+ * written: 5 tensor passes for the two launches' 7).  Arguments of as_conv32_wino_bwd without g_z; g_x equals the two-launch
+ * result bit for bit, dW / db to rounding (another order of the sum over tiles).
+ *   next_bn_workspace   as_conv32_wino_bwd_fused_parts() partials of [64] doubles;  workspace: as_conv32_wino_bwd_fused_workspace() floats
+ * Replaces, per layer of EdgeAwareRefinement (reference models/stereo_net.py:10-18, 33-51, 97), autograd's conv2d backward +
+ * BatchNorm backward + LeakyReLU backward + the residual add. */
+int as_conv32_wino_bwd_fused_parts(void);
+int64_t as_conv32_wino_bwd_fused_workspace(void);
+int as_conv32_wino_bwd_fused(const float* x, const as_pcl* gin, const float* g_a, const float* z, const as_pcl* gout,
+                             const as_conv_shape* s, const float* wino_wt, const float* scale, const float* shift,
+                             const float* mean, const float* coef, float slope, const float* next_z,
+                             const float* next_scale, const float* next_shift, const float* next_mean, float* g_x,
+                             float* dW, float* db, int accumulate, float* next_bn_workspace, float* workspace, void* stream);
 
 /* ---- the 5x5 stride-2 32->32 layers of the feature head (stereo_net.py:59-72): as_conv32_fwd and as_conv32_dgrad_s2(_packed)
  * run them on csrc/conv32_s2.hip (coalesced row staging through wave-private LDS) when the map fills the chip; 0 switches back to

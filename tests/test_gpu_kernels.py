@@ -1510,6 +1510,85 @@ def test_conv32_backward_by_minimal_filtering(B, H, W, dil):
               g_x_rms_err_vs_fp64=r_w, direct_g_x_rms_err_vs_fp64=r_d, dW_rel_l2_vs_fp64=dw_w, direct_dW_rel_l2_vs_fp64=dw_d)
 
 
+@pytest.mark.parametrize("B,H,W,dil", _dgrad_generation_cases())
+def test_backward_in_one_launch_by_minimal_filtering(B, H, W, dil):
+  """as_conv32_wino_bwd_fused (csrc/conv32_wino_bwd.hip: data gradient and weight gradient side by side in one 8-wave workgroup
+  per CU, g_z never written) against the two launches of as_conv32_wino_bwd: g_x BIT FOR BIT (the data-gradient waves run the
+  same role code on the same tiles); dW is another order of the same sum over tiles, so both are held against the fp64 weight
+  gradient from the two-launch path's fp32 g_z and the fused one may be at most 2x further away (or within 2e-6); db to summation
+  order; the next BatchNorm's sums through the finalize they feed (256 partials here, 512 there); two launches bit-identical;
+  nothing written into the halo.  Every dilation, the small odd geometries of the tiling's edges (shared columns of the shifted
+  last segment: the weight gradient must count them once), the KITTI size at 4 pairs, single-segment images."""
+  g = Pcl(B, 1, H, W, 0, 8, 8)
+  shape = ops.conv_shape_2d(dil)
+  lib = nat.load()
+  assert lib.as_conv32_wino_ok(g, g, shape) == 1
+  T = lambda seed: ops.ncdhw_to_pcl(rnd(B, 32, 1, H, W, seed=seed).to(DEV), g)
+  x, g_a, zz, zn = T(3), T(4), T(5), T(6)
+  w = (rnd(32, 32, 3, 3, seed=9) * 0.06).to(DEV)
+  ww_t = torch.empty(16 * 1024, device=DEV)
+  nat.call("as_conv32_wino_pack_weights", nat.ptr(w), nat.ptr(ww_t), 1, nat.stream())
+  st, stn = ops.BnState(DEV), ops.BnState(DEV)
+  for i, s_ in enumerate((st, stn)):
+    s_.mean.copy_(rnd(32, seed=5 + 10 * i).to(DEV) * 0.1); s_.invstd.copy_(rnd(32, seed=6 + 10 * i).abs().to(DEV) + 0.5)
+    s_.scale.copy_(s_.invstd * 1.1); s_.shift.copy_(rnd(32, seed=7 + 10 * i).to(DEV) * 0.1 - s_.mean * s_.scale)
+  gamman = torch.full((32,), 1.1, device=DEV)
+  coef = (rnd(96, seed=21) * 0.05).to(DEV); coef[64:] = coef[64:].abs() + 0.7
+  tag = "fused wino bwd B%d H%d W%d d%d" % (B, H, W, dil)
+  # the two launches
+  gz, gx2 = ops.pcl_zeros(g, DEV), ops.pcl_zeros(g, DEV)
+  dW2, db2 = torch.zeros(32, 32, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+  nws2 = torch.zeros(lib.as_bn_bwd_workspace(g), device=DEV)
+  fws2 = torch.empty(lib.as_conv32_wino_bwd_workspace(), device=DEV)
+  nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
+           nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(stn.scale), nat.ptr(stn.shift),
+           nat.ptr(stn.mean), nat.ptr(gz), nat.ptr(gx2), nat.ptr(dW2), nat.ptr(db2), 0, nat.ptr(nws2), nat.ptr(fws2), nat.stream())
+  # one launch
+  nparts = lib.as_conv32_wino_bwd_fused_parts()
+  assert nparts * 128 <= lib.as_bn_bwd_workspace(g)
+  def run(acc, gx, dW, db, nws):
+    fws = torch.empty(lib.as_conv32_wino_bwd_fused_workspace(), device=DEV)
+    nat.call("as_conv32_wino_bwd_fused", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(stn.scale), nat.ptr(stn.shift),
+             nat.ptr(stn.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), acc, nat.ptr(nws), nat.ptr(fws), nat.stream())
+    torch.cuda.synchronize()
+  gx, dW, db = ops.pcl_zeros(g, DEV), torch.zeros(32, 32, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+  nws = torch.zeros(lib.as_bn_bwd_workspace(g), device=DEV)
+  run(0, gx, dW, db, nws)
+  full = ops.pcl_view(gx, g).clone(); ops.pcl_interior(full, g).zero_()
+  assert float(full.abs().max()) == 0.0, tag + ": g_x written into the halo"
+  if not bool(torch.equal(gx, gx2)):
+    va, vb = ops.pcl_view(gx, g), ops.pcl_view(gx2, g)
+    bad = (va != vb).nonzero()
+    raise AssertionError("%s: g_x differs from the two-launch form at %d elements; first [b, d, y, x, c] (padded) = %s: %r against %r" % (
+        tag, bad.shape[0], bad[0].tolist(), float(va[tuple(bad[0])]), float(vb[tuple(bad[0])])))
+  assert float(ops.pcl_interior(ops.pcl_view(gx, g), g).abs().max()) > 0.0
+  # weight / bias gradient: fp64 from the two-launch path's fp32 g_z
+  gz64 = ops.pcl_to_ncdhw(gz, g)[:, :, 0].double().cpu(); x64 = ops.pcl_to_ncdhw(x, g)[:, :, 0].double().cpu()
+  dW64 = torch.nn.grad.conv2d_weight(x64, tuple(w.shape), gz64, padding=dil, dilation=dil)
+  e1 = float((dW.double().cpu() - dW64).norm() / dW64.norm()); e2 = float((dW2.double().cpu() - dW64).norm() / dW64.norm())
+  assert e2 < 3e-6 and e1 <= max(2.0 * e2, 2e-6), (tag, "dW", e1, e2)
+  db64 = gz64.sum(dim=(0, 2, 3)); mag = float(gz64.abs().sum(dim=(0, 2, 3)).max())
+  assert float((db.double().cpu() - db64).abs().max()) <= 5e-7 * mag, tag + ": bias gradient"
+  # the next BatchNorm's sums through its finalize
+  _, gg1, gb1 = ops.bn_act_bwd(gx, zn, stn, gamman, g, True, sums=ops.BnBwdSums(nws, nparts))
+  _, gg2, gb2 = ops.bn_act_bwd(gx2, zn, stn, gamman, g, True, sums=ops.BnBwdSums(nws2, lib.as_conv32_wino_bwd_parts()))
+  n = B * H * W
+  close(gg1, gg2, 2e-6 * n ** 0.5 * float(gg2.abs().max()) + 1e-5, 1e-5, tag + " next g_gamma")
+  close(gb1, gb2, 2e-6 * n ** 0.5 * float(gb2.abs().max()) + 1e-5, 1e-5, tag + " next g_beta")
+  # determinism, and the accumulate flavour
+  gx_b, dW_b, db_b = ops.pcl_zeros(g, DEV), torch.zeros(32, 32, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+  nws_b = torch.zeros(lib.as_bn_bwd_workspace(g), device=DEV)
+  run(0, gx_b, dW_b, db_b, nws_b)
+  assert bool(torch.equal(gx_b, gx)) and bool(torch.equal(dW_b, dW)) and bool(torch.equal(db_b, db)), tag + ": two launches differ"
+  assert bool(torch.equal(nws_b[:nparts * 128].view(torch.int32), nws[:nparts * 128].view(torch.int32))), tag + ": sums differ"
+  run(1, gx_b, dW_b, db_b, nws_b)
+  close(dW_b, 2 * dW, 1e-4 * float(dW.abs().max()), 1e-4, tag + " accumulated dW")
+  from conftest import parity_note
+  parity_note("conv32_wino_bwd_fused[%s]" % tag, g_x_bit_identical_to_two_launches=True, dW_rel_l2_vs_fp64=e1,
+              two_launch_dW_rel_l2_vs_fp64=e2)
+
+
 # ----------------------------------------------------------------------------- a7 forward with the previous BN + LReLU on the way in
 @pytest.mark.parametrize("B,H,W,dil,skip", [(2, 160, 1242, 1, True), (2, 161, 1242, 2, True), (1, 375, 1030, 4, True),
                                             (2, 163, 1237, 8, True), (4, 97, 700, 1, False)])
