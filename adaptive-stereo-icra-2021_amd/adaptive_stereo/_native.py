@@ -117,6 +117,7 @@ _SIGNATURES = {
   "as_conv32_wino_bwd_fused_workspace": (c_i64, []),
   "as_conv32_wino_bwd_fused": (c_int, [c_vp, _P(Pcl), c_vp, c_vp, _P(Pcl), _P(ConvShape), c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_vp,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+  "as_conv3d_wgrad_lds_assignment": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
   "as_conv32_s2_enable": (c_int, [c_int]),
   "as_conv4_s2_enable": (c_int, [c_int]),
   "as_refine_out_ok": (c_int, [_P(Pcl)]),

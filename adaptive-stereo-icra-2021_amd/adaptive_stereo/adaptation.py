@@ -36,18 +36,34 @@ from .utils.ema import online_ema
 
 
 def _release_comm(comm):
+  """Fallback release of a communicator whose adapter was dropped (or is still alive at interpreter exit) without close().
+  Ranks reach this point at different times, or not at all (a crashed rank), the process group may be gone and a captured
+  hipGraph may still hold nodes of the communicator: a blocking destroy here could hang the surviving ranks, so the teardown is
+  ncclCommAbort (does not wait for outstanding work or for peers).  close() is the orderly, collective release."""
+  import sys
   try:
-    if torch.cuda.is_available():
-      torch.cuda.synchronize()
-    comm.destroy()
-  except Exception:                        # noqa: BLE001 — interpreter shutdown: nothing left to report to
-    pass
+    print("adaptive_stereo: an OnlineAdapter with a live RCCL communicator was finalized without close(): aborting the "
+          "communicator (call close() on every rank before dropping the adapter or destroying the process group)", file=sys.stderr)
+    comm.abort()
+  except Exception as e:                   # noqa: BLE001 — interpreter shutdown: report what can still be reported
+    try:
+      print("adaptive_stereo: ncclCommAbort in the finalizer failed: %r" % (e,), file=sys.stderr)
+    except Exception:                      # noqa: BLE001
+      pass
 
 
-def never_executed(name):
-  """BasicBlock.conv2 is constructed but never called by the reference (stereo_net.py:40 against :44-51): its tensors are part
-  of the state_dict, receive no gradient (``grad is None``: torch.optim.Adam skips them, adapt.py:208-210) and never change."""
-  return ".conv2." in name
+def never_executed_names(module):
+  """Names (as in ``module.named_parameters()``) of the parameters of every BasicBlock.conv2 under ``module``: constructed but
+  never called by the reference (stereo_net.py:40 against :44-51) — part of the state_dict, no gradient (``grad is None``:
+  torch.optim.Adam skips them, adapt.py:208-210), never changed.  Keyed on the OWNING MODULE's type, not on a substring of
+  the name: a layer of some other module that happens to be called conv2 trains and synchronises like any other."""
+  from .models.stereo_net import _ResidualBlock2d as BasicBlock     # (the reference's BasicBlock: stereo_net.py:33-51)
+  names = set()
+  for mname, m in module.named_modules():
+    if isinstance(m, BasicBlock):
+      prefix = (mname + "." if mname else "") + "conv2."
+      names.update(prefix + n for n, _ in m.conv2.named_parameters())
+  return names
 
 
 class FlatArena(object):
@@ -64,8 +80,9 @@ class FlatArena(object):
     for mi, m in enumerate(modules):
       start = offset
       listed = []
+      dead = never_executed_names(m)
       for name, p in m.named_parameters():
-        live = not never_executed(name)
+        live = name not in dead
         listed.append((name, p, live))
         if not live:
           continue

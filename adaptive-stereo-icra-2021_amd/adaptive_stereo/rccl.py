@@ -44,6 +44,8 @@ def _load():
     lib.ncclAllReduce.argtypes = [vp, vp, sz, ci, ci, vp, vp]
     lib.ncclAllGather.argtypes = [vp, vp, sz, ci, vp, vp]
     lib.ncclCommDestroy.argtypes = [vp]
+    lib.ncclCommAbort.argtypes = [vp]
+    lib.ncclGetVersion.argtypes = [ctypes.POINTER(ci)]
     lib.ncclGetErrorString.restype = ctypes.c_char_p
     lib.ncclGetErrorString.argtypes = [ci]
     _lib = lib
@@ -92,6 +94,12 @@ class RcclComm(object):
   def __init__(self, handle, group, rank, world):
     self._comm, self.group, self.rank, self.world = handle, group, rank, world
     self.device = torch.cuda.current_device()
+    self.evidence = None        # filled by the probe stage: what the first collective of this communicator returned
+
+  def describe(self):
+    """Rank-count evidence for logs and bench.py's JSON line: the result of the probe all-reduce (a sum of ones = the number of
+    ranks that took part), the HIP device of every rank as all-gathered through THIS communicator, the library's version."""
+    return dict(self.evidence or {}, world=self.world, rank=self.rank)
 
   def _stream(self):
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -119,8 +127,16 @@ class RcclComm(object):
     return out
 
   def destroy(self):
+    """Orderly release (a collective: every rank calls it, with the communicator's work done)."""
     if self._comm is not None and self._comm.value:
       _load().ncclCommDestroy(self._comm)
+    self._comm = None
+
+  def abort(self):
+    """Non-blocking teardown for paths on which the peers may be gone or at another point of the program (garbage collection,
+    interpreter exit after a crash elsewhere): ncclCommAbort does not wait for outstanding work or for the other ranks."""
+    if self._comm is not None and self._comm.value:
+      _load().ncclCommAbort(self._comm)
     self._comm = None
 
 
@@ -140,6 +156,9 @@ class _RcclStages(object):
   def prepare(self):
     return torch.ones(8, dtype=torch.float32, device="cuda")    # a live HIP context on this device + the probe's buffer
 
+  def agree_flag(self):
+    return torch.zeros(1, dtype=torch.int32, device="cuda")     # the agreements' one buffer, allocated before the first of them
+
   def init(self, uid_bytes, group, rank, world):
     uid = _UniqueId()
     ctypes.memmove(ctypes.addressof(uid), uid_bytes, 128)
@@ -149,9 +168,16 @@ class _RcclStages(object):
     return RcclComm(comm, group, rank, world)
 
   def probe(self, comm, probe):
+    devs = torch.full((comm.world,), -1, dtype=torch.int32, device="cuda")
+    mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int32, device="cuda")
     with _c_stdout_to_stderr():
       comm.all_reduce(probe)
+      comm.all_gather(devs, mine)
       torch.cuda.synchronize()
+    ver = ctypes.c_int(0)
+    _load().ncclGetVersion(ctypes.byref(ver))
+    comm.evidence = {"ranks": float(probe[0]), "device_ids": [int(v) for v in devs.cpu()], "nccl_version": int(ver.value),
+                     "how": "ranks = the communicator's first all-reduce of ones; device_ids = an all-gather of each rank's HIP device"}
     if float(probe[0]) != float(comm.world):
       raise RuntimeError("probe all-reduce returned %r over %d ranks" % (float(probe[0]), comm.world))
 
@@ -171,8 +197,10 @@ def _injected_failure(stage, rank):
     raise RuntimeError("injected failure at stage %s on rank %d (AS_RCCL_FAIL_AT)" % (stage, rank))
 
 
-def _all_agree(ok, group, device="cuda"):
-  flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+def _all_agree(ok, group, flag):
+  """MIN over the ranks of "I am fine", in the buffer every rank allocated BEFORE the first agreement (no allocation, hence
+  nothing that can fail locally, stands between a rank and a collective its peers are entering)."""
+  flag.fill_(1 if ok else 0)
   dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
   return int(flag) == 1
 
@@ -183,11 +211,17 @@ def _create_staged(group, stages):
     ncclCommInitRank | agree | probe all-reduce | agree
   — so a rank that fails at any stage never leaves the others inside a collective it does not enter itself: a failure is
   carried to the next agreement and all ranks leave together with None.  (Round 3 raised out of the constructor when
-  ncclGetUniqueId failed on rank 0, i.e. BEFORE the broadcast the other ranks were already waiting in.)"""
+  ncclGetUniqueId failed on rank 0, i.e. BEFORE the broadcast the other ranks were already waiting in.)
+  The agreements' flag buffer is allocated FIRST, before any collective (round 4 allocated it inside the first agreement,
+  outside any try: a rank whose HIP context could not be created raised there while its peers sat in the all-reduce).  The one
+  residual case: a rank that cannot allocate those 4 bytes on its device cannot take part in ANY collective of an nccl group,
+  the agreement included — it raises, and its peers leave through the process group's timeout; nothing in a library can do
+  better for a rank without a device."""
   global last_error
   rank, world = dist.get_rank(group), dist.get_world_size(group)
-  dev = stages.agree_device
   err = None
+  _injected_failure("agree_tensor", rank)      # (tests: the residual case raises out of try_create, before any collective)
+  flag = stages.agree_flag()
 
   def attempt(stage, fn, collective=False):
     nonlocal err
@@ -205,7 +239,7 @@ def _create_staged(group, stages):
       return None
 
   def agreed():
-    return _all_agree(err is None, group, dev)
+    return _all_agree(err is None, group, flag)
 
   def give_up(comm=None):
     global last_error

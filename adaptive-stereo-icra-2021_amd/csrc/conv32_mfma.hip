@@ -1075,6 +1075,15 @@ extern "C" int as_conv32_wino_bwd_fused(const float* x, const as_pcl* gin, const
   return AS_OK;
 }
 
+// Host-side view of conv3d_wgrad_lds_kernel's work assignment (csrc/conv3d_lds.h: conv3d_wgrad_assign — the very function the
+// kernel calls): for workgroup `block` of a launch over `ntiles` tiles in `nchunks` chunks, its chunk, kd and extra tile (-1:
+// none).  Returns 1 for a working block, 0 for a padding block.  No GPU involved: the CPU suite walks it.
+extern "C" int as_conv3d_wgrad_lds_assignment(int ntiles, int nchunks, int block, int* chunk, int* kd, int* extra_tile) {
+  AS_CHECK_ARG(chunk && kd && extra_tile && ntiles >= 1 && nchunks >= 1 && nchunks <= ntiles && block >= 0,
+               "as_conv3d_wgrad_lds_assignment: bad arguments");
+  return conv3d_wgrad_assign(block, ntiles, nchunks, chunk, kd, extra_tile) ? 1 : 0;
+}
+
 // Convolution (data gradient) fused with stage 1 of the BatchNorm backward that consumes its output.
 extern "C" int as_conv32_bnbwd_parts(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s) {
   if (!as_pcl_ok(gin) || !as_pcl_ok(gout) || !s) return AS_ERR_ARG;

@@ -6,6 +6,16 @@
 #include "conv32_wino.h"
 #include "conv32_wino_dev.h"
 
+// build-time switches of the FUSED flavour (tests/tools/fused_bwd_ab.sh times every combination on one box)
+#ifndef FB_PK_XF
+#define FB_PK_XF 0        // the matrix loop's differences on packed instructions
+#endif
+#ifndef FB_PK_T
+#define FB_PK_T 0         // T = (M A) on packed instructions
+#endif
+#ifndef FB_MASK_BRANCH
+#define FB_MASK_BRANCH 0  // the shared-column mask of the next BatchNorm's sums behind a real branch
+#endif
 #ifndef DG_GRID
 #define DG_GRID 512
 #endif
@@ -276,9 +286,14 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
         f32x4 V[4];
         {
           f32x4 Rt[4];
+          constexpr bool PKX = FUSED && FB_PK_XF;
 #pragma unroll
-          for (int m = 0; m < 4; ++m) Rt[m] = SG_PLUS ? xa[m] + xb[m] : xa[m] - xb[m];
-          V[0] = Rt[0] - Rt[2]; V[1] = Rt[1] + Rt[2]; V[2] = Rt[2] - Rt[1]; V[3] = Rt[1] - Rt[3];
+          for (int m = 0; m < 4; ++m) Rt[m] = SG_PLUS ? xa[m] + xb[m] : wn_sub4_if<PKX>(xa[m], xb[m]);
+          // (FUSED: the differences on packed instructions — conv32_wino_dev.h; a vector instruction costs the SIMD ~5 cycles of
+          //  matrix time whichever of its two waves issues it, and here nothing else hides them)
+          V[0] = wn_sub4_if<PKX>(Rt[0], Rt[2]); V[1] = Rt[1] + Rt[2]; V[2] = wn_sub4_if<PKX>(Rt[2], Rt[1]);
+          V[3] = wn_sub4_if<PKX>(Rt[1], Rt[3]);
+          if constexpr (PKX) wn_before_mfma();
         }
         __builtin_amdgcn_sched_barrier(0);
         if (q + 1 < 4) {                                   // the next chunk's operands: in flight under this chunk's MFMAs
@@ -316,10 +331,24 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
       }
       // T[jc] = (M[r] A)[jc]: A^T = [1 1 1 0; 0 1 -1 -1]
       f32x16 T0, T1;
+      if constexpr (FUSED && FB_PK_T) {
+        wn_after_mfma();                                   // (the matrix phase ended at a sched_barrier right above)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        T0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
-        T1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+        for (int gq = 0; gq < 4; ++gq) {
+          f32x4 a4[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a4[c] = (f32x4){acc[c][4 * gq + 0], acc[c][4 * gq + 1], acc[c][4 * gq + 2], acc[c][4 * gq + 3]};
+          const f32x4 t0 = (a4[0] + a4[1]) + a4[2];
+          const f32x4 t1 = wn_sub4(wn_sub4(a4[1], a4[2]), a4[3]);
+          T0[4 * gq + 0] = t0.x; T0[4 * gq + 1] = t0.y; T0[4 * gq + 2] = t0.z; T0[4 * gq + 3] = t0.w;
+          T1[4 * gq + 0] = t1.x; T1[4 * gq + 1] = t1.y; T1[4 * gq + 2] = t1.z; T1[4 * gq + 3] = t1.w;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          T0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+          T1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);                   // (the accumulators die HERE, before anything below asks for registers)
       FB_T(1);
@@ -413,22 +442,55 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
           const int y = r0 + yrow * d;
           float* gx_base = p.g_x + ((img + y + p.g.ph) * Wp + x0 + p.g.pw) * 32;
           const auto rs = __builtin_amdgcn_make_buffer_rsrc(gx_base, 0, keep_l * 128, 0x00020000);
-#pragma unroll
-          for (int jc = 0; jc < 2; ++jc) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[jc][r] += res[jc][r];
 #define DG_ST(r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[jc][r]), rs, (int)io_off + jc * d * 128 + DG_IMM(r), 0, 0); \
                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Y[jc][8 + r]), rs, (int)io_off + 4096 + jc * d * 128 + DG_IMM(r), 0, 0);
-            DG_FOR_8(DG_ST)
-#undef DG_ST
+          if constexpr (FUSED && FB_MASK_BRANCH) {
+            // The shared-column mask of the sums behind a REAL branch (one segment of twenty shares columns; as selects the mask is
+            // 64 vector instructions per tile).  The branch stands BEFORE the stores: with stores in flight hipcc drains the
+            // whole queue at the join (measured: +25-40 % on the launch).
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float yv = fmaf(zt[jc][r], bn_sc, bn_sh);
-              float gy = yv > 0.f ? Y[jc][r] : Y[jc][r] * p.slope;
-              if (keep_l < 64) gy = DG_COL(r, jc) < keep_l ? gy : 0.f;
-              bn_dy[jc] += gy; bn_dx[jc] = fmaf(gy, zt[jc][r] - bn_mu, bn_dx[jc]);
+            for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) Y[jc][r] += res[jc][r];
+            if (keep_l == 64) {
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const float yv = fmaf(zt[jc][r], bn_sc, bn_sh);
+                  const float gy = yv > 0.f ? Y[jc][r] : Y[jc][r] * p.slope;
+                  bn_dy[jc] += gy; bn_dx[jc] = fmaf(gy, zt[jc][r] - bn_mu, bn_dx[jc]);
+                }
+            } else {
+#pragma unroll
+              for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const float yv = fmaf(zt[jc][r], bn_sc, bn_sh);
+                  float gy = yv > 0.f ? Y[jc][r] : Y[jc][r] * p.slope;
+                  gy = DG_COL(r, jc) < keep_l ? gy : 0.f;
+                  bn_dy[jc] += gy; bn_dx[jc] = fmaf(gy, zt[jc][r] - bn_mu, bn_dx[jc]);
+                }
+            }
+#pragma unroll
+            for (int jc = 0; jc < 2; ++jc) { DG_FOR_8(DG_ST) }
+          } else {
+#pragma unroll
+            for (int jc = 0; jc < 2; ++jc) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) Y[jc][r] += res[jc][r];
+              DG_FOR_8(DG_ST)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float yv = fmaf(zt[jc][r], bn_sc, bn_sh);
+                float gy = yv > 0.f ? Y[jc][r] : Y[jc][r] * p.slope;
+                if (keep_l < 64) gy = DG_COL(r, jc) < keep_l ? gy : 0.f;
+                bn_dy[jc] += gy; bn_dx[jc] = fmaf(gy, zt[jc][r] - bn_mu, bn_dx[jc]);
+              }
             }
           }
+#undef DG_ST
         }
         __builtin_amdgcn_sched_barrier(0);
         FB_T(4);

@@ -233,17 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_lds_kernel(Wgrad3dLdsArgs
   // Tiles: `full` rounds of tile = chunk + k * nchunks, and the remaining tiles one each to the chunks that are dispatched FIRST
   // on every XCD (they land on different CUs: no CU then hosts two workgroups with an extra tile — the launch is matrix-bound, a
   // CU's time is the sum of its two workgroups' tiles; with the extra tiles on chunks 0..rem-1 = one XCD's neighbours: 55 us for 50).
-  int chunk, kd, extra_tile = -1;
+  int chunk, kd, extra_tile;
   const int full = p.ntiles / p.nchunks;
-  {
-    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
-    const int per_xcd = (p.nchunks + 7) >> 3;
-    kd = q % 3;
-    chunk = xcd * per_xcd + q / 3;
-    if (chunk >= p.nchunks || q / 3 >= per_xcd) return;            // padding blocks (uniform per workgroup)
-    const int j = (q / 3) * 8 + xcd;
-    if (j < p.ntiles - full * p.nchunks) extra_tile = full * p.nchunks + j;
-  }
+  if (!conv3d_wgrad_assign(blockIdx.x, p.ntiles, p.nchunks, &chunk, &kd, &extra_tile)) return;     // padding blocks (uniform per workgroup)
   const long plane_vox = (long)Wp * p.g.Hp;
   const int first = p.g.ph * Wp + p.g.pw;
   const int last_group = (int)plane_vox - 8;                       // last 8-voxel group that lies inside a plane

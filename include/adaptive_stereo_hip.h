@@ -353,6 +353,11 @@ int as_conv32_dgrad_s2_packed(const float* gz, const as_pcl* ggz, const float* p
 int64_t as_conv32_wgrad_workspace(const as_pcl* gin, const as_pcl* gout, const as_conv_shape* s);
 int as_conv32_wgrad(const float* x, const as_pcl* gin, const float* gz, const as_pcl* gout,
                     const as_conv_shape* s, float* dW, float* db, int accumulate, float* workspace, void* stream);
+/* Host-side view of the work assignment of the LDS-staged 3-D weight gradient (csrc/conv3d_lds.hip): chunk, kd and extra tile
+ * (-1: none) of workgroup `block` for a launch over ntiles tiles in nchunks chunks; returns 1 (working block) / 0 (padding
+ * block).  Runs on the host — the function the kernel itself calls — so that a test without a GPU can check that every
+ * tile is covered exactly three times for any (ntiles, nchunks). */
+int as_conv3d_wgrad_lds_assignment(int ntiles, int nchunks, int block, int* chunk, int* kd, int* extra_tile);
 
 /* ---- BatchNorm (train/eval) + LeakyReLU around the convolution --------------
  * nn.BatchNorm3d / nn.BatchNorm2d (eps, momentum as given) + nn.LeakyReLU(0.2)

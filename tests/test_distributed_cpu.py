@@ -197,6 +197,9 @@ class _FakeStages(object):
     self.calls.append("prepare")
     return torch.ones(1)
 
+  def agree_flag(self):
+    return torch.zeros(1, dtype=torch.int32)
+
   def init(self, uid, group, rank, world):
     assert uid == bytes(range(128))
     self.calls.append("init")
@@ -233,6 +236,36 @@ def _staged_worker(rank, world, port, out_dir):
   os.environ.pop("AS_RCCL_FAIL_AT", None)
   torch.save(rows, os.path.join(out_dir, "staged_%d.pt" % rank))
   dist.destroy_process_group()
+
+
+def _agree_tensor_worker(rank, world, port, out_dir):
+  import datetime
+  for p in (REPO, PKG):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+  dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+  from adaptive_stereo import rccl
+  os.environ["AS_RCCL_FAIL_AT"] = "agree_tensor:0"
+  stages = _FakeStages()
+  try:
+    rccl._create_staged(None, stages)
+    verdict = "returned"
+  except RuntimeError as e:
+    verdict = "raised: %s" % e
+  os.environ.pop("AS_RCCL_FAIL_AT", None)
+  torch.save((verdict, list(stages.calls)), os.path.join(out_dir, "agree_%d.pt" % rank))
+  dist.destroy_process_group()
+
+
+def test_a_rank_without_its_agreement_buffer_raises_before_any_collective(tmp_path):
+  """The documented residual case of the staged construction: a rank that cannot allocate the agreements' flag buffer on its
+  device cannot take part in ANY collective — it must raise before the first one is entered (its peers then leave through the
+  process group's timeout), not inside an agreement as round 4 did.  One rank: nothing may have run when it raises."""
+  mp.spawn(_agree_tensor_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+  verdict, calls = torch.load(str(tmp_path / "agree_0.pt"))
+  assert verdict.startswith("raised:") and "agree_tensor" in verdict, verdict
+  assert calls == [], calls
 
 
 def test_staged_communicator_construction_never_strands_a_rank(tmp_path):

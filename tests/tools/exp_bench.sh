@@ -8,7 +8,7 @@ n=0
 for flags in "$@"; do
   n=$((n+1))
   for f in $files; do touch adaptive-stereo-icra-2021_amd/csrc/$f; done
-  make -C adaptive-stereo-icra-2021_amd/csrc EXTRA="$flags" > gpurun_out/exp_bench_build_$n.log 2>&1 || { tail -5 gpurun_out/exp_bench_build_$n.log; exit 1; }
+  make -C adaptive-stereo-icra-2021_amd/csrc SCAN=0 EXTRA="$flags" > gpurun_out/exp_bench_build_$n.log 2>&1 || { tail -5 gpurun_out/exp_bench_build_$n.log; exit 1; }
   for rep in 1 2; do
     timeout -k 10 300 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-online --no-dp-overhead > gpurun_out/exp_bench_$n.json 2> gpurun_out/exp_bench_$n.err || { tail -5 gpurun_out/exp_bench_$n.err; exit 1; }
     python3 -c "

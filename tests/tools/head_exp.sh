@@ -8,7 +8,7 @@ n=0
 for flags in "$@"; do
   n=$((n+1))
   touch adaptive-stereo-icra-2021_amd/csrc/conv32_mfma.hip
-  make -C adaptive-stereo-icra-2021_amd/csrc EXTRA="$flags" > gpurun_out/head_exp_build_$n.log 2>&1 || { tail -5 gpurun_out/head_exp_build_$n.log; exit 1; }
+  make -C adaptive-stereo-icra-2021_amd/csrc SCAN=0 EXTRA="$flags" > gpurun_out/head_exp_build_$n.log 2>&1 || { tail -5 gpurun_out/head_exp_build_$n.log; exit 1; }
   rm -rf gpurun_out/head_exp_$n
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/head_exp_$n -o h -- python3 tests/tools/head_ab.py ${HEAD_IMAGES:-8} > gpurun_out/head_exp_$n.log 2>&1 || { tail -5 gpurun_out/head_exp_$n.log; exit 1; }
   echo "== [$flags]"

@@ -63,6 +63,7 @@ if lib.as_conv32_wino_ok(g, g, shape) == 1:
   a_by = torch.zeros(g.numel(), device=dev)
   gzw = torch.zeros(g.numel(), device=dev)
   fws_w = torch.empty(lib.as_conv32_wino_bwd_workspace(), device=dev)
+  fws_1 = torch.empty(lib.as_conv32_wino_bwd_fused_workspace(), device=dev)
   for _ in range(5):
     for skip in (x, None):
       nat.call("as_conv32_wino_fwd", nat.ptr(zb), nat.ptr(skip), nat.ptr(st.scale), nat.ptr(st.shift), nat.ptr(a_by), g, nat.ptr(ww),
@@ -70,6 +71,10 @@ if lib.as_conv32_wino_ok(g, g, shape) == 1:
     nat.call("as_conv32_wino_bwd", nat.ptr(x), g, nat.ptr(gzo), nat.ptr(z), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
              nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zb), nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(gzw), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(bws2), nat.ptr(fws_w), nat.stream())
+    # conv32_wino_bwd_kernel<0>: both gradients in ONE launch (what a step launches since round 5): x, g_a, z, z_next read, g_x written
+    nat.call("as_conv32_wino_bwd_fused", nat.ptr(x), g, nat.ptr(gzo), nat.ptr(z), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
+             nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zb), nat.ptr(st.scale), nat.ptr(st.shift),
+             nat.ptr(st.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(bws2), nat.ptr(fws_1), nat.stream())
 # a3: one 3-D cost-aggregation layer: rolling-window forward (plain, with moments, with the previous BatchNorm merged and
 # applied in LDS + by-product), the fused tail (a4 + a5 + a8) and the LDS weight gradient
 g3 = Pcl(B, 12, 24, 78, 1, 1, 1)

@@ -5,7 +5,9 @@ of a wide coalesced stream -> read bytes = 2 x FETCH_SIZE(KB) x 1024; WRITE_SIZE
 MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles): MFMA_BUSY is the chip-wide sum
 of per-SIMD matrix-pipe cycles (it equals launches' MFMA count x 64 exactly for v_mfma_f32_32x32x2_f32);
 kernel cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the counter over the 8 XCDs)."""
-import collections, csv, json, sys
+import collections, csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from bench import csrc_digest
 
 def load(path):
   acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -30,6 +32,7 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "conv32_wino_kernel<2, 0>": 5 * vox * 128,              # g_a, z, z_next read; g_z (by-product), g_x written
        "conv32_wino_dgrad_kernel<0>": 5 * vox * 128,           # second generation of the data gradient (conv32_wino_dgrad.hip)
        "conv32_wino_wgrad_kernel<0>": 2 * vox * 128,           # x, g_z read
+       "conv32_wino_bwd_kernel<0>": 5 * vox * 128,             # both gradients in one launch: x, g_a, z, z_next read; g_x written
        "conv32_fwd_kernel<27>": 2 * vox3 * 128 + 27 * 4096, "conv32_wgrad_kernel<3>": 2 * vox3 * 128,
        "conv3d_lds_kernel": 2 * vox3 * 128 + 27 * 4096, "conv3d_wgrad_lds_kernel": 2 * vox3 * 128,
        "agg3d_kernel<0, 2, false>": 2 * vox3 * 128 + 27 * 4096, "agg3d_kernel<0, 0, false>": 2 * vox3 * 128 + 27 * 4096,
@@ -39,6 +42,7 @@ alg = {"conv32_lds_kernel<0, false>": 2 * vox * 128, "conv32_lds_kernel<2, true>
        "agg_tail_direct_kernel<2, true, 32>": 2 * vox3 * 128 + vox3 * 4}
 out = {"shape": "2-D 3x3 stride 1, 32->32, %d pair(s) x 375x1242 (one full-resolution refinement layer); 3-D rows: 12x24x78 per pair" % B,
        "pairs_per_launch": B, "algorithmic_flops_per_launch": flops,
+       "csrc_digest": csrc_digest(),       # sha256 over csrc/*.hip, *.h as they were when the counters were taken: bench.py refuses stale files
        "command": "rocprofv3 --kernel-trace --pmc <counters> -- python3 tests/tools/pmc_conv.py   (separate passes: SQ_* ; FETCH_SIZE ; WRITE_SIZE GRBM_GUI_ACTIVE)",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams -> read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM); WRITE_SIZE x 1024 exact.",
        "kernels": {}}

@@ -71,10 +71,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_loop(const float* src, float* ou
   if (lane == 0) { cyc[blockIdx.x * 8 + wave] = t1 - t0; wall[blockIdx.x * 8 + wave] = w1 - w0; }
 }
 
-// waves 0-3: MFMAs only (64 per tile); waves 4-7: NVW packed vector instructions per tile, nothing else
-template <int NVW>
+// waves 0-3: MFMAs only (64 per tile); waves 4-7: NVW vector instructions of kind OP per tile, nothing else
+// OP: 0 v_pk_add_f32, 1 v_add_f32, 2 v_fma_f32, 3 v_cndmask_b32, 4 v_mul_f32, 5 v_pk_fma_f32, 6 v_pk_mul_f32, 7 v_mov_b32,
+//     8 v_cmp_gt_f32, 9 v_add_u32, 10 ds_read_b32 (an LDS instruction's issue), 11 v_max_f32, 12 s_nop 0
+template <int NVW, int OP = 0>
 __global__ __launch_bounds__(512, 1) void k_split(const float* src, float* out, long long* cyc, long long* wall, int tiles) {
+  __shared__ float lds_s[512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  lds_s[threadIdx.x] = src[threadIdx.x];
+  __syncthreads();
   float b[16];
   for (int i = 0; i < 16; ++i) b[i] = src[(threadIdx.x * 16 + i) & 65535];
   float s = 0.f;
@@ -94,15 +99,54 @@ __global__ __launch_bounds__(512, 1) void k_split(const float* src, float* out, 
   } else {
     f32x2 d[8];
     for (int i = 0; i < 8; ++i) d[i] = (f32x2){b[2 * i], b[2 * i + 1]};
+    float e[8];
+    for (int i = 0; i < 8; ++i) e[i] = b[i];
+    unsigned laddr = (unsigned)(threadIdx.x * 4);
+    unsigned laddr4 = (unsigned)((threadIdx.x & 63) * 16);
+    unsigned sc[4] = {1u, 2u, 3u, 4u};
+    unsigned long long msk = 0x00ff00ff00ff00ffull;
+    f32x4 q4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     t0 = clock64(); w0 = wall_clock64();
     for (int t = 0; t < tiles; ++t) {
 #pragma unroll
-      for (int v = 0; v < NVW; ++v) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[v & 7]) : "v"(d[(v + 3) & 7]));
+      for (int v = 0; v < NVW; ++v) {
+        if (OP == 0) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[v & 7]) : "v"(d[(v + 3) & 7]));
+        else if (OP == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 2) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 3) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 4) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 5) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(d[v & 7]) : "v"(d[(v + 3) & 7]));
+        else if (OP == 6) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[v & 7]) : "v"(d[(v + 3) & 7]));
+        else if (OP == 7) asm volatile("v_mov_b32 %0, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 8) asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(e[v & 7]), "v"(e[(v + 3) & 7]) : "vcc");
+        else if (OP == 9) asm volatile("v_add_u32 %0, %0, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 10) { asm volatile("ds_read_b32 %0, %1" : "=v"(e[v & 7]) : "v"(laddr)); if ((v & 7) == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        else if (OP == 11) asm volatile("v_max_f32 %0, %0, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 12) asm volatile("s_nop 0");
+        else if (OP == 13) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc[v & 3]));
+        else if (OP == 14) asm volatile("s_mul_i32 %0, %0, 3" : "+s"(sc[v & 3]));
+        else if (OP == 15) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]), "s"(msk));
+        else if (OP == 16) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 17) asm volatile("v_cvt_f32_i32 %0, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 18) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sc[v & 3]) : "v"(e[v & 7]));
+        else if (OP == 19) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(e[v & 7]) : "s"(sc[v & 3]));
+        else if (OP == 20) asm volatile("s_waitcnt lgkmcnt(0)");
+        else if (OP == 21) asm volatile("v_pk_mov_b32 %0, %1, %1" : "+v"(d[v & 7]) : "v"(d[(v + 3) & 7]));
+        else if (OP == 22) asm volatile("v_mul_f32_e64 %0, %0, %1 clamp" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 23) asm volatile("ds_write_b32 %1, %0" :: "v"(e[v & 7]), "v"(laddr) : "memory");
+        else if (OP == 24) { asm volatile("ds_read_b128 %0, %1" : "=v"(q4[v & 1]) : "v"(laddr4)); if ((v & 7) == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        else if (OP == 25) { asm volatile("global_load_dword %0, %1, off" : "=v"(e[v & 7]) : "v"(src + threadIdx.x + (v & 7) * 512) : "memory"); if ((v & 7) == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else if (OP == 26) asm volatile("v_med3_i32 %0, %0, %1, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else if (OP == 27) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(msk) : "v"(e[v & 7]), "v"(e[(v + 3) & 7]));
+        else if (OP == 28) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(e[v & 7]) : "v"(e[(v + 3) & 7]));
+        else asm volatile("s_nop 0");
+      }
     }
     t1 = clock64(); w1 = wall_clock64();
-    for (int i = 0; i < 8; ++i) s += d[i].x + d[i].y;
+    for (int i = 0; i < 8; ++i) s += d[i].x + d[i].y + e[i];
+    s += (float)(sc[0] + sc[1] + sc[2] + sc[3]) + (float)(msk & 7) + q4[0].x + q4[1].y;
   }
-  out[blockIdx.x * 512 + threadIdx.x] = s;
+  out[blockIdx.x * 512 + threadIdx.x] = s + lds_s[(threadIdx.x + 1) & 511];
   if (lane == 0) { cyc[blockIdx.x * 8 + wave] = t1 - t0; wall[blockIdx.x * 8 + wave] = w1 - w0; }
 }
 
@@ -134,12 +178,12 @@ template <int LDSR, int NV, int VM, int THREADS> void run(const char* name, int 
   report(name, THREADS, tiles, best, 0, THREADS / 64, 64.0, "");
 }
 
-template <int NVW> void run_split(const char* name, int tiles) {
+template <int NVW, int OP = 0> void run_split(const char* name, int tiles) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   float best = 1e30f;
   for (int rep = 0; rep < 4; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k_split<NVW>), dim3(256), dim3(512), 0, 0, g_src, g_out, g_cyc, g_wall, tiles);
+    hipLaunchKernelGGL((k_split<NVW, OP>), dim3(256), dim3(512), 0, 0, g_src, g_out, g_cyc, g_wall, tiles);
     (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep > 0 && ms < best) best = ms;
@@ -148,7 +192,14 @@ template <int NVW> void run_split(const char* name, int tiles) {
   (void)hipMemcpy(hc, g_cyc, sizeof(hc), hipMemcpyDeviceToHost);
   double cv = 0; for (int b = 0; b < 256; ++b) for (int i = 4; i < 8; ++i) cv += hc[b * 8 + i]; cv /= 1024;
   char extra[160];
-  snprintf(extra, sizeof(extra), "  | vector waves: %d v_pk_add_f32 per tile, %.1f cycles each", NVW, NVW ? cv / ((double)NVW * tiles) : 0.0);
+  // what one instruction of the partner costs the SIMD: (kernel time - the MFMA waves' time) / instructions, in cycles at the clock held
+  static long long hw[2048];
+  (void)hipMemcpy(hw, g_wall, sizeof(hw), hipMemcpyDeviceToHost);
+  double cm = 0, wm = 0; for (int b = 0; b < 256; ++b) for (int i = 0; i < 4; ++i) { cm += hc[b * 8 + i]; wm += hw[b * 8 + i]; }
+  const double ghz = cm / wm * 0.1;
+  const double simd_cycles_per_tile = best * 1e-3 * ghz * 1e9 / tiles;
+  snprintf(extra, sizeof(extra), "  | partner: %d per tile; SIMD time per tile %.0f cycles = 4096 + %.2f per partner instruction", NVW,
+           simd_cycles_per_tile, NVW ? (simd_cycles_per_tile - 4096.0) / NVW : 0.0);
   report(name, 512, tiles, best, 0, 4, 64.0, extra);
 }
 
@@ -175,5 +226,20 @@ int main() {
   run_split<192>("split: MFMA | 192 VALU per tile", T);
   run_split<384>("split: MFMA | 384 VALU per tile", T);
   run_split<768>("split: MFMA | 768 VALU per tile", T);
+  run_split<384, 0>("split 384: v_pk_add_f32", T);   run_split<384, 1>("split 384: v_add_f32", T);
+  run_split<384, 2>("split 384: v_fma_f32", T);      run_split<384, 3>("split 384: v_cndmask_b32", T);
+  run_split<384, 4>("split 384: v_mul_f32", T);      run_split<384, 5>("split 384: v_pk_fma_f32", T);
+  run_split<384, 6>("split 384: v_pk_mul_f32", T);   run_split<384, 7>("split 384: v_mov_b32", T);
+  run_split<384, 8>("split 384: v_cmp_gt_f32", T);   run_split<384, 9>("split 384: v_add_u32", T);
+  run_split<384, 10>("split 384: ds_read_b32", T);   run_split<384, 11>("split 384: v_max_f32", T);
+  run_split<384, 12>("split 384: s_nop 0", T);
+  run_split<384, 13>("split 384: s_add_u32", T);     run_split<384, 14>("split 384: s_mul_i32", T);
+  run_split<384, 15>("split 384: v_cndmask_b32_e64 (sgpr mask)", T);   run_split<384, 16>("split 384: v_med3_f32", T);
+  run_split<384, 17>("split 384: v_cvt_f32_i32", T); run_split<384, 18>("split 384: v_readlane_b32", T);
+  run_split<384, 19>("split 384: v_writelane_b32", T); run_split<384, 20>("split 384: s_waitcnt lgkmcnt(0)", T);
+  run_split<384, 21>("split 384: v_pk_mov_b32", T);  run_split<384, 22>("split 384: v_mul_f32 clamp", T);
+  run_split<384, 23>("split 384: ds_write_b32", T);  run_split<384, 24>("split 384: ds_read_b128", T);
+  run_split<384, 25>("split 384: global_load_dword", T); run_split<384, 26>("split 384: v_med3_i32", T);
+  run_split<384, 27>("split 384: v_cmp_gt_f32_e64 (sgpr)", T); run_split<384, 28>("split 384: v_sub_f32", T);
   return 0;
 }

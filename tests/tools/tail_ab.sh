@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
 for flags in "-DTAIL_FIRST_GENERATION" ""; do
   touch adaptive-stereo-icra-2021_amd/csrc/agg_tail.hip
-  make -C adaptive-stereo-icra-2021_amd/csrc EXTRA="$flags" > gpurun_out/tail_ab_build.log 2>&1 || exit 1
+  make -C adaptive-stereo-icra-2021_amd/csrc SCAN=0 EXTRA="$flags" > gpurun_out/tail_ab_build.log 2>&1 || exit 1
   for pairs in ${@:-4}; do
     rm -rf gpurun_out/tail_ab
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tail_ab -o w -- python3 tests/tools/microbench_agg3d.py $pairs > gpurun_out/tail_ab.log 2>&1 || { tail -5 gpurun_out/tail_ab.log; exit 1; }

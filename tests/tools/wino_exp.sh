@@ -6,7 +6,7 @@ n=0
 for flags in "$@"; do
   n=$((n+1))
   touch adaptive-stereo-icra-2021_amd/csrc/conv32_wino.hip adaptive-stereo-icra-2021_amd/csrc/conv32_wino_wgrad.hip
-  make -C adaptive-stereo-icra-2021_amd/csrc EXTRA="$flags" > gpurun_out/wino_exp_build_$n.log 2>&1 || exit 1
+  make -C adaptive-stereo-icra-2021_amd/csrc SCAN=0 EXTRA="$flags" > gpurun_out/wino_exp_build_$n.log 2>&1 || exit 1
   rm -rf gpurun_out/wino_exp_$n
   WMB_ONLY=${WMB_ONLY:-bwd} timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/wino_exp_$n -o w -- python3 tests/tools/wino_microbench.py ${WMB_PAIRS:-4} > gpurun_out/wino_exp_$n.log 2>&1 || exit 1
   echo "== [$flags]"

@@ -87,7 +87,7 @@ for dil in (1, 2, 4, 8):
     nat.call("as_conv32_wino_bwd_fused", nat.ptr(x), g, nat.ptr(g_a), nat.ptr(zz), g, shape, nat.ptr(ww_t), nat.ptr(st.scale),
              nat.ptr(st.shift), nat.ptr(st.mean), nat.ptr(coef), 0.2, nat.ptr(zn), nat.ptr(st.scale), nat.ptr(st.shift),
              nat.ptr(st.mean), nat.ptr(gx), nat.ptr(dW), nat.ptr(db), 1, nat.ptr(nws), nat.ptr(fws1), nat.stream())
-  gens = [int(v) for v in os.environ.get("WMB_GEN", "2").split(",")]      # data-gradient kernel generation(s): "1,2" times both
+  gens = [int(v) for v in os.environ.get("WMB_GEN", "2").split(",") if v]      # data-gradient kernel generation(s): "1,2" times both
   legs = [("wino g%d" % gn, run_wino, gn) for gn in gens]
   legs = legs + [("wino 1L", run_wino_one, None)]           # both gradients in one launch (conv32_wino_bwd.hip)
   if not ONLY_BWD:
