@@ -166,6 +166,9 @@ _SIGNATURES = {
   "as_conv4_wgrad": (c_int, [c_vp, _P(Pcl), c_vp, _P(Pcl), _P(ConvShape), c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_softargmax_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
   "as_softargmax_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+  "as_agg_tail_bwd_ok": (c_int, [_P(Pcl)]),
+  "as_agg_tail_bwd_workspace": (c_i64, [_P(Pcl)]),
+  "as_agg_tail_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, _P(Pcl), c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
   "as_upsample_bilinear_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),
   "as_upsample_bilinear_bwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),
   "as_warp_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -178,6 +181,10 @@ _SIGNATURES = {
                                     c_vp]),
   "as_monodepth_loss_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp,
                                     c_vp, c_vp, c_vp]),
+  "as_photometric_chain_workspace": (c_i64, [c_int, c_int, c_int]),
+  "as_photometric_chain_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
+  "as_photometric_chain_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp]),
+  "as_monodepth_loss_rows_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
   "as_masked_sum_workspace": (c_i64, [c_i64]),
   "as_masked_sum": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
   "as_masked_sum_mean": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),

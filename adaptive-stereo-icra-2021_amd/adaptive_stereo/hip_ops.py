@@ -845,6 +845,16 @@ def set_bwd_fused(flag: bool):
   return prev
 
 
+_TAIL_BWD = True         # False: the tail's backward as three launches (as_softargmax_bwd, then as_conv3d_out_bwd's two)
+
+
+def set_tail_bwd(flag: bool):
+  """Test switch: the one-launch backward of the aggregation tail (csrc/agg_tail_bwd.hip) on / off."""
+  global _TAIL_BWD
+  prev, _TAIL_BWD = _TAIL_BWD, bool(flag)
+  return prev
+
+
 def set_agg_tail(flag: bool):
   global _AGG_TAIL
   prev, _AGG_TAIL = _AGG_TAIL, bool(flag)
@@ -1021,24 +1031,28 @@ class CostAggregationFn(torch.autograd.Function):
     lib = nat.load()
     xs, zs, sts = ctx.xs, ctx.zs, ctx.sts
 
-    g_logits = torch.empty_like(logits)
     g_pred, g_logits_in = f32c(g_pred), f32c(g_logits_in)      # keep any contiguous copies alive past the launch (None = zero)
-    call("as_softargmax_bwd", ptr(logits), ptr(g_pred), ptr(g_logits_in), B, D, H, W, ptr(g_logits), stream())
-
     grads = [None] * 18
     w_out = params[16]
     sinks = ctx.sinks
     g_a = POOL.get(g, dev)
-    ws = _empty(lib.as_conv3d_out_bwd_workspace(g), dev)
-    if _sink(sinks, 16) is not None and _sink(sinks, 17) is not None:
-      call("as_conv3d_out_bwd", ptr(g_logits), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(sinks[16]), ptr(sinks[17]), 1,
-           ptr(ws), stream())
+    into_sinks = _sink(sinks, 16) is not None and _sink(sinks, 17) is not None
+    if into_sinks:
+      g_wout, g_bout = sinks[16], sinks[17]
     else:
-      g_wout = torch.empty_like(w_out)
-      g_bout = _empty(1, dev)
-      call("as_conv3d_out_bwd", ptr(g_logits), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout), 0,
-           ptr(ws), stream())
+      g_wout, g_bout = torch.empty_like(w_out), _empty(1, dev)
       grads[16], grads[17] = g_wout, g_bout
+    if _TAIL_BWD and lib.as_agg_tail_bwd_ok(g) == 1:
+      # soft-argmax backward + both gradients of conv3d_alone in one launch: the logits gradient stays in LDS
+      ws = _empty(lib.as_agg_tail_bwd_workspace(g), dev)
+      call("as_agg_tail_bwd", ptr(logits), ptr(g_pred), ptr(g_logits_in), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(g_wout),
+           ptr(g_bout), 1 if into_sinks else 0, ptr(ws), stream())
+    else:
+      g_logits = torch.empty_like(logits)
+      call("as_softargmax_bwd", ptr(logits), ptr(g_pred), ptr(g_logits_in), B, D, H, W, ptr(g_logits), stream())
+      ws = _empty(lib.as_conv3d_out_bwd_workspace(g), dev)
+      call("as_conv3d_out_bwd", ptr(g_logits), ptr(xs[4]), g, ptr(w_out), ptr(g_a), ptr(g_wout), ptr(g_bout),
+           1 if into_sinks else 0, ptr(ws), stream())
 
     need_feat = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
     for l in range(3, -1, -1):
@@ -1677,9 +1691,9 @@ class MonodepthLossFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------------------
 # The adaptation step's whole loss tail in one Function (adapt.py:78-86: monodepth_single_loss): warp the right image with the
-# predicted disparity, photometric + smoothness loss map, mean over the valid pixels.  Same kernels as LinearWarpFn,
-# MonodepthLossFn and MaskedMeanFn; what disappears is the glue between them — three loss maps nobody reads, the dense
-# gradient map mask * (g / N) and the element-wise launches that build it, the autograd add of the disparity's two gradients.
+# predicted disparity, photometric + smoothness loss map, mean over the valid pixels.  One row-walking pass each way
+# (csrc/photometric_rows.hip) that gives the bits of LinearWarpFn -> MonodepthLossFn -> MaskedMeanFn: no loss map, no dense
+# gradient map mask * (g / N), no coefficient planes and no gradient of the warped image ever reach HBM.
 # ----------------------------------------------------------------------------------------
 class MaskedPhotometricFn(torch.autograd.Function):
   """pred [B,1,H,W], left, right [B,3,H,W] -> (mean, sum, count, warped, valid mask uint8 [B,1,H,W]).
@@ -1696,15 +1710,11 @@ class MaskedPhotometricFn(torch.autograd.Function):
     lib = nat.load()
     warped = torch.empty_like(right)
     mask = torch.empty(B, 1, H, W, dtype=torch.uint8, device=dev)
-    call("as_warp_fwd", ptr(right), ptr(pred), B, C, H, W, 1, ptr(warped), ptr(mask), stream())
-    total = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-    ws = _empty(lib.as_monodepth_workspace(B, H, W), dev)
-    call("as_monodepth_loss_fwd", ptr(pred), ptr(left), ptr(warped), B, H, W, float(smoothness_weight), ptr(total), None, None,
-         None, ptr(ws), stream())
     out3 = _empty(4, dev)                          # sum, count, mean, count (a second copy: the non-differentiable output)
-    ws2 = _empty(lib.as_masked_sum_workspace(total.numel()), dev)
-    call("as_masked_sum_mean", ptr(total), ptr(mask), total.numel(), ptr(out3), ptr(ws2), stream())
-    ctx.save_for_backward(pred, left, right, warped, mask, out3)
+    ws = _empty(lib.as_photometric_chain_workspace(B, H, W), dev)
+    call("as_photometric_chain_fwd", ptr(pred), ptr(left), ptr(right), B, H, W, float(smoothness_weight), ptr(warped), ptr(mask),
+         ptr(out3), ptr(ws), stream())
+    ctx.save_for_backward(pred, left, right, out3)
     ctx.sw = float(smoothness_weight)
     ctx.fwd_ws = ws                          # the forward workspace: its per-image mean disparity is reused by backward
     count = out3[3]
@@ -1714,7 +1724,7 @@ class MaskedPhotometricFn(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, g_mean, g_sum, _g_count, _g_warped, _g_mask):
-    pred, left, right, warped, mask, out3 = ctx.saved_tensors
+    pred, left, right, out3 = ctx.saved_tensors
     if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
       raise NotImplementedError("MaskedPhotometricFn: gradients w.r.t. the images are not part of the adaptation path")
     if g_mean is None and g_sum is None:
@@ -1723,13 +1733,11 @@ class MaskedPhotometricFn(torch.autograd.Function):
     dev = left.device
     g_mean = f32c(g_mean).reshape(1) if g_mean is not None else None
     g_sum = f32c(g_sum).reshape(1) if g_sum is not None else None
-    g_direct, g_warped = torch.empty_like(pred), torch.empty_like(warped)
-    ws = _empty(nat.load().as_monodepth_workspace(B, H, W), dev)
-    call("as_monodepth_loss_bwd_masked", ptr(mask), ptr(g_sum), ptr(g_mean), ptr(out3), ptr(pred), ptr(left), ptr(warped), B, H, W,
-         ctx.sw, ptr(g_direct), ptr(g_warped), ptr(ws), ptr(ctx.fwd_ws), stream())
-    ctx.fwd_ws = None
     g_pred = torch.empty_like(pred)
-    call("as_warp_bwd_add", ptr(g_warped), ptr(right), ptr(pred), ptr(g_direct), B, C, H, W, 1, ptr(g_pred), stream())
+    ws = _empty(nat.load().as_photometric_chain_workspace(B, H, W), dev)
+    call("as_photometric_chain_bwd", ptr(g_sum), ptr(g_mean), ptr(out3), ptr(pred), ptr(left), ptr(right), B, H, W, ctx.sw,
+         ptr(g_pred), ptr(ws), ptr(ctx.fwd_ws), stream())
+    ctx.fwd_ws = None
     return g_pred, None, None, None
 
 

@@ -13,7 +13,7 @@
 // divisions (by 9, by 3, by the mean disparity, n/d) and two expf per pixel, ~600 vector instructions.  Staging 32x8 tiles
 // with a halo in LDS and taking the 54 / 81 window taps from there (same order, same bits; tried in round 2) changed
 // nothing: 73 / 87 / 55 us on a box that runs the step 4 % slower.  Not kept.
-#include "as_common.h"
+#include "photometric_dev.h"
 #pragma clang fp contract(off)
 
 #define PH_BLOCKS_PER_IMAGE 512     // x B workgroups: eight per CU at 4 images
@@ -43,22 +43,7 @@ __global__ __launch_bounds__(64) void image_sum_finalize_kernel(const double* __
   if (threadIdx.x == 0) out[b] = (float)(s * mul);
 }
 
-// ---- division by 9 and by 3 ---------------------------------------------------------------------
-// The kernels divide ~19 times per pixel by these two constants (the reference's avg_pool2d and means divide, so must we,
-// bit for bit) and an IEEE fp32 division is ~12 instructions.  q = x*c, r = fma(-q, y, x), q' = fma(r, c, q) with
-// c = RN(1/y) is the correctly rounded x / y for EVERY finite binary32 x for y = 9 and y = 3, -0 excepted (it comes out
-// as +0): checked exhaustively over all 2^32 bit patterns (tests/tools/div_const.c).  Three instructions.
-__device__ inline float div_const(float x, float y, float c) {
-  const float q = x * c;
-  const float r = __builtin_fmaf(-q, y, x);
-  return __builtin_fmaf(r, c, q);
-}
-__device__ inline float div9(float x) { return div_const(x, 9.f, 1.f / 9.f); }
-__device__ inline float div3(float x) { return div_const(x, 3.f, 1.f / 3.f); }
-
-// ---- shared per-pixel SSIM arithmetic --------------------------------------------------------
-struct SsimTerms { float mux, muy, A1, A2, B1, B2, n, d, raw; };
-
+// ---- shared per-pixel SSIM arithmetic (photometric_dev.h): the 3x3 sums here, the terms there ----------------------
 __device__ inline SsimTerms ssim_at(const float* __restrict__ X, const float* __restrict__ Y, int y, int x, int H, int W) {
   float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
   if (y > 0 && y < H - 1 && x > 0 && x < W - 1) {
@@ -88,36 +73,17 @@ __device__ inline SsimTerms ssim_at(const float* __restrict__ X, const float* __
       }
     }
   }
-  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-  SsimTerms t;
-  t.mux = div9(sx); t.muy = div9(sy);
-  const float sigx = div9(sxx) - t.mux * t.mux;
-  const float sigy = div9(syy) - t.muy * t.muy;
-  const float sigxy = div9(sxy) - t.mux * t.muy;
-  t.A1 = 2.f * t.mux * t.muy + C1;
-  t.A2 = 2.f * sigxy + C2;
-  t.B1 = t.mux * t.mux + t.muy * t.muy + C1;
-  t.B2 = sigx + sigy + C2;
-  t.n = t.A1 * t.A2;
-  t.d = t.B1 * t.B2;
-  t.raw = (1.f - t.n / t.d) / 2.f;
-  return t;
+  return ssim_from_sums(sx, sy, sxx, syy, sxy);
 }
-
-__device__ inline float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
 // edge weights exp(-mean_c |I(p) - I(p+e)|)
 __device__ inline float edge_wx(const float* __restrict__ img, long plane, int y, int x, int W) {
   const long o = (long)y * W + x;
-  const float m = div3(fabsf(img[o] - img[o + 1]) + fabsf(img[plane + o] - img[plane + o + 1]) +
-                       fabsf(img[2 * plane + o] - img[2 * plane + o + 1]));
-  return expf(-m);
+  return edge_weight(img[o], img[o + 1], img[plane + o], img[plane + o + 1], img[2 * plane + o], img[2 * plane + o + 1]);
 }
 __device__ inline float edge_wy(const float* __restrict__ img, long plane, int y, int x, int W) {
   const long o = (long)y * W + x;
-  const float m = div3(fabsf(img[o] - img[o + W]) + fabsf(img[plane + o] - img[plane + o + W]) +
-                       fabsf(img[2 * plane + o] - img[2 * plane + o + W]));
-  return expf(-m);
+  return edge_weight(img[o], img[o + W], img[plane + o], img[plane + o + W], img[2 * plane + o], img[2 * plane + o + W]);
 }
 
 // ---- forward -------------------------------------------------------------------------------------
@@ -201,12 +167,10 @@ __global__ __launch_bounds__(256) void monodepth_bwd_a_kernel(
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const SsimTerms t = ssim_at(I + c * plane, Wp + c * plane, y, x, H, W);
-      const float pass = (t.raw >= 0.f && t.raw <= 1.f) ? 1.f : 0.f;
-      const float Gq = div3(G_ssim) * (-0.5f) * pass;
-      const float d2 = t.d * t.d;
-      cf[(3 * c + 0) * plane] = Gq * ((2.f * t.mux * (t.A2 - t.A1)) * t.d - t.n * (2.f * t.muy * (t.B2 - t.B1))) / d2;
-      cf[(3 * c + 1) * plane] = Gq * (-(t.n * t.B1)) / d2;
-      cf[(3 * c + 2) * plane] = Gq * (2.f * t.A1) / t.d;
+      const SsimCoef k = ssim_coef(t, G_ssim);
+      cf[(3 * c + 0) * plane] = k.a;
+      cf[(3 * c + 1) * plane] = k.b;
+      cf[(3 * c + 2) * plane] = k.c;
     }
     // smoothness: derivative w.r.t. the normalised disparity at this pixel
     const float nd = P[o] / den;
@@ -342,13 +306,16 @@ static PhWs carve(float* ws, int B) {
   return w;
 }
 
-static int image_mean(const float* pred, int B, long plane, PhWs& w, hipStream_t st) {
-  hipLaunchKernelGGL(image_sum_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, pred, plane, w.partial);
+// per-image mean of pred into mean[B] (partial: B x PH_BLOCKS_PER_IMAGE doubles); photometric_rows.hip uses it too
+int as_photometric_image_mean(const float* pred, int B, long plane, double* partial, float* mean, hipStream_t st) {
+  hipLaunchKernelGGL(image_sum_kernel, dim3(PH_BLOCKS_PER_IMAGE, B), dim3(256), 0, st, pred, plane, partial);
   AS_CHECK_LAUNCH("monodepth(mean)");
-  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(B), dim3(64), 0, st, w.partial,
-                     PH_BLOCKS_PER_IMAGE, B, 1.0 / (double)plane, w.mean);
+  hipLaunchKernelGGL(image_sum_finalize_kernel, dim3(B), dim3(64), 0, st, partial, PH_BLOCKS_PER_IMAGE, B, 1.0 / (double)plane, mean);
   AS_CHECK_LAUNCH("monodepth(mean finalize)");
   return AS_OK;
+}
+static int image_mean(const float* pred, int B, long plane, PhWs& w, hipStream_t st) {
+  return as_photometric_image_mean(pred, B, plane, w.partial, w.mean, st);
 }
 
 extern "C" int as_monodepth_loss_fwd(const float* pred, const float* img, const float* warped, int B, int H, int W,

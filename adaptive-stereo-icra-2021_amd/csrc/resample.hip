@@ -7,7 +7,7 @@
 // Both are HBM-bound gathers; one output pixel per lane, W-coalesced.  Arithmetic
 // follows ATen's order of operations (source index = scale*(dst+0.5)-0.5 clamped at 0;
 // grid un-normalisation ((g+1)*size-1)/2; border clip with zero gradient at the clip).
-#include "as_common.h"
+#include "photometric_dev.h"
 
 __device__ inline void bilin_src(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1) {
   float r = scale * ((float)dst + 0.5f) - 0.5f;
@@ -19,102 +19,110 @@ __device__ inline void bilin_src(float scale, int dst, int in_size, int& i0, int
   l0 = 1.f - l1;
 }
 
-__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ src, int B, int h, int w,
-                                                            float* __restrict__ dst, int H, int W, float gain) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)B * H * W) return;
-  const int X = i % W, Y = (i / W) % H, b = i / ((long)W * H);
+// One fine row per workgroup (no per-pixel division), four adjacent pixels per thread and step, one 16-byte store each:
+// the kernel is a 4-byte-per-pixel write stream over an L2-resident source.
+__global__ __launch_bounds__(1024) void upsample_fwd_kernel(const float* __restrict__ src, int B, int h, int w,
+                                                             float* __restrict__ dst, int H, int W, float gain) {
+  const int row = blockIdx.x;                 // b * H + Y
+  const int b = row / H, Y = row - b * H;
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
-  int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+  int y0, y1; float ly0, ly1;
   bilin_src(sh, Y, h, y0, y1, ly0, ly1);
-  bilin_src(sw, X, w, x0, x1, lx0, lx1);
-  const float* s = src + (long)b * h * w;
-  const float top = lx0 * s[y0 * w + x0] + lx1 * s[y0 * w + x1];
-  const float bot = lx0 * s[y1 * w + x0] + lx1 * s[y1 * w + x1];
-  dst[i] = (ly0 * top + ly1 * bot) * gain;
-}
-
-// Adjoint in gather form (deterministic): one wave per coarse pixel, lanes sweep the fine
-// footprint, then a wavefront-shuffle sum.
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ g_dst, int B, int H, int W,
-                                                            float* __restrict__ g_src, int h, int w, float gain) {
-  const int lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pix >= (long)B * h * w) return;
-  const int j = pix % w, i = (pix / w) % h, b = pix / ((long)w * h);
-  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
-  // fine rows/cols whose two source taps can include (i, j)
-  int Y0 = (int)floorf(((float)i - 1.f + 0.5f) / sh - 0.5f) - 1, Y1 = (int)ceilf(((float)i + 1.f + 0.5f) / sh - 0.5f) + 1;
-  int X0 = (int)floorf(((float)j - 1.f + 0.5f) / sw - 0.5f) - 1, X1 = (int)ceilf(((float)j + 1.f + 0.5f) / sw - 0.5f) + 1;
-  Y0 = max(Y0, 0); X0 = max(X0, 0); Y1 = min(Y1, H - 1); X1 = min(X1, W - 1);
-  const int ny = Y1 - Y0 + 1, nx = X1 - X0 + 1;
-  const float* g = g_dst + (long)b * H * W;
-  float acc = 0.f;
-  for (int k = lane; k < ny * nx; k += 64) {
-    const int Y = Y0 + k / nx, X = X0 + k % nx;
-    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
-    bilin_src(sh, Y, h, y0, y1, ly0, ly1);
-    bilin_src(sw, X, w, x0, x1, lx0, lx1);
-    const float wy = (y0 == i ? ly0 : 0.f) + (y1 == i ? ly1 : 0.f);
-    const float wx = (x0 == j ? lx0 : 0.f) + (x1 == j ? lx1 : 0.f);
-    acc += wy * wx * g[(long)Y * W + X];
+  const float* s0 = src + ((long)b * h + y0) * w;
+  const float* s1 = src + ((long)b * h + y1) * w;
+  float* d = dst + (long)row * W;
+  const int mis = (int)(((uintptr_t)d >> 2) & 3);       // the row's first pixel relative to a 16-byte boundary
+  // pieces start at X = 4 * q - mis: aligned stores for every row (the first piece of a misaligned row starts before it)
+  for (int X0 = 4 * (int)threadIdx.x - mis; X0 < W; X0 += 4 * (int)blockDim.x) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int X = min(max(X0 + k, 0), W - 1);
+      int x0, x1; float lx0, lx1;
+      bilin_src(sw, X, w, x0, x1, lx0, lx1);
+      const float top = lx0 * s0[x0] + lx1 * s0[x1];
+      const float bot = lx0 * s1[x0] + lx1 * s1[x1];
+      v[k] = (ly0 * top + ly1 * bot) * gain;
+    }
+    if (X0 >= 0 && X0 + 3 < W) {
+      f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+      *reinterpret_cast<f32x4*>(d + X0) = o;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (X0 + k >= 0 && X0 + k < W) d[X0 + k] = v[k];
+    }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) g_src[pix] = acc * gain;
 }
 
-// ---- LinearWarping -------------------------------------------------------------------------
-struct WarpCoord {
-  float ix, iy;       // clipped sample position
-  float mx, my;       // d(clipped)/d(unclipped): 0 or 1
-  int valid;
-};
-
-__device__ inline float clip_border(float v, int size, float& mult) {
-  const float hi = (float)(size - 1);
-  if (v <= 0.f) { mult = 0.f; return 0.f; }
-  if (v >= hi) { mult = 0.f; return hi; }
-  mult = 1.f;
-  return v;
+// fine rows / columns whose two source taps can include coarse index i
+__device__ inline void footprint(float scale, int i, int fine, int& lo, int& hi) {
+  lo = (int)floorf(((float)i - 1.f + 0.5f) / scale - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.f + 0.5f) / scale - 0.5f) + 1;
+  lo = max(lo, 0); hi = min(hi, fine - 1);
+}
+// weight of coarse index i in fine index D's interpolation
+__device__ inline float tap_weight(float scale, int D, int in_size, int i) {
+  int i0, i1; float l0, l1;
+  bilin_src(scale, D, in_size, i0, i1, l0, l1);
+  return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
 }
 
-__device__ inline WarpCoord warp_coord(int x, int y, float d, int H, int W, int r2l) {
-  WarpCoord c;
-  const float fx = r2l ? (float)x - d : (float)x + d;
-  const float fy = (float)y;
-  const float nx = (2.f * fx) / (float)W - 1.0f;
-  const float ny = (2.f * fy) / (float)H - 1.0f;
-  c.valid = (nx >= -1.0f && nx <= 1.0f && ny >= -1.0f && ny <= 1.0f) ? 1 : 0;
-  const float ux = ((nx + 1.f) * (float)W - 1.f) / 2.f;
-  const float uy = ((ny + 1.f) * (float)H - 1.f) / 2.f;
-  c.ix = clip_border(ux, W, c.mx);
-  c.iy = clip_border(uy, H, c.my);
-  return c;
+// Adjoint, separable and in gather form (deterministic).  One workgroup per (image, coarse row i, chunk of coarse columns):
+//   pass 1  colsum[X] = sum_Y wy(Y, i) * g[Y][X]   one thread per fine column of the chunk's footprint, rows top to bottom:
+//                                                  coalesced row reads, each fine pixel read by the two coarse rows it feeds
+//   pass 2  g_src[i][j] = gain * sum_X wx(X, j) * colsum[X]   one wave per coarse column, lanes over its ~2/scale fine columns
+// (the first generation spent a whole wave on the ~1,150 fine pixels of ONE coarse pixel and recomputed both interpolations
+// for every one of them: 21.6 us at 4 pairs of 375x1242 for 7.4 MB)
+#define UPB_SPAN 1024
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ g_dst, int B, int H, int W,
+                                                            float* __restrict__ g_src, int h, int w, float gain, int chunk) {
+  __shared__ float colsum[UPB_SPAN];
+  const int nchunks = (w + chunk - 1) / chunk;
+  const int c = blockIdx.x % nchunks;
+  const int i = (blockIdx.x / nchunks) % h, b = blockIdx.x / (nchunks * h);
+  const int j0 = c * chunk, j1 = min(j0 + chunk, w);
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  int Y0, Y1, X0, X1, t0, t1;
+  footprint(sh, i, H, Y0, Y1);
+  footprint(sw, j0, W, X0, t1);
+  footprint(sw, j1 - 1, W, t0, X1);
+  const float* g = g_dst + (long)b * H * W;
+  for (int X = X0 + threadIdx.x; X <= X1; X += 256) {
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) acc += tap_weight(sh, Y, h, i) * g[(long)Y * W + X];
+    colsum[X - X0] = acc;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (int j = j0 + (threadIdx.x >> 6); j < j1; j += 4) {
+    int a0, a1;
+    footprint(sw, j, W, a0, a1);
+    float acc = 0.f;
+    for (int X = a0 + lane; X <= a1; X += 64) acc += tap_weight(sw, X, w, j) * colsum[X - X0];
+    acc = wave_sum(acc);
+    if (lane == 0) g_src[((long)b * h + i) * w + j] = acc * gain;
+  }
 }
 
+// ---- LinearWarping (sample geometry and weights: photometric_dev.h, shared with photometric_rows.hip) ---------------
 __global__ __launch_bounds__(256) void warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ disp,
                                                         int B, int C, int H, int W, int r2l,
                                                         float* __restrict__ warped, uint8_t* __restrict__ mask) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)B * H * W) return;
   const int x = i % W, y = (i / W) % H, b = i / ((long)W * H);
-  const WarpCoord c = warp_coord(x, y, disp[i], H, W, r2l);
-  const float fx0 = floorf(c.ix), fy0 = floorf(c.iy);
-  const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
-  const float wx1 = c.ix - fx0, wx0 = (fx0 + 1.f) - c.ix;
-  const float wy1 = c.iy - fy0, wy0 = (fy0 + 1.f) - c.iy;
-  const bool bx1 = x1 <= W - 1, by1 = y1 <= H - 1;   // x0,y0 are always in range after the clip
+  const WarpGeom g = warp_geom(x, y, disp[i], H, W, r2l);
   const long plane = (long)H * W;
   for (int ch = 0; ch < C; ++ch) {
     const float* p = img + ((long)b * C + ch) * plane;
-    const float nw = p[(long)y0 * W + x0];
-    const float ne = bx1 ? p[(long)y0 * W + x1] : 0.f;
-    const float sw = by1 ? p[(long)y1 * W + x0] : 0.f;
-    const float se = (bx1 && by1) ? p[(long)y1 * W + x1] : 0.f;
-    warped[((long)b * C + ch) * plane + (long)y * W + x] =
-        nw * (wx0 * wy0) + ne * (wx1 * wy0) + sw * (wx0 * wy1) + se * (wx1 * wy1);
+    const float nw = p[(long)g.y0 * W + g.x0];      // x0, y0 are always in range after the clip
+    const float ne = g.bx1 ? p[(long)g.y0 * W + g.x0 + 1] : 0.f;
+    const float sw = g.by1 ? p[(long)(g.y0 + 1) * W + g.x0] : 0.f;
+    const float se = (g.bx1 && g.by1) ? p[(long)(g.y0 + 1) * W + g.x0 + 1] : 0.f;
+    warped[((long)b * C + ch) * plane + (long)y * W + x] = warp_interp(nw, ne, sw, se, g);
   }
-  if (mask) mask[i] = (uint8_t)c.valid;
+  if (mask) mask[i] = (uint8_t)g.valid;
 }
 
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__ g_warped, const float* __restrict__ img,
@@ -123,35 +131,32 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)B * H * W) return;
   const int x = i % W, y = (i / W) % H, b = i / ((long)W * H);
-  const WarpCoord c = warp_coord(x, y, disp[i], H, W, r2l);
-  const float fx0 = floorf(c.ix), fy0 = floorf(c.iy);
-  const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
-  const float wy1 = c.iy - fy0, wy0 = (fy0 + 1.f) - c.iy;
-  const bool bx1 = x1 <= W - 1, by1 = y1 <= H - 1;
+  const WarpGeom g = warp_geom(x, y, disp[i], H, W, r2l);
   const long plane = (long)H * W;
   float gix = 0.f;
   for (int ch = 0; ch < C; ++ch) {
     const float* p = img + ((long)b * C + ch) * plane;
-    const float nw = p[(long)y0 * W + x0];
-    const float ne = bx1 ? p[(long)y0 * W + x1] : 0.f;
-    const float sw = by1 ? p[(long)y1 * W + x0] : 0.f;
-    const float se = (bx1 && by1) ? p[(long)y1 * W + x1] : 0.f;
+    const float nw = p[(long)g.y0 * W + g.x0];
+    const float ne = g.bx1 ? p[(long)g.y0 * W + g.x0 + 1] : 0.f;
+    const float sw = g.by1 ? p[(long)(g.y0 + 1) * W + g.x0] : 0.f;
+    const float se = (g.bx1 && g.by1) ? p[(long)(g.y0 + 1) * W + g.x0 + 1] : 0.f;
     const float go = g_warped[((long)b * C + ch) * plane + (long)y * W + x];
-    gix += go * ((ne - nw) * wy0 + (se - sw) * wy1);
+    gix = __builtin_fmaf(go, warp_dix(nw, ne, sw, se, g), gix);
   }
-  // d ix / d nx = W/2 (times the clip multiplier); d nx / d fx = 2/W; d fx / d disp = -/+ 1.
-  const float g_nx = gix * (c.mx * ((float)W / 2.f));
-  const float g_fx = g_nx * (2.f / (float)W);
-  g_disp[i] = (r2l ? -g_fx : g_fx) + (add_src ? add_src[i] : 0.f);
+  g_disp[i] = warp_gdisp(gix, g, W, r2l) + (add_src ? add_src[i] : 0.f);
 }
 
 // ---- host ------------------------------------------------------------------------------------
 extern "C" int as_upsample_bilinear_fwd(const float* src, int B, int h, int w, float* dst, int H, int W,
                                         float gain, void* stream) {
   AS_CHECK_ARG(src && dst && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "as_upsample_bilinear_fwd: bad argument");
-  const long n = (long)B * H * W;
   as_prof_mark(AS_PROF_UPSAMPLE_FWD, (hipStream_t)stream, 1, 0.0);
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, src, B, h, w,
+  const long nblk = (long)B * H;
+  AS_CHECK_ARG(nblk < (1L << 31), "as_upsample_bilinear_fwd: too many rows");
+  // whole waves covering one row in one pass where it fits (1242 pixels: 5 waves), at most 1024 threads
+  int threads = ((W + 3) / 4 + 1 + 63) / 64 * 64;
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)nblk), dim3(threads), 0, (hipStream_t)stream, src, B, h, w,
                      dst, H, W, gain);
   as_prof_mark(AS_PROF_UPSAMPLE_FWD, (hipStream_t)stream, 0, 4.0 * ((double)B * h * w + (double)B * H * W));
   AS_CHECK_LAUNCH("as_upsample_bilinear_fwd");
@@ -161,10 +166,18 @@ extern "C" int as_upsample_bilinear_fwd(const float* src, int B, int h, int w, f
 extern "C" int as_upsample_bilinear_bwd(const float* g_dst, int B, int H, int W, float* g_src, int h, int w,
                                         float gain, void* stream) {
   AS_CHECK_ARG(g_dst && g_src && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "as_upsample_bilinear_bwd: bad argument");
-  const long n = (long)B * h * w;
   as_prof_mark(AS_PROF_UPSAMPLE_BWD, (hipStream_t)stream, 1, 0.0);
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(as_div_up(n, 4)), dim3(256), 0, (hipStream_t)stream, g_dst, B, H, W,
-                     g_src, h, w, gain);
+  // coarse columns per workgroup: as many as keep the chunk's fine footprint ((chunk + 2) / scale + 4 columns) within a
+  // 256-thread row and inside the LDS row of column sums
+  const double inv = (double)W / (double)w;
+  int chunk = (int)((252.0 / inv)) - 2;
+  if (chunk < 1) chunk = 1;
+  if (chunk > w) chunk = w;
+  AS_CHECK_ARG((chunk + 2) * inv + 6.0 <= (double)UPB_SPAN, "as_upsample_bilinear_bwd: scale factor beyond %d fine columns per coarse column", UPB_SPAN / 3);
+  const long nblk = (long)B * h * ((w + chunk - 1) / chunk);
+  AS_CHECK_ARG(nblk < (1L << 31), "as_upsample_bilinear_bwd: too many workgroups");
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, g_dst, B, H, W,
+                     g_src, h, w, gain, chunk);
   as_prof_mark(AS_PROF_UPSAMPLE_BWD, (hipStream_t)stream, 0, 4.0 * ((double)B * h * w + (double)B * H * W));
   AS_CHECK_LAUNCH("as_upsample_bilinear_bwd");
   return AS_OK;

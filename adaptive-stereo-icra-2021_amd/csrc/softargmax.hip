@@ -536,6 +536,14 @@ static inline int out_blocks(long M) {
 #define OUTW_BLOCKS 1024                 // one round of four workgroups per CU; 2048 (two rounds): 70.7 + 9.6 us (kernel + slab reduction) against 69.2 + 6.8
 #endif
 
+// slab reduction of a 32->1 weight gradient: partial [nblocks][ntaps * 32 + 1] -> g_w [32][ntaps], g_bias [1] (agg_tail_bwd.hip too)
+int as_conv32to1_wgrad_reduce(const float* partial, int nblocks, int ntaps, float* g_w, float* g_bias, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(conv32to1_wgrad_reduce_kernel, dim3(as_div_up(ntaps * 32 + 1, 4)), dim3(256), 0, st, partial, nblocks, ntaps,
+                     g_w, g_bias, accumulate);
+  AS_CHECK_LAUNCH("conv32to1 weight gradient (slab reduction)");
+  return AS_OK;
+}
+
 extern "C" int as_conv32to1_fwd(const float* a, const as_pcl* g, const as_conv_shape* s, const float* w,
                                 const float* bias, const float* add_src, int relu, float* out, void* stream) {
   OutConvArgs p;

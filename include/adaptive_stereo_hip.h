@@ -460,6 +460,16 @@ int as_softargmax_fwd(const float* logits, int B, int D, int H, int W,
 int as_softargmax_bwd(const float* logits, const float* g_pred, const float* g_logits_in,
                       int B, int D, int H, int W, float* g_logits, void* stream);
 
+/* The backward of a5 + a4 in ONE launch (csrc/agg_tail_bwd.hip): the logits gradient p_d*(d - pred)*g_pred (+ g_logits_in) is
+ * formed in LDS per (row, 4 disparity planes) and feeds the data gradient g_a and the weight / bias gradient of conv3d_alone from
+ * one read of the activation a; it never reaches HBM.  g_pred [B][H][W], g_logits_in [B][D][H][W]: either may be NULL (zero).
+ * a, g_a: PCL of geometry g; g_w [32][27], g_bias [1] (may be NULL): overwritten, or added to with accumulate != 0.
+ * workspace: as_agg_tail_bwd_workspace(g) floats.  as_agg_tail_bwd_ok(g) == 0: use as_softargmax_bwd + as_conv3d_out_bwd. */
+int as_agg_tail_bwd_ok(const as_pcl* g);
+int64_t as_agg_tail_bwd_workspace(const as_pcl* g);
+int as_agg_tail_bwd(const float* logits, const float* g_pred, const float* g_logits_in, const float* a, const as_pcl* g,
+                    const float* w, float* g_a, float* g_w, float* g_bias, int accumulate, float* workspace, void* stream);
+
 /* ---- generic 32 -> 1 convolution (3x3x3 or 3x3, 'same' padding, any dilation) ----------
  * The 3-D instance is a4 above; the 2-D instance is EdgeAwareRefinement.conv2d_out =
  * nn.Conv2d(32,1,3,padding=1) with the block's tail fused: out = relu(add_src + conv(a) + bias)
@@ -561,6 +571,25 @@ int as_monodepth_loss_bwd_masked(const uint8_t* mask, const float* g_sum, const 
                                  const float* pred, const float* img, const float* warped, int B, int H, int W,
                                  float smoothness_weight, float* g_pred, float* g_warped, float* workspace,
                                  const float* fwd_workspace, void* stream);
+
+/* ---- a9 + a10 + adapt.py:81-83 in one pass each way (csrc/photometric_rows.hip) -----------------------------------------
+ * monodepth_single_loss (adapt.py:78-86): warp the right image with the predicted disparity (models/linear_warping.py:18-57),
+ * monodepth loss map (utils/loss_functions.py:106-138), mean over the valid pixels — as row-walking strips: every input value is
+ * loaded once, the 3x3 windows come from neighbouring lanes and from registers, no intermediate map touches HBM.  Bit for bit
+ * what as_warp_fwd -> as_monodepth_loss_fwd -> as_masked_sum_mean and as_monodepth_loss_bwd_masked -> as_warp_bwd_add give.
+ * pred [B,1,H,W]; left, right, warped [B,3,H,W]; mask uint8 [B,1,H,W]; out4 = {masked sum, count, mean, count}.
+ * workspace: as_photometric_chain_workspace() floats, 16-byte aligned; the backward call takes the forward call's workspace as
+ * fwd_workspace (per-image mean disparity) and its out4.  g_sum / g_mean: device scalars, either may be NULL. */
+int64_t as_photometric_chain_workspace(int B, int H, int W);
+int as_photometric_chain_fwd(const float* pred, const float* left, const float* right, int B, int H, int W,
+                             float smoothness_weight, float* warped, uint8_t* mask, float* out4, float* workspace, void* stream);
+int as_photometric_chain_bwd(const float* g_sum, const float* g_mean, const float* out4, const float* pred, const float* left,
+                             const float* right, int B, int H, int W, float smoothness_weight, float* g_pred, float* workspace,
+                             const float* fwd_workspace, void* stream);
+/* The four loss maps from a given warped image, same strips (any output may be NULL); workspace as above. */
+int as_monodepth_loss_rows_fwd(const float* pred, const float* img, const float* warped, int B, int H, int W,
+                               float smoothness_weight, float* total, float* l1, float* ssim, float* smooth,
+                               float* workspace, void* stream);
 
 /* ---- loss[mask].mean() without a host sync — adapt.py:81-83 --------------------
  * out[0] = sum(v*m), out[1] = count(m); value = out[0]/out[1] is formed by the caller

@@ -245,6 +245,53 @@ def test_out_conv_softargmax_fcs(B, D, H, W, gain):
   assert ga_pred_only is not None
 
 
+@pytest.mark.parametrize("B,D,H,W,with_gin", [(1, 8, 5, 9, True), (2, 12, 6, 19, False), (1, 24, 4, 33, True), (1, 5, 3, 7, False),
+                                              (4, 12, 24, 78, False), (2, 24, 47, 156, True), (1, 3, 1, 1, True)])
+def test_agg_tail_backward_in_one_launch(B, D, H, W, with_gin):
+  """as_agg_tail_bwd (csrc/agg_tail_bwd.hip: the logits gradient formed in LDS, data + weight gradient of conv3d_alone from one
+  read of the activation) against as_softargmax_bwd -> as_conv3d_out_bwd: g_a bit for bit (same taps, same order), g_w / g_bias
+  within the rounding of a different summation order (both against an fp64 sum), overwrite and accumulate."""
+  lib = nat.load()
+  g = Pcl(B, D, H, W, 1, 1, 1)
+  assert lib.as_agg_tail_bwd_ok(g) == 1
+  logits = (rnd(B, D, H, W, seed=1) * 6.0).to(DEV)
+  gp = rnd(B, H, W, seed=2).to(DEV)
+  gin = (rnd(B, D, H, W, seed=3, scale=0.1)).to(DEV) if with_gin else None
+  a = ops.ncdhw_to_pcl(rnd(B, 32, D, H, W, seed=4).to(DEV), g)
+  w = (rnd(1, 32, 3, 3, 3, seed=5, scale=0.05)).to(DEV).contiguous()
+  # reference: three launches
+  g_logits = torch.empty(B, D, H, W, device=DEV)
+  nat.call("as_softargmax_bwd", nat.ptr(logits), nat.ptr(gp), nat.ptr(gin), B, D, H, W, nat.ptr(g_logits), nat.stream())
+  ga_ref = ops.pcl_zeros(g, DEV); gw_ref = torch.empty_like(w); gb_ref = torch.empty(1, device=DEV)
+  ws = torch.empty(lib.as_conv3d_out_bwd_workspace(g), device=DEV)
+  nat.call("as_conv3d_out_bwd", nat.ptr(g_logits), nat.ptr(a), g, nat.ptr(w), nat.ptr(ga_ref), nat.ptr(gw_ref), nat.ptr(gb_ref), 0,
+           nat.ptr(ws), nat.stream())
+  # one launch
+  ga = ops.pcl_zeros(g, DEV); gw = torch.full_like(w, float("nan")); gb = torch.full((1,), float("nan"), device=DEV)
+  ws2 = torch.empty(lib.as_agg_tail_bwd_workspace(g), device=DEV)
+  nat.call("as_agg_tail_bwd", nat.ptr(logits), nat.ptr(gp), nat.ptr(gin), nat.ptr(a), g, nat.ptr(w), nat.ptr(ga), nat.ptr(gw),
+           nat.ptr(gb), 0, nat.ptr(ws2), nat.stream())
+  assert torch.equal(ga, ga_ref), float((ga - ga_ref).abs().max())      # (halo included: nothing written there)
+  # fp64 weight gradient from the same logits gradient
+  a64 = ops.pcl_to_ncdhw(a, g).double().cpu()
+  gl64 = g_logits.double().cpu().unsqueeze(1)
+  gw64 = torch.nn.grad.conv3d_weight(a64, (1, 32, 3, 3, 3), gl64, padding=1).to(DEV)
+  gb64 = gl64.sum().to(DEV)
+  scale = float(gw64.abs().max())
+  e_new, e_old = float((gw.double() - gw64).abs().max()), float((gw_ref.double() - gw64).abs().max())
+  assert e_new <= max(2.0 * e_old, 2e-6 * scale), (e_new, e_old, scale)
+  assert abs(float(gb) - float(gb64)) <= max(2.0 * abs(float(gb_ref) - float(gb64)), 2e-6 * float(gl64.abs().sum()) ** 0.5 + 1e-6)
+  # accumulate into sinks
+  gw2, gb2 = gw.clone(), gb.clone()
+  nat.call("as_agg_tail_bwd", nat.ptr(logits), nat.ptr(gp), nat.ptr(gin), nat.ptr(a), g, nat.ptr(w), nat.ptr(ga), nat.ptr(gw2),
+           nat.ptr(gb2), 1, nat.ptr(ws2), nat.stream())
+  close(gw2, 2.0 * gw, 1e-7 * max(scale, 1e-30), 1e-6, "tail bwd accumulate g_w")
+  close(gb2, 2.0 * gb, 1e-6, 1e-6, "tail bwd accumulate g_bias")
+  from conftest import parity_note
+  parity_note("agg_tail_bwd[B%d D%d %dx%d]" % (B, D, H, W), g_a_bit_identical=True, g_w_max_err_vs_fp64=e_new,
+              three_launches_g_w_max_err_vs_fp64=e_old)
+
+
 def test_softargmax_ties_and_extremes():
   """First maximum wins (torch.argmax semantics); large logits must not overflow."""
   l = torch.zeros(1, 6, 1, 4)
@@ -1741,7 +1788,31 @@ def test_fused_full_resolution_kernels_refuse_unsupported_geometry():
              nat.ptr(st.mean), nat.ptr(buf[3]), nat.ptr(dW), nat.ptr(db), 0, nat.ptr(ws), nat.ptr(fws), nat.stream())
 
 
-@pytest.mark.parametrize("B,H,W", [(1, 41, 67), (2, 96, 256), (1, 375, 1242)])
+@pytest.mark.parametrize("B,H,W", [(1, 2, 2), (3, 8, 11), (1, 41, 67), (2, 33, 59), (1, 17, 60), (2, 9, 61), (1, 19, 62), (1, 12, 63),
+                                   (3, 25, 121), (1, 37, 125), (2, 96, 256), (3, 130, 701), (1, 375, 1242)])
+def test_monodepth_loss_row_strips_equal_the_pixel_kernel(B, H, W):
+  """as_monodepth_loss_rows_fwd (csrc/photometric_rows.hip: a wave walks a strip of rows, 3x3 windows from neighbouring lanes
+  by DPP and from registers) against as_monodepth_loss_fwd (one thread per pixel, every tap loaded): the four loss maps bit for
+  bit — widths around the 62-column blocks, heights below / across the strip height, image planes that are not 16-byte multiples."""
+  lib = nat.load()
+  g = torch.Generator().manual_seed(7 + H + W)
+  img = torch.rand(B, 3, H, W, generator=g).to(DEV)
+  warped = (img.cpu() + (torch.rand(B, 3, H, W, generator=g) - 0.5) * 0.3).clamp(0, 1).to(DEV)
+  pred = (torch.rand(B, 1, H, W, generator=g) * 20 + 0.5).to(DEV)
+  ws_a = torch.empty(lib.as_monodepth_workspace(B, H, W), device=DEV)
+  ws_b = torch.empty(lib.as_photometric_chain_workspace(B, H, W), device=DEV)
+  ref = [torch.full((B, 1, H, W), float("nan"), device=DEV) for _ in range(4)]
+  got = [torch.full((B, 1, H, W), float("nan"), device=DEV) for _ in range(4)]
+  nat.call("as_monodepth_loss_fwd", nat.ptr(pred), nat.ptr(img), nat.ptr(warped), B, H, W, 1e-3, *[nat.ptr(t) for t in ref],
+           nat.ptr(ws_a), nat.stream())
+  nat.call("as_monodepth_loss_rows_fwd", nat.ptr(pred), nat.ptr(img), nat.ptr(warped), B, H, W, 1e-3, *[nat.ptr(t) for t in got],
+           nat.ptr(ws_b), nat.stream())
+  for name, a, b in zip(("total", "l1", "ssim", "smooth"), got, ref):
+    assert bool(torch.isfinite(b).all()) and torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 2, 2), (3, 8, 11), (1, 41, 67), (2, 33, 59), (1, 17, 60), (2, 9, 61), (1, 19, 62), (3, 25, 121),
+                                   (2, 96, 256), (3, 130, 701), (1, 375, 1242), (4, 375, 1242)])
 def test_masked_photometric_loss_in_one_node_equals_the_separate_functions(B, H, W):
   """hip_ops.MaskedPhotometricFn (warp + monodepth loss + masked mean as one autograd node, the gradient map mask * g / N
   never built, the disparity's two gradients added by the warp's backward kernel) against LinearWarpFn -> MonodepthLossFn ->
@@ -1751,7 +1822,7 @@ def test_masked_photometric_loss_in_one_node_equals_the_separate_functions(B, H,
   g = torch.Generator().manual_seed(41)
   left = torch.rand(B, 3, H, W, generator=g).to(DEV)
   right = torch.rand(B, 3, H, W, generator=g).to(DEV)
-  pred0 = (torch.rand(B, 1, H, W, generator=g) * 12.0).to(DEV)
+  pred0 = (torch.rand(B, 1, H, W, generator=g) * min(12.0, W / 4.0)).to(DEV)      # (narrow images: keep some samples inside)
   for use_sum in (False, True):
     p1 = pred0.clone().requires_grad_(True)
     warped, mask = ops.LinearWarpFn.apply(right, p1, True)
@@ -1769,7 +1840,9 @@ def test_masked_photometric_loss_in_one_node_equals_the_separate_functions(B, H,
     assert torch.equal(warped2, warped) and torch.equal(mask2.bool(), mask)
     assert int(count) == int(mask.sum())
     if not use_sum:
-      assert float(mean) == float(ref)
+      # (fp64 partial sums in a different order, rounded to fp32 once: the same float unless the fp64 sum sits on a rounding
+      # boundary)
+      assert abs(float(mean) - float(ref)) <= 1.2e-7 * abs(float(ref))
     else:
       assert abs(float(lsum) - float(ref)) <= 1e-5 * abs(float(ref))
     assert torch.equal(p2.grad, p1.grad), float((p2.grad - p1.grad).abs().max())

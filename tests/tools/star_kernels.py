@@ -23,11 +23,16 @@ table = [
   ("agg_tail_kernel", "a4+a5+a8 fused tail, LDS-staged (+ layer-4 BN/LReLU, by-product)", 2 * V + Lg + 3 * P, None),
   ("agg_tail_direct_kernel", "a4+a5+a8 fused tail (+ layer-4 BN/LReLU, by-product)", 2 * V + Lg + 3 * P, None),
   ("conv3d_wgrad_lds_kernel", "a3 conv3d wgrad (LDS)", None, 2.0 * B * Dc * Hc * Wc * 1024 * 27),
+  ("agg_tail_bwd_kernel", "a4+a5 backward, one launch (softmax bwd + dgrad + wgrad)", 2 * V + Lg + P, None),
   ("conv32to1_fwd_kernel", "a4 conv3d_alone fwd", V + Lg, None),
   ("conv32to1_dgrad_kernel", "a4 dgrad", Lg + V, None), ("conv32to1_wgrad_kernel<27>", "a4 wgrad", V + Lg, None),
   ("softargmax_fwd", "a5+a8 softargmax+FCS fwd", Lg + 3 * P, None), ("softargmax_bwd", "a5 bwd", 2 * Lg + P, None),
   ("upsample_fwd", "a6/a7 bilinear up", P + I1, None), ("upsample_bwd", "a6/a7 bilinear up bwd", I1 + P, None),
   ("warp_fwd", "a9 warp fwd", 3 * I1 + I1 + 3 * I1 + I1 // 4, None), ("warp_bwd", "a9 warp bwd", 3 * I1 + 3 * I1 + 2 * I1, None),
+  ("photo_rows_fwd_kernel<true, true>", "a9+a10 warp + loss + masked sum, one pass (row strips)", (1 + 3 + 3 + 3) * I1 + I1 // 4, None),
+  ("photo_rows_bwd_kernel", "a9+a10 backward, one pass (row strips)", (1 + 3 + 3 + 2) * I1, None),
+  ("rows_mean_term_kernel", "a10 backward: per-image mean term", 3 * I1, None),
+  ("image_sum_kernel", "a10 per-image mean disparity", I1, None),
   ("monodepth_fwd", "a10 loss fwd", (1 + 3 + 3 + 1) * I1, None),
   ("monodepth_bwd_a", "a10 loss bwd A", (1 + 1 + 3 + 3 + 10) * I1, None), ("monodepth_bwd_b", "a10 loss bwd B", (1 + 1 + 3 + 3 + 10 + 1 + 3) * I1, None),
   ("conv32_lds_kernel<0, false>", "a7 conv 3x3 fwd (LDS)", 2 * A, 2.0 * B * H * W * 1024 * 9),
