@@ -46,6 +46,9 @@ def parse():
   ap.add_argument("--no-online", action="store_true", help="skip \"online_batch1\" (the same step and forward at ONE pair per "
                   "step, the reference's own online setting: adapt_*.sh --batch_size 1), measured by default AFTER the "
                   "profiled region; tracing scripts pass this so that a kernel trace holds launches of one size")
+  ap.add_argument("--no-legs", action="store_true", help="skip the side legs \"batch16\" (BASELINE.md 4: a saturating per-GPU "
+                  "batch), \"sceneflow_fwd\" (960x540 forward only, evaluation/stereonet_timing.py:22-41) and \"sustained\" (the captured "
+                  "step replayed for >= 2 s)")
   ap.add_argument("--no-dp-overhead", action="store_true", help="skip \"dp_path_overhead_ms\" (N=1 only: the data-parallel "
                   "step in a one-rank RCCL group minus the plain step, the one scaling-loss term one GPU can measure)")
   ap.add_argument("--one-stream", action="store_true", help="the two feature extractions of a pair back to back on one "
@@ -64,6 +67,19 @@ def log(msg):
 
 
 T0 = time.perf_counter()
+
+
+def csrc_digest():
+  """sha256 over the kernel sources (csrc/*.hip, *.h, sorted by name) — recorded in a PMC summary when its counters are taken
+  (tests/tools/pmc_summarize.py) and compared here: HBM-counter figures of other kernels than the ones this run timed are not
+  reported."""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  d = os.path.join(REPO, "adaptive-stereo-icra-2021_amd", "csrc")
+  for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+    h.update(os.path.basename(path).encode()); h.update(b"\0"); h.update(open(path, "rb").read())
+  return h.hexdigest()[:16]
 
 
 def model_flops(H, W, k, maxdisp):
@@ -370,7 +386,7 @@ def main():
   if not use_graph:
     t_adapt = min(t_adapt, t_adapt_eager)
   prof = []
-  for kid in range(27):
+  for kid in range(28):             # AS_PROF_IDS (csrc/as_common.h)
     n, ms, fl = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
     nat.call("as_prof_read", kid, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
     prof.append((n.value, ms.value, fl.value))
@@ -435,6 +451,9 @@ def main():
       26: ("conv32_wino_kernel<0|1, L>", "conv32_wino_kernel<1, 0>", 4,
            "full-resolution training forward by minimal filtering F(2x2,3x3): previous BatchNorm + LeakyReLU + skip applied on the "
            "way in, by-product written back, raw output + moments"),
+      27: ("conv32_wino_bwd_kernel<L>", "conv32_wino_bwd_kernel<0>", 5,
+           "full-resolution layer backward in ONE launch by minimal filtering: stage 3 of the BatchNorm backward on the way in, data "
+           "gradient F(2x2,3x3) + skip, weight gradient F(3x3,2x2) from the same g_z tiles (g_z never reaches HBM), next BatchNorm's sums"),
       22: ("conv32_bwd_fused_kernel", "conv32_bwd_fused_kernel", 5,
            "full-resolution layer backward in one launch, direct form: BatchNorm-backward apply, data gradient + skip, weight "
            "gradient, next BatchNorm's sums"),
@@ -455,18 +474,28 @@ def main():
     traffic, traffic_detail, traffic_source = None, None, None
     rec = None
     # the newest committed PMC file wins (rocprofv3 --pmc passes cannot run inside this timed process: the counters come
-    # from tests/tools/pmc_run.sh runs of the same kernels at 1, 2 and 4 pairs per launch, committed under profiles/)
-    for name in ("r04_pmc_by_pairs.json", "r03_pmc_by_pairs.json", "r02_pmc_by_pairs.json"):
+    # from tests/tools/pmc_run.sh runs of the same kernels at 1, 2 and 4 pairs per launch, committed under profiles/) — but
+    # only a file whose counters were taken on THESE kernel sources: each summary records the digest of csrc/ it was measured
+    # on; one measured on other sources is named, with the reason, and not used
+    digest_now = csrc_digest()
+    for name in ("r05_pmc_by_pairs.json", "r04_pmc_by_pairs.json", "r03_pmc_by_pairs.json", "r02_pmc_by_pairs.json"):
       by_pairs = os.path.join(REPO, "profiles", name)
       if os.path.exists(by_pairs):
         table = json.load(open(by_pairs))
         keys = sorted(int(k_) for k_ in table if k_.isdigit())
         if keys:
           near = min(keys, key=lambda k_: (abs(k_ - B), -k_))
-          rec = table[str(near)]
+          measured_on = table[str(near)].get("csrc_digest")
           traffic_source = {"file": "profiles/" + name, "pairs_per_launch_measured": near, "exact": near == B,
+                            "csrc_digest_measured_on": measured_on, "csrc_digest_now": digest_now,
+                            "git_commit": table.get("git_commit"),
                             "how": "separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE), "
                                    "tests/tools/pmc_run.sh; per launch; scaled by pairs when not exact"}
+          if measured_on == digest_now:
+            rec = table[str(near)]
+          else:
+            traffic_source["stale"] = ("the counters were taken on other kernel sources (csrc digest %s, now %s): traffic is not "
+                                       "reported" % (measured_on, digest_now))
           break
     if rec is not None:
       ks = rec.get("kernels", {})
@@ -519,7 +548,7 @@ def main():
         e.update({"bound": "mfma", "achieved": views["executed_mfma"]["achieved"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                   "frac": f_mfma})
       return e
-    if dom_id in (24, 25, 26):
+    if dom_id in (24, 25, 26, 27):
       views = wino_views(dom_id, dom)
       roofline.update(views)
       binding(roofline, views)
@@ -530,10 +559,10 @@ def main():
                           "FLOPs / time / matrix peak, kept for comparison with the direct kernels")
     roofline["traffic_detail"] = traffic_detail
     flav = []
-    for i in (24, 25, 26, 22, 23):
+    for i in (27, 24, 25, 26, 22, 23):
       e = entry(i, "%s (%s)" % (NAMES[i][0], NAMES[i][3]))
       if e is not None:
-        if i in (24, 25, 26):
+        if i in (24, 25, 26, 27):
           views = wino_views(i, e)
           e.update({k_: v for k_, v in views.items() if k_ != "algorithm"})
           binding(e, views)
@@ -616,6 +645,69 @@ def main():
     "fwd_ms_per_step": round(1e3 * t_fwd / args.steps, 3),
     "roofline": roofline,
   }
+  if world > 1 and adapter.comm is not None:
+    # what the communicator's first collectives returned (adaptive_stereo/rccl.py, stage "probe"): an all-reduce of ones = the
+    # number of ranks that took part, an all-gather of each rank's HIP device, the library's version
+    out["rccl"] = getattr(adapter.comm, "evidence", None)
+  if world == 1 and use_graph and not args.no_legs:
+    # "sustained": the captured step replayed back to back for >= 2 s (the 20-step region above lasts ~0.15 s)
+    adapter.capture(left, right, warmup=1)
+    sl, sr = adapter.graph_inputs(); sl.copy_(left); sr.copy_(right)
+    adapter.step(sl, sr); torch.cuda.synchronize()
+    n_sus, t_sus = 0, 0.0
+    while t_sus < 2.0:
+      t_sus += timed(lambda: adapter.step(sl, sr), 50, 1); n_sus += 50
+    out["sustained"] = {"ms_per_step": round(1e3 * t_sus / n_sus, 3), "pairs_per_s": round(B * n_sus / t_sus, 3), "steps": n_sus,
+                        "seconds": round(t_sus, 3), "note": "the same captured step, replayed back to back in blocks of 50"}
+    log("sustained: %.3f ms/step over %d steps" % (1e3 * t_sus / n_sus, n_sus))
+    adapter._graph = None
+
+  def side_leg(Bl, Hl, Wl, forward_only, seed):
+    """A fresh pair of networks and an adapter of their own at another batch / image size: (seconds per step, per forward)."""
+    f1, s1 = FeatureExtractorNetwork(args.k), StereoNet(args.k, 1, 0, maxdisp=args.maxdisp)
+    f1.load_state_dict(fsd); s1.load_state_dict(ssd)
+    a1 = OnlineAdapter(f1.to(dev), s1.to(dev), Hl, Wl, lr=5e-5, clip_grad_norm=True, overlap_features=not args.one_stream)
+    l1, r1 = syn.stereo_pair(Bl, Hl, Wl, seed=seed)
+    l1, r1 = l1.to(dev), r1.to(dev)
+    t_step = None
+    if not forward_only:
+      l1s, r1s = l1, r1
+      for _ in range(max(2, args.warmup // 2)):
+        a1.step(l1, r1)
+      if use_graph:
+        a1.capture(l1, r1, warmup=1)
+        g1l, g1r = a1.graph_inputs(); g1l.copy_(l1); g1r.copy_(r1); l1s, r1s = g1l, g1r
+        a1.step(l1s, r1s)
+      torch.cuda.synchronize()
+      t_step = timed(lambda: a1.step(l1s, r1s), args.steps, 1) / args.steps
+    for _ in range(2):
+      a1.infer(l1, r1)
+    li, ri = l1, r1
+    if use_graph:
+      a1.capture_infer(l1, r1)
+      li, ri = a1.infer_inputs(); li.copy_(l1); ri.copy_(r1)
+      a1.infer(li, ri)
+    torch.cuda.synchronize()
+    t_inf = timed(lambda: a1.infer(li, ri), args.steps, 1) / args.steps
+    del a1, f1, s1
+    return t_step, t_inf
+
+  if world == 1 and not args.no_legs:
+    try:
+      if B != 16:
+        t16, t16f = side_leg(16, args.height, args.width, False, 11)
+        out["batch16"] = {"pairs_per_s": round(16 / t16, 3), "ms_per_step": round(1e3 * t16, 3), "fwd_pairs_per_s": round(16 / t16f, 3),
+                          "fwd_ms_per_step": round(1e3 * t16f, 3),
+                          "note": "16 pairs per GPU and step (BASELINE.md 4: a saturating per-GPU batch), same kernels and graphs"}
+        log("batch 16: %.2f ms/step, forward %.2f ms" % (1e3 * t16, 1e3 * t16f))
+      _, tsf = side_leg(B, 540, 960, True, 13)
+      out["sceneflow_fwd"] = {"pairs_per_s": round(B / tsf, 3), "ms_per_forward": round(1e3 * tsf, 3), "pairs_per_gpu": B,
+                              "workload": "SceneFlow Flying 960x540, maxdisp %d, k=%d, forward only (eval, no_grad; BASELINE.json configs[1], "
+                                          "evaluation/stereonet_timing.py:22-41)" % (args.maxdisp, args.k)}
+      log("SceneFlow 960x540 forward: %.2f ms for %d pairs" % (1e3 * tsf, B))
+    except Exception as e:                 # noqa: BLE001 — a side leg must never take the headline line down with it
+      log("side legs failed: %r" % (e,))
+      out["side_legs_error"] = repr(e)[:300]
   if world == 1 and B != 1 and not args.no_online:
     # The reference adapts online, one pair per step (experiments/adaptation/adapt_*.sh: --batch_size 1): the same
     # step at batch 1 next to the headline configuration (fresh networks, its own captured graphs).
