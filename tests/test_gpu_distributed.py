@@ -515,3 +515,49 @@ def test_rccl_data_parallel_step_at_the_bench_workload(tmp_path, golden_loader):
   assert le == lg and torch.equal(pe, pg_)
   from conftest import parity_note
   parity_note("rccl_dp_kitti_b4", loss=loss, ref_loss=gold.scalar("train/loss"), clip_norm_rel_err=abs(norm - ref_norm) / ref_norm)
+
+
+# ----------------------------------------------------------------------------- bench.py --gpus 2, every rung of its ladder
+def _bench_two_ranks(extra_args, extra_env, tmp_path, tag):
+  """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) — rehearsed on ONE GPU: both
+  ranks on device 0, gloo instead of RCCL (AS_BENCH_SINGLE_DEVICE / AS_BENCH_BACKEND: bench.py's own rehearsal switches)."""
+  import json, subprocess, sys
+  repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, AS_BENCH_SINGLE_DEVICE="1", AS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", **extra_env)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+         "--batch", "2", "--no-cpu-baseline"] + list(extra_args)
+  out_path, err_path = tmp_path / ("bench_%s.out" % tag), tmp_path / ("bench_%s.err" % tag)
+  with open(out_path, "w") as fo, open(err_path, "w") as fe:
+    rc = subprocess.run(cmd, stdout=fo, stderr=fe, env=env, timeout=600).returncode
+  err = open(err_path).read()
+  assert rc == 0, err[-3000:]
+  lines = [l for l in open(out_path).read().splitlines() if l.strip()]
+  assert len(lines) == 1, "bench.py must print ONE line on stdout, got %d: %r" % (len(lines), lines[:3])
+  return json.loads(lines[0]), err
+
+
+@pytest.mark.parametrize("rung", ["two_graphs", "capture_fails", "sync_bn"])
+def test_bench_two_rank_rehearsal_reports_its_launch_mode_and_collectives(rung, tmp_path):
+  """Every rung of bench.py's N > 1 ladder runs to its one JSON line and says which rung it took: torch.distributed
+  collectives between two captured graphs (what two gloo ranks can capture); eager launches when a capture fails on a rank
+  (AS_BENCH_TEST_CAPTURE_FAILS: the agreement after each rung takes every rank down the same path); eager launches with
+  cross-replica BatchNorm over torch.distributed collectives (its collectives sit inside forward and backward)."""
+  args, env = {"two_graphs": ([], {}), "capture_fails": ([], {"AS_BENCH_TEST_CAPTURE_FAILS": "1"}),
+               "sync_bn": (["--sync-bn"], {})}[rung]
+  line, err = _bench_two_ranks(args, env, tmp_path, rung)
+  assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 2 and line["scaling"] == "weak"
+  assert line["config"]["pairs_per_gpu"] == 2 and line["config"]["global_batch"] == 4
+  assert line["value"] > 0 and abs(line["value"] - 4 * 3 / (3 * line["ms_per_step"] * 1e-3)) <= 0.01 * line["value"]
+  assert line["metric"].startswith("stereo pairs/sec") and line["dtype"] == "f32" and line["vs_baseline"] is None
+  if rung == "two_graphs":
+    assert line["launch_mode"] == "hipGraph replay of the captured step (2 graphs)"
+    assert line["collectives"] == "torch.distributed, between two graphs"
+    assert "per-replica" in line["config"]["parallelism"]
+  elif rung == "capture_fails":
+    assert line["launch_mode"] == "eager" and line["collectives"] == "torch.distributed, eager"
+    assert "capture failed on rank" in err and "falling back to eager launches" in err
+  else:
+    assert line["launch_mode"] == "eager" and line["collectives"] == "torch.distributed, eager"
+    assert "cross-replica" in line["config"]["parallelism"]
+  assert "rccl" not in line           # (no native communicator over gloo: nothing to give evidence of)
