@@ -1,7 +1,7 @@
 #!/bin/bash
 # pairs/s (fwd+adapt, fwd) at the sizes of SURVEY §8's table; usage (GPU box): tests/tools/config_sweep.sh > gpurun_out/configs.txt
 run() {  # name height width k maxdisp batch
-  out=$(timeout -k 10 300 python bench.py --height $2 --width $3 --k $4 --maxdisp $5 --batch $6 --steps 10 --warmup 3 --no-cpu-baseline --no-online --no-dp-overhead 2>gpurun_out/config_sweep.err | tail -1)
+  out=$(timeout -k 10 300 python bench.py --height $2 --width $3 --k $4 --maxdisp $5 --batch $6 --steps 10 --warmup 3 --no-cpu-baseline --no-online --no-dp-overhead --no-legs 2>gpurun_out/config_sweep.err | tail -1)
   echo "$out" | python -c "
 import json,sys
 try:

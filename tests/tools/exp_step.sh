@@ -11,7 +11,7 @@ for flags in "$@"; do
   for f in $files; do touch adaptive-stereo-icra-2021_amd/csrc/$f; done
   make -C adaptive-stereo-icra-2021_amd/csrc SCAN=0 EXTRA="$flags" > gpurun_out/exp_step_build_$n.log 2>&1 || { tail -5 gpurun_out/exp_step_build_$n.log; exit 1; }
   rm -rf gpurun_out/exp_step_$n
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/exp_step_$n -o e -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-online --no-dp-overhead --no-graph > gpurun_out/exp_step_$n.log 2> gpurun_out/exp_step_$n.err || { tail -5 gpurun_out/exp_step_$n.err; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/exp_step_$n -o e -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-online --no-dp-overhead --no-legs --no-graph > gpurun_out/exp_step_$n.log 2> gpurun_out/exp_step_$n.err || { tail -5 gpurun_out/exp_step_$n.err; exit 1; }
   echo "== [$flags]"
   python3 - "$pat" <<PY
 import csv, glob, re, sys

@@ -5,7 +5,7 @@ tag=${1:-x}
 shift
 extra=${@:---no-graph}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT || exit 1
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o e -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-online --no-dp-overhead $extra > gpurun_out/be.log 2>gpurun_out/be.err || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o e -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-online --no-dp-overhead --no-legs $extra > gpurun_out/be.log 2>gpurun_out/be.err || exit 1
 trace=$(find gpurun_out/prof_$tag -name "e_kernel_trace.csv" | head -1)
 python tests/tools/steady_state.py $trace 10 "$tag steady state ($extra)" > gpurun_out/ss_$tag.txt
 python tests/tools/step_timeline.py $trace fastest > gpurun_out/timeline_$tag.txt
