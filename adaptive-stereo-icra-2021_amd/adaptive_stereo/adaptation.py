@@ -537,10 +537,12 @@ class OnlineAdapter(object):
     torch.cuda.synchronize()
     self.optimizer.step_count_at_capture = self.optimizer.step_count
     self._capture_origin = side.cuda_stream
+    prev_origin = hip_ops.set_fork_origin(side.cuda_stream)      # (the weight gradients launched beside the data gradients)
     try:
       self._capture_graphs(side)
     finally:
       self._capture_origin = None
+      hip_ops.set_fork_origin(prev_origin)
     # capture only records: the python-side counter advanced, the device-side one did not
     self.optimizer.step_count = self.optimizer.step_count_at_capture
     return self

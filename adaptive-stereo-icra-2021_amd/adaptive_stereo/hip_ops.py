@@ -253,6 +253,62 @@ def set_winograd(enabled, backward=None):
   return prev
 
 
+# ----------------------------------------------------------------------------------------
+# Weight-gradient kernels beside the data-gradient chain.  In the backward pass of a layer the weight gradient (reads the
+# layer's input and its output gradient, writes private slabs) and the data gradient (reads the output gradient, writes the
+# input gradient the NEXT layer's backward needs) are independent; where neither fills the chip on its own — the strided head
+# (0.23 / 0.56 of the matrix peak), the 3-D aggregation layers (52 + 50 us on 90 K voxels), the 32->1 output layer — the
+# weight gradient CAN be launched on a side stream at the point the output gradient is ready and joined right behind the data
+# gradient: the same kernels, the same bits, in a captured step two parallel branches of the graph.
+# OFF by default: measured on one box, interleaved (profiles/r05_l_ab_wgrad_beside*.txt), the step is not faster with it —
+# 6.91-7.02 ms against 6.80-6.98 at four pairs, 2.52-2.54 against 2.45-2.46 at one: two kernels that each already occupy every
+# CU slow each other down by what the overlap gains, and the fork / join edges add launch latency.  AS_WGRAD_BESIDE=1 or
+# set_wgrad_beside(True) turns it on (tests/test_gpu_end_to_end.py holds it to the one-stream bits).
+# ----------------------------------------------------------------------------------------
+class _Beside(object):
+  enabled = os.environ.get("AS_WGRAD_BESIDE", "0") == "1"
+  stream = None
+  origin = None          # inside a capture: the handle of the stream that may fork (the capture's origin stream)
+  forks = 0
+
+
+def set_wgrad_beside(flag: bool):
+  prev, _Beside.enabled = _Beside.enabled, bool(flag)
+  return prev
+
+
+def set_fork_origin(handle):
+  """OnlineAdapter tells which stream a capture it opened runs on: a fork from an already forked stream inside a capture
+  crashes hipStreamEndCapture on ROCm 7.2, so inside a capture only that stream forks (anywhere else the body runs inline)."""
+  prev, _Beside.origin = _Beside.origin, handle
+  return prev
+
+
+def fork_beside(fn):
+  """Runs fn() — launches that READ what the current stream has produced so far and WRITE only buffers nobody else touches
+  before join_beside() — on the side stream; returns the handle join_beside() takes (None: fn ran inline)."""
+  main = torch.cuda.current_stream()
+  if (not _Beside.enabled or _BN_SYNC is not None or
+      (torch.cuda.is_current_stream_capturing() and main.cuda_stream != _Beside.origin)):
+    fn()
+    return None
+  if _Beside.stream is None:
+    _Beside.stream = torch.cuda.Stream()
+  side = _Beside.stream
+  side.wait_stream(main)
+  with torch.cuda.stream(side):
+    fn()
+  ev = torch.cuda.Event()
+  ev.record(side)
+  _Beside.forks += 1
+  return ev
+
+
+def join_beside(ev):
+  if ev is not None:
+    torch.cuda.current_stream().wait_event(ev)
+
+
 def _rmw_wait(t):
   if _RmwOrder.enabled and t is not None:
     last = _RmwOrder.last.get(t.data_ptr())
@@ -740,6 +796,7 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
   data gradient and returned as next_sums (None when not available)."""
   sw, sb, sg, sbeta = sinks if sinks is not None else (None, None, None, None)
   lib = nat.load()
+  beside = None
   all_sunk = sw is not None and sb is not None and sg is not None and sbeta is not None
   if _BWD_FUSED and all_sunk and skip and need_dx and train and next_bn is not None and _BN_SYNC is None and \
       lib.as_conv32_bwd_fused_ok(g, g, shape) == 1:
@@ -805,7 +862,12 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
     g_gamma = g_beta = dW = db = None
   else:
     g_z, g_gamma, g_beta = bn_act_bwd(g_out, z, st, gamma, g, train, sg, sbeta, sums)
-    dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
+    if sw is not None and sb is not None and need_dx:
+      # (sunk gradients: nothing comes back to autograd) beside the data gradient below
+      dW = db = None
+      beside = fork_beside(lambda: conv32_wgrad(x, g, g_z, g, shape, True, sw, sb))
+    else:
+      dW, db = conv32_wgrad(x, g, g_z, g, shape, True, sw, sb)
   g_x, next_sums = None, None
   if need_dx:
     wp_t = pack_weights(w, shape, True)
@@ -818,6 +880,7 @@ def block_backward(g_out, x, z, st, w, gamma, g: Pcl, shape: ConvShape, train, s
       g_x = agg3d(g_z, g, wp_t, None, epilogue=2)            # rolling-window kernel: the data gradient of a 3-D layer
     else:
       g_x = conv32(g_z, g, wp_t, None, g, shape, residual=g_out if skip else None)
+  join_beside(beside)
   POOL.put(g_z, g)
   return g_x, dW, db, g_gamma, g_beta, next_sums
 
@@ -1285,12 +1348,18 @@ class FeatureExtractorFn(torch.autograd.Function):
           grads[0], grads[1] = dW, db
       else:
         gprev = geoms[i - 1]
-        dW, db = conv32_wgrad(levels[i - 1], gprev, g_a, gi, CONV5_S2, True, _sink(sinks, 2 * i), _sink(sinks, 2 * i + 1))
-        grads[2 * i], grads[2 * i + 1] = dW, db
+        sw_, sb_ = _sink(sinks, 2 * i), _sink(sinks, 2 * i + 1)
+
+        def head_wgrad(i=i, gprev=gprev, gi=gi, g_a=g_a, sw_=sw_, sb_=sb_):
+          dW, db = conv32_wgrad(levels[i - 1], gprev, g_a, gi, CONV5_S2, True, sw_, sb_)
+          grads[2 * i], grads[2 * i + 1] = dW, db
+        # sunk gradients only: a dW handed back to autograd would be consumed on the main stream
+        ev = fork_beside(head_wgrad) if (sw_ is not None and sb_ is not None) else head_wgrad()
         g_prev = POOL.get(gprev, dev)
         wps = pack_special(wd, PACK_S2_DGRAD, 25, 25 * 1024,
                            lambda w_, o_: call("as_conv32_dgrad_s2_pack", ptr(w_), ptr(o_), stream()))
         call("as_conv32_dgrad_s2_packed", ptr(g_a), gi, ptr(wps), ptr(g_prev), gprev, stream())
+        join_beside(ev)
         POOL.put(g_a, gi)
         g_a = g_prev
     POOL.put(g_a, geoms[0])
@@ -1508,11 +1577,13 @@ class EdgeRefineFn(torch.autograd.Function):
       if _TAIL_BNSUMS and ctx.train and _BN_SYNC is None and lib.as_conv32to1_bnsums_ok(g, s33) == 1:
         # the data gradient also leaves stage 1 of the last block's BatchNorm backward behind (its own pass otherwise)
         nws = _empty(lib.as_bn_bwd_workspace(g), dev)
+        # the weight gradient (reads the last activation and g_pre, adds into its sinks) beside the data gradient
+        ev = fork_beside(lambda: call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), None, ptr(sinks[28]),
+                                      ptr(sinks[29]), 1, ptr(ws), stream()))
         call("as_conv32to1_dgrad_bnsums", ptr(g_pre), g, s33, ptr(w_out), ptr(g_a), ptr(zs[5]), ptr(sts[5].scale),
              ptr(sts[5].shift), ptr(sts[5].mean), LEAKY_SLOPE, ptr(nws), stream())
+        join_beside(ev)
         sums = BnBwdSums(nws, lib.as_conv32to1_bnsums_parts(g))
-        call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), None, ptr(sinks[28]), ptr(sinks[29]), 1,
-             ptr(ws), stream())
       else:
         call("as_conv32to1_bwd", ptr(g_pre), ptr(xs[6]), g, s33, ptr(w_out), ptr(g_a), ptr(sinks[28]), ptr(sinks[29]), 1,
              ptr(ws), stream())

@@ -477,6 +477,43 @@ def test_two_stream_feature_extraction_equals_one_stream():
       assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("H,W,B", [(96, 256, 2), (375, 1242, 1)])
+def test_weight_gradients_beside_the_data_gradients_give_the_same_bits(H, W, B):
+  """hip_ops.fork_beside: in the backward pass the weight gradients of the strided head, of the 3-D aggregation layers and of
+  the refinement's output layer run on a side stream next to the data gradient of the same layer (joined right behind it).
+  The same kernels on the same operands: losses, gradients, weights and BatchNorm buffers must be bit for bit those of the
+  one-stream order — eagerly and in graph replay (where the fork becomes two branches) — and the fork must really happen."""
+  from adaptive_stereo import hip_ops
+  meta = dict(k=4, s=0, maxdisp=192, gain=1.0)
+  batches = [syn.stereo_pair(B, H, W, seed=s) for s in (91, 92, 93)]
+  batches = [(l.to(DEV), r.to(DEV)) for l, r in batches]
+  results, forks = [], []
+  for beside, use_graph in ((False, False), (True, False), (True, True)):
+    prev = hip_ops.set_wgrad_beside(beside)
+    try:
+      f0 = hip_ops._Beside.forks
+      fnet, snet = build(meta)
+      adapter = OnlineAdapter(fnet, snet, H, W, lr=5e-5)
+      adapter.step(*batches[0])
+      if use_graph:
+        adapter.capture(*batches[0], warmup=1)
+      else:
+        adapter.step(*batches[0])
+      losses = [float(adapter.step(l, r)["loss"]) for l, r in batches[1:]]
+      torch.cuda.synchronize()
+      bufs = torch.cat([b.detach().double().reshape(-1) for net in (fnet, snet) for _, b in sorted(net.named_buffers())])
+      results.append((losses, adapter.arena.params.clone(), adapter.arena.grads.clone(), bufs))
+      forks.append(hip_ops._Beside.forks - f0)
+    finally:
+      hip_ops.set_wgrad_beside(prev)
+  assert forks[0] == 0 and forks[1] >= 8 and forks[2] >= 8, forks      # 3 head levels + 4 aggregation layers + the output layer, per step
+  ref = results[0]
+  for got in results[1:]:
+    assert got[0] == ref[0], (got[0], ref[0])
+    for a, b in zip(got[1:], ref[1:]):
+      assert torch.equal(a, b)
+
+
 def test_deferred_weight_gradient_reductions_equal_the_immediate_ones():
   """Inside a step the slab reductions behind the weight-gradient kernels are recorded and run in ONE launch when backward is
   over (as_wgrad_defer / as_wgrad_defer_flush; a layer used by both feature towers is one destination with two jobs, applied
