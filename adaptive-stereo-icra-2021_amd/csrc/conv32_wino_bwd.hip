@@ -166,6 +166,9 @@ __device__ __forceinline__ void fused_w_role(const FusedBwdArgs& q, char* smem) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   float bsum = 0.f;
+#ifdef FB_PRIO_W                                           // (experiment: static issue priority of the weight-gradient waves)
+  __builtin_amdgcn_s_setprio(FB_PRIO_W);
+#endif
   constexpr bool FUSED = true;                             // (for FB_T)
 #ifdef FB_TIMING_BUILD
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

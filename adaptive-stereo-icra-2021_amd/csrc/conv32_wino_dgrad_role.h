@@ -87,6 +87,9 @@ __device__ __forceinline__ void dgrad_role(const DgradArgs& p, char* smem) {
   const int lane = threadIdx.x & 63;
   const int h = lane >> 5, li = lane & 31;
   const int H = p.g.H, W = p.g.W, Wp = p.g.Wp;
+#ifdef FB_PRIO_D                                  // (experiment: static issue priority of the data-gradient waves in the one-launch backward)
+  if constexpr (FUSED) __builtin_amdgcn_s_setprio(FB_PRIO_D);
+#endif
 #ifdef FB_TIMING_BUILD
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   [[maybe_unused]] long long tlast = clock64();
