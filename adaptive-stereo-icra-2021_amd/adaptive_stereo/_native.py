@@ -172,6 +172,7 @@ _SIGNATURES = {
   "as_upsample_bilinear_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),
   "as_upsample_bilinear_bwd": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_float, c_vp]),
   "as_warp_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+  "as_warp_nearest_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
   "as_warp_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
   "as_warp_bwd_add": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
   "as_monodepth_loss_bwd_masked": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_float, c_vp, c_vp, c_vp,

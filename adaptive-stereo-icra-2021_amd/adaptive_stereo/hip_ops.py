@@ -1722,6 +1722,31 @@ class LinearWarpFn(torch.autograd.Function):
     return None, g_disp, None
 
 
+class LinearWarpNearestFn(torch.autograd.Function):
+  """LinearWarping.forward(mode="nearest"): the nearest tap instead of the bilinear blend.  The output is piecewise constant
+  in the disparity: autograd's gradient w.r.t. it is zero (what F.grid_sample returns for the grid in this mode)."""
+
+  @staticmethod
+  def forward(ctx, img, disp, right_to_left):
+    img, disp = f32c(img), f32c(disp)
+    B, C, H, W = img.shape
+    if tuple(disp.shape) != (B, 1, H, W):
+      raise RuntimeError("LinearWarpNearestFn: disparity must be [B,1,H,W]")
+    warped = torch.empty_like(img)
+    mask = torch.empty(B, 1, H, W, dtype=torch.uint8, device=img.device)
+    call("as_warp_nearest_fwd", ptr(img), ptr(disp), B, C, H, W, int(bool(right_to_left)), ptr(warped), ptr(mask), stream())
+    ctx.disp_shape = disp.shape
+    mask = mask.bool()
+    ctx.mark_non_differentiable(mask)
+    return warped, mask
+
+  @staticmethod
+  def backward(ctx, g_warped, _g_mask):
+    if ctx.needs_input_grad[0]:
+      raise NotImplementedError("LinearWarpNearestFn: gradient w.r.t. the image is not part of the adaptation path")
+    return None, torch.zeros(ctx.disp_shape, dtype=g_warped.dtype, device=g_warped.device), None
+
+
 # ----------------------------------------------------------------------------------------
 # a10: monodepth photometric loss (utils/loss_functions.py:106-138)
 # ----------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ but samples with align_corners=False, so the tap is at (x -/+ d - 0.5, y - 0.5))
 import torch.nn as nn
 
 from .. import _native as nat
-from ..hip_ops import LinearWarpFn
+from ..hip_ops import LinearWarpFn, LinearWarpNearestFn
 
 
 class LinearWarping(nn.Module):
@@ -22,9 +22,12 @@ class LinearWarping(nn.Module):
     """img [B,C,H,W], positive_disp [B,1,H,W] -> (warped [B,C,H,W], valid_mask bool [B,1,H,W]).
     right_to_left=True synthesises the left view from a right image: L'(x,y) = R(x - d(x,y), y)."""
     nat.require_gpu(img, positive_disp)
-    if mode != "bilinear":
-      raise NotImplementedError("LinearWarping: only bilinear sampling is implemented")
+    if mode not in ("bilinear", "nearest"):
+      raise NotImplementedError("LinearWarping: mode %r (the reference forwards it to F.grid_sample; bilinear and nearest "
+                                "are implemented, no caller uses another)" % (mode,))
     b, c, h, w = img.shape
     assert h == self._height
     assert w == self._width
+    if mode == "nearest":
+      return LinearWarpNearestFn.apply(img, positive_disp, bool(right_to_left))
     return LinearWarpFn.apply(img, positive_disp, bool(right_to_left))

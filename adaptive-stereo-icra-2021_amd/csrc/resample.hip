@@ -88,9 +88,19 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   footprint(sw, j0, W, X0, t1);
   footprint(sw, j1 - 1, W, t0, X1);
   const float* g = g_dst + (long)b * H * W;
+  // the row weights are the same for every column: once per workgroup (up to 256 footprint rows), not once per thread and row
+  __shared__ float wy_tab[256];
+  const int ny = Y1 - Y0 + 1;
+  const bool tab = ny <= 256;
+  if (tab && (int)threadIdx.x < ny) wy_tab[threadIdx.x] = tap_weight(sh, Y0 + threadIdx.x, h, i);
+  __syncthreads();
   for (int X = X0 + threadIdx.x; X <= X1; X += 256) {
     float acc = 0.f;
-    for (int Y = Y0; Y <= Y1; ++Y) acc += tap_weight(sh, Y, h, i) * g[(long)Y * W + X];
+    if (tab) {
+      for (int Y = Y0; Y <= Y1; ++Y) acc += wy_tab[Y - Y0] * g[(long)Y * W + X];
+    } else {
+      for (int Y = Y0; Y <= Y1; ++Y) acc += tap_weight(sh, Y, h, i) * g[(long)Y * W + X];
+    }
     colsum[X - X0] = acc;
   }
   __syncthreads();
@@ -144,6 +154,22 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const float* __restrict__
     gix = __builtin_fmaf(go, warp_dix(nw, ne, sw, se, g), gix);
   }
   g_disp[i] = warp_gdisp(gix, g, W, r2l) + (add_src ? add_src[i] : 0.f);
+}
+
+// grid_sample(mode="nearest", padding_mode="border", align_corners=False): the tap nearest to the clipped sample position,
+// ties to even (std::nearbyint, as ATen).  No gradient reaches the disparity (a piecewise-constant function of the grid).
+__global__ __launch_bounds__(256) void warp_nearest_kernel(const float* __restrict__ img, const float* __restrict__ disp,
+                                                            int B, int C, int H, int W, int r2l,
+                                                            float* __restrict__ warped, uint8_t* __restrict__ mask) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * H * W) return;
+  const int x = i % W, y = (i / W) % H, b = i / ((long)W * H);
+  const WarpGeom g = warp_geom(x, y, disp[i], H, W, r2l);
+  const int xn = min((int)rintf((float)g.x0 + g.wx1), W - 1), yn = min((int)rintf((float)g.y0 + g.wy1), H - 1);
+  const long plane = (long)H * W;
+  for (int ch = 0; ch < C; ++ch)
+    warped[((long)b * C + ch) * plane + (long)y * W + x] = img[((long)b * C + ch) * plane + (long)yn * W + xn];
+  if (mask) mask[i] = (uint8_t)g.valid;
 }
 
 // ---- host ------------------------------------------------------------------------------------
@@ -210,4 +236,14 @@ extern "C" int as_warp_bwd_add(const float* g_warped, const float* img, const fl
 extern "C" int as_warp_bwd(const float* g_warped, const float* img, const float* disp, int B, int C, int H, int W,
                            int right_to_left, float* g_disp, void* stream) {
   return as_warp_bwd_add(g_warped, img, disp, nullptr, B, C, H, W, right_to_left, g_disp, stream);
+}
+
+extern "C" int as_warp_nearest_fwd(const float* img, const float* disp, int B, int C, int H, int W, int right_to_left,
+                                   float* warped, uint8_t* mask, void* stream) {
+  AS_CHECK_ARG(img && disp && warped && B > 0 && C > 0 && H > 0 && W > 0, "as_warp_nearest_fwd: bad argument");
+  const long n = (long)B * H * W;
+  hipLaunchKernelGGL(warp_nearest_kernel, dim3(as_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, img, disp, B, C, H,
+                     W, right_to_left, warped, mask);
+  AS_CHECK_LAUNCH("as_warp_nearest_fwd");
+  return AS_OK;
 }

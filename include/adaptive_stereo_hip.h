@@ -545,6 +545,10 @@ int as_warp_fwd(const float* img, const float* disp, int B, int C, int H, int W,
                 float* warped, uint8_t* mask, void* stream);
 int as_warp_bwd(const float* g_warped, const float* img, const float* disp, int B, int C, int H, int W,
                 int right_to_left, float* g_disp, void* stream);
+/* LinearWarping.forward(mode="nearest") (models/linear_warping.py:57 forwards `mode` to F.grid_sample): the nearest tap of the
+ * clipped sample position, ties to even; same validity mask.  No gradient w.r.t. the disparity exists in this mode. */
+int as_warp_nearest_fwd(const float* img, const float* disp, int B, int C, int H, int W, int right_to_left,
+                        float* warped, uint8_t* mask, void* stream);
 /* The same with g_disp = (gradient through the warp) + add_src[i] (add_src may be NULL): the disparity receives its gradient
  * from the loss map directly and through the warped image (adapt.py:78-86) — the sum autograd would form in a launch of its own. */
 int as_warp_bwd_add(const float* g_warped, const float* img, const float* disp, const float* add_src, int B, int C,

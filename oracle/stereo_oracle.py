@@ -187,7 +187,7 @@ def feature_contrast_mean(logits):
 # a9 — LinearWarping (models/linear_warping.py:18-57). Normalises with 2x/w - 1
 # but samples with align_corners=False, i.e. at (x - d - 0.5, y - 0.5).
 # --------------------------------------------------------------------------
-def linear_warp(img, disp, right_to_left: bool = True):
+def linear_warp(img, disp, right_to_left: bool = True, mode: str = "bilinear"):
   b, c, h, w = img.shape
   ys, xs = torch.meshgrid(torch.arange(h, device=img.device), torch.arange(w, device=img.device), indexing="ij")
   gx = xs.float().unsqueeze(0).expand(b, -1, -1)
@@ -198,7 +198,7 @@ def linear_warp(img, disp, right_to_left: bool = True):
   ny = 2 * gy / h - 1.0
   grid = torch.stack([nx, ny], dim=-1)
   valid = ((nx >= -1.0) & (nx <= 1.0) & (ny >= -1.0) & (ny <= 1.0)).unsqueeze(1)
-  warped = F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=False)
+  warped = F.grid_sample(img, grid, mode=mode, padding_mode="border", align_corners=False)   # (linear_warping.py:57)
   return warped, valid
 
 

@@ -342,6 +342,44 @@ def test_linear_warp(B, H, W, r2l):
   close(dd.grad, d.grad, 2e-5, 1e-4, "warp bwd")
 
 
+@pytest.mark.parametrize("r2l", [True, False])
+def test_linear_warp_nearest_mode(r2l):
+  """LinearWarping(..., mode="nearest") (the reference forwards `mode` to F.grid_sample, models/linear_warping.py:57).  The
+  reference's grid puts EVERY sample exactly half-way between two rows (y - 0.5: it normalises with 2y/h - 1 and samples with
+  align_corners=False), so which of the two rows "nearest" picks is decided by the last bit of the un-normalisation — in ATen
+  as here.  The test therefore accepts, per pixel, the oracle's value for the sample position itself or nudged by 1e-3 of a
+  pixel up or down, and excludes columns within 1e-3 of a horizontal tie; the validity mask is exact; the disparity receives a
+  zero gradient; other modes raise."""
+  from adaptive_stereo.models.linear_warping import LinearWarping
+  import torch.nn.functional as F
+  B, H, W = 2, 33, 70
+  img = rnd(B, 3, H, W, seed=1) * 0.5 + 0.5
+  disp = (rnd(B, 1, H, W, seed=2) * 6.0 + 4.0)
+  _, mask_ref = orc.linear_warp(img, disp, r2l, mode="nearest")
+  ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+  gx = xs.float().unsqueeze(0) - disp[:, 0] if r2l else xs.float().unsqueeze(0) + disp[:, 0]
+  gy = ys.float().unsqueeze(0).expand(B, -1, -1)
+  refs = []
+  for nudge in (0.0, 1e-3, -1e-3):
+    grid = torch.stack([2 * gx / W - 1.0, 2 * (gy + nudge) / H - 1.0], dim=-1)
+    refs.append(F.grid_sample(img, grid, mode="nearest", padding_mode="border", align_corners=False))
+  dd = disp.to(DEV).requires_grad_(True)
+  warped, mask = LinearWarping(H, W)(img.to(DEV), dd, mode="nearest", right_to_left=r2l)
+  assert torch.equal(mask.cpu(), mask_ref)
+  got = warped.detach().cpu()
+  ok = torch.zeros(B, 1, H, W, dtype=torch.bool)
+  for r in refs:
+    ok |= (got == r).all(dim=1, keepdim=True)
+  pos = gx.unsqueeze(1) - 0.5
+  near_tie = ((pos - pos.floor()) - 0.5).abs() < 1e-3
+  assert not bool((~ok & ~near_tie).any()), int((~ok & ~near_tie).sum())
+  assert int((~ok).sum()) <= 0.01 * ok.numel()
+  warped.sum().backward()
+  assert float(dd.grad.abs().max()) == 0.0
+  with pytest.raises(NotImplementedError):
+    LinearWarping(H, W)(img.to(DEV), dd, mode="bicubic")
+
+
 # ----------------------------------------------------------------------------- a10
 @pytest.mark.parametrize("B,H,W", [(1, 8, 11), (2, 37, 53)])
 def test_monodepth_loss_fwd_bwd(B, H, W):
