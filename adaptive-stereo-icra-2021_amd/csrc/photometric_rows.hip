@@ -470,19 +470,28 @@ __global__ __launch_bounds__(256) void rows_mean_term_kernel(const float* __rest
   }
 }
 
-// strip height: the tallest of these that still gives every SIMD two waves (halo rows are recomputed: 2 / 4 per strip)
-int pick_rows(int B, int H, int ncb) {
-  const int cand[] = {32, 24, 16, 12, 8};
-  for (int R : cand)
-    if ((long)B * ((H + R - 1) / R) * ncb >= 2048) return R;
-  return 8;
+// Strip height.  A wave walks R + 2 * halo rows for R rows of output and a SIMD works through its waves at the full vector
+// issue rate only with two or more of them resident, so the launch lasts about ceil(waves / 1024 SIMDs) * (R + 2 * halo) row
+// steps (twice that while there is at most one wave per SIMD): the candidate with the smallest product, the taller on a tie.
+// 4 pairs of 375 x 1242: 16 rows (2,016 waves: two per SIMD, 18 / 20 steps each); 32 pairs: 64; one pair: 8.
+int pick_rows(int B, int H, int ncb, int halo) {
+  const int cand[] = {64, 48, 32, 24, 20, 16, 12, 8};
+  int best = 8;
+  long best_cost = -1;
+  for (int R : cand) {
+    const long waves = (long)B * ((H + R - 1) / R) * ncb;
+    const long per = (waves + 1023) / 1024;
+    const long cost = per * (R + 2 * halo) * (per <= 1 ? 2 : 1);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = R; }
+  }
+  return best;
 }
 
 RowsGeom make_geom(int B, int H, int W, int halo) {
   RowsGeom g;
   g.B = B; g.H = H; g.W = W;
   g.ncb = (W + (64 - 2 * halo) - 1) / (64 - 2 * halo);
-  g.R = pick_rows(B, H, g.ncb);
+  g.R = pick_rows(B, H, g.ncb, halo);
   g.nstrips = (H + g.R - 1) / g.R;
   return g;
 }
