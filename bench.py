@@ -597,10 +597,11 @@ def main():
     star = [(10, "a2 cost volume fwd"), (11, "a2 cost volume bwd"),
             (8, "a4+a5+a8 conv3d_alone + soft-argmax + arg-max + FCS fwd (one launch, with layer 4's BatchNorm + LeakyReLU)"),
             (20, "a4 conv3d_alone fwd (separate launch)"), (21, "a5+a8 soft-argmax + FCS fwd (separate launch)"),
-            (12, "a4 conv3d_alone bwd (data + weight gradient)"), (13, "a5 soft-argmax bwd"),
+            (12, "a4+a5 soft-argmax + conv3d_alone bwd (data + weight gradient; one launch + slab reduction since round 5)"), (13, "a5 soft-argmax bwd (separate launch)"),
             (14, "a6/a7 bilinear up-sampling fwd"), (15, "a6/a7 bilinear up-sampling bwd"),
             (16, "a9 LinearWarping fwd"), (17, "a9 LinearWarping bwd"),
-            (18, "a10 monodepth loss fwd (image mean + SSIM/L1/smoothness)"), (19, "a10 monodepth loss bwd (two passes)")]
+            (18, "a9+a10 LinearWarping + monodepth loss + masked sum fwd (image mean + one row-strip pass)"),
+            (19, "a9+a10 backward (one row-strip pass + the per-image mean term)")]
     roofline["hbm_rows"] = [dict(e, row=nm.split(" ")[0]) for e, nm in ((hbm_entry(i, nm_), nm_) for i, nm_ in star) if e is not None]
 
   mf = model_flops(args.height, args.width, args.k, args.maxdisp)
