@@ -18,8 +18,8 @@
 // so a tile costs the SIMD 128 MFMAs + all vector work; what the pairing buys is that nobody WAITS: the weight-gradient waves
 // run tile j's matrix steps between the data gradient's barriers B1 and B2 (its conversion / epilogue phase: HBM round trips,
 // LDS traffic), and sit at the barrier during its matrix phase.
-//   P1 (B2 of tile j-2 .. B1): data-gradient matrix phase on rows j-1 .. j+2;  weight-gradient waves: their x rows are home
-//   P2 (B1 .. B2):            conversion of rows j+3, j+4 + output rows;       weight-gradient matrix steps on rows j, j+1 / x rows
+//   P1 (B2 of tile j-2 .. B1): data-gradient matrix phase on rows j-1 .. j+2;  weight-gradient waves: the first FB_K1 matrix steps
+//   P2 (B1 .. B2):            conversion of rows j+3, j+4 + output rows;       the other weight-gradient matrix steps (rows j, j+1 / x rows)
 // Rows j, j+1 of g_z must therefore outlive B1 while rows j+3, j+4 are written: a ring of FIVE rows (row r in slot r mod 5).
 //
 // Shared columns.  The last 64-pixel segment of a row is shifted back to end at the image edge (conv32_wino.hip); its neighbour
@@ -41,6 +41,10 @@
 
 #ifndef FB_GRID
 #define FB_GRID 256
+#endif
+#ifndef FB_K1
+#define FB_K1 6                       // weight-gradient steps of a tile (of 16) that run beside the data gradient's matrix phase: 0 .. 16 swept,
+                                      // 4-6 best by 1-3 % per launch, 0.4 % of a step (profiles/r05_s_ab_*: the pipe is the same pipe)
 #endif
 
 template <int L> struct FbGeo {
@@ -80,9 +84,10 @@ template <int L> __host__ __device__ constexpr int fb_swz(int v) {
 // The sixteen matrix steps of one tile (rows j, j+1 of g_z; rows j-1 .. j+2 of x) for the wave that owns row RW of the transformed
 // tiles.  Step s takes tiles s (lanes 0-31) and s + 16 (lanes 32-63: 32 voxels further in both rings, the same swizzle key).
 // MASKED: g_z values of columns >= keep are not this segment's (kh = keep - 32 * half).
-template <int RW, int L, bool MASKED>
+template <int RW, int L, bool MASKED, int S0, int S1>
 __device__ __forceinline__ void fb_w_steps(f32x16 (&acc)[4], float& bsum, const char* smem, int xa_base, int xb_base,
                                            const int (&g0_base)[8], const int (&g1_base)[8], int kh) {
+  if constexpr (S0 >= S1) return;
   using G = DgGeo<L, true>;
   constexpr int d = 1 << L;
   float xa[2][4], xb[2][4], g0[2][2], g1[2][2];
@@ -106,10 +111,10 @@ __device__ __forceinline__ void fb_w_steps(f32x16 (&acc)[4], float& bsum, const 
       }
     }
   };
-  load_step(0, xa[0], xb[0], g0[0], g1[0]);
+  load_step(S0, xa[S0 & 1], xb[S0 & 1], g0[S0 & 1], g1[S0 & 1]);
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    if (s + 1 < 16) load_step(s + 1, xa[(s + 1) & 1], xb[(s + 1) & 1], g0[(s + 1) & 1], g1[(s + 1) & 1]);
+  for (int s = S0; s < S1; ++s) {
+    if (s + 1 < S1) load_step(s + 1, xa[(s + 1) & 1], xb[(s + 1) & 1], g0[(s + 1) & 1], g1[(s + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
     // both transforms on packed instructions (conv32_wino_wgrad.hip: the same sequences, the same hazard padding)
     const fb_f32x2 u0 = {g0[s & 1][0], g0[s & 1][1]}, u1 = {g1[s & 1][0], g1[s & 1][1]};
@@ -207,12 +212,13 @@ __device__ __forceinline__ void fused_w_role(const FusedBwdArgs& q, char* smem) 
     __syncthreads();                                       // (= the data gradient's barrier behind its run-in)
     FB_T(0);
 
+    // Everything tile j's matrix steps read is in LDS when the barrier B2 of tile j-2 opens (g_z rows j, j+1 were converted
+    // during tiles j-4 and j-2; the x rows are home: see the wait below) and nothing overwrites it before B1 of tile j+2, so
+    // the first FB_K1 of the sixteen steps run BESIDE the data gradient's matrix phase (between B2 and B1): the SIMD then has
+    // two waves with matrix work, and one's LDS / issue stalls are filled by the other's MFMAs.  FB_K1 = 0 is the schedule
+    // of the header (every step between B1 and B2).
     for (int j = j0; j < j1; j += 2) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the rows requested a tile ago (rows j+1, j+2) are home
-      FB_T(6);
-      __syncthreads();                                     // B1
-      FB_T(3);
-      if (j + 2 < j1)                                      // rows j+3, j+4 into the two slots nobody reads
+      if (j + 2 < j1)                                      // rows j+3, j+4 into the two slots nobody reads (last read: tile j-2's steps)
         for (int i = RW; i < 2 * NPC; i += 4) issue_row(j + 3 + i / NPC, i % NPC);
       const int xa_base = x_lane + F::xslot(j - 1 + ra) * F::XROWB;
       const int xb_base = x_lane + F::xslot(j - 1 + rb) * F::XROWB;
@@ -220,9 +226,16 @@ __device__ __forceinline__ void fused_w_role(const FusedBwdArgs& q, char* smem) 
       const int s0 = G::slot(j) * G::ROWB, s1 = G::slot(j + 1) * G::ROWB;
 #pragma unroll
       for (int S = 0; S < 8; ++S) { g0_base[S] = g_lane[S] + s0; g1_base[S] = g_lane[S] + s1; }
-      if (keep < 64) fb_w_steps<RW, L, true>(acc, bsum, smem, xa_base, xb_base, g0_base, g1_base, kh);
-      else fb_w_steps<RW, L, false>(acc, bsum, smem, xa_base, xb_base, g0_base, g1_base, kh);
+      if (keep < 64) fb_w_steps<RW, L, true, 0, FB_K1>(acc, bsum, smem, xa_base, xb_base, g0_base, g1_base, kh);
+      else fb_w_steps<RW, L, false, 0, FB_K1>(acc, bsum, smem, xa_base, xb_base, g0_base, g1_base, kh);
+      FB_T(1);
+      __syncthreads();                                     // B1
+      FB_T(3);
+      if (keep < 64) fb_w_steps<RW, L, true, FB_K1, 16>(acc, bsum, smem, xa_base, xb_base, g0_base, g1_base, kh);
+      else fb_w_steps<RW, L, false, FB_K1, 16>(acc, bsum, smem, xa_base, xb_base, g0_base, g1_base, kh);
       FB_T(4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the rows requested at the top of this tile are home before B2: every wave may read them after it
+      FB_T(6);
       __syncthreads();                                     // B2
       FB_T(5);
     }
