@@ -908,6 +908,15 @@ def set_bwd_fused(flag: bool):
   return prev
 
 
+# Who merges a train-mode BatchNorm's per-workgroup partials: the consuming kernel (up to this many partials) or a finalize
+# launch in front of it.  Measured inside a step at 4 pairs, same box, interleaved (tests/tools/ab_env_step.sh,
+# profiles/r05_u_ab_*_merge.txt):
+#   the tail kernel (one wave per SIMD, 234 workgroups, each merging on its own): 38.9 us merging itself against 7.6 + 22.4 us
+#     with a finalize launch -> the launch wins by 9 us: 0;
+#   aggregation layers 2-4: 71.0 us merging themselves against 7.8 + 62.0 us -> a wash, and a launch boundary more in the replayed
+#     graph: they keep merging (512; beyond that the reads through L2 grow quadratically).
+_TAIL_MERGE_MAX = int(os.environ.get("AS_TAIL_MERGE_MAX", "0"))
+_AGG_MERGE_MAX = int(os.environ.get("AS_AGG_MERGE_MAX", "512"))
 _TAIL_BWD = True         # False: the tail's backward as three launches (as_softargmax_bwd, then as_conv3d_out_bwd's two)
 
 
@@ -1004,7 +1013,7 @@ class CostAggregationFn(torch.autograd.Function):
       # every workgroup of the consumer merges ALL of the producer's partials: fine for a few hundred (240 at 4 KITTI pairs),
       # quadratic beyond (k = 3 volumes: 1,632 workgroups x 1,632 partials = 0.7 GB through L2 per layer, measured 2x the
       # layer's time) — there one finalize launch per layer is the cheaper form
-      merge_in_consumer = nparts <= 512
+      merge_in_consumer = nparts <= _AGG_MERGE_MAX
       x, prev = vol, None
       for l in range(4):
         w, b, gamma, beta = params[4 * l:4 * l + 4]
@@ -1049,7 +1058,7 @@ class CostAggregationFn(torch.autograd.Function):
         # one launch: layer 4's BatchNorm (merged from its partials) + LeakyReLU on the way in, 32->1 convolution,
         # soft-argmax, arg-max, FCS
         a4 = POOL.get(g, dev) if need_bwd else None
-        if bn4.stats.nparts <= 512:
+        if bn4.stats.nparts <= _TAIL_MERGE_MAX:
           _rmw_wait(bn4.rm)
           call("as_agg_tail_fwd", ptr(z4), g, None, None, bn4.block, ptr(a4), ptr(w_out), ptr(b_out), LEAKY_SLOPE,
                ptr(logits), ptr(pred), ptr(argmax), ptr(fcs), stream())

@@ -312,7 +312,13 @@ __global__ __launch_bounds__(8 * NPOS, 1) void agg_tail_direct_kernel(TailArgs p
     }
     // by-product: the activated voxel of this thread's own position — ONE unconditional store per thread and plane (planes
     // beyond D write the zeros they loaded onto the zero halo plane; halo columns inside the tile likewise)
+#if defined(TAIL_EXP_NT_STORE)                            // (experiment: the by-product past the caches; tests/tools/exp_step.sh)
+    if (OUT) __builtin_nontemporal_store(centre, reinterpret_cast<f32x4*>(p.a_out + base + (long)min(q, D + 1) * plane_vox * 32));
+#elif defined(TAIL_EXP_NO_STORE)                          // (diagnostic: no by-product at all — the backward pass is then wrong)
+    if (OUT && q > 1000) *reinterpret_cast<f32x4*>(p.a_out + base + (long)min(q, D + 1) * plane_vox * 32) = centre;
+#else
     if (OUT) *reinterpret_cast<f32x4*>(p.a_out + base + (long)min(q, D + 1) * plane_vox * 32) = centre;
+#endif
     float q0 = p0.x + p0.y, q1 = p1.x + p1.y, q2 = p2.x + p2.y;
     q0 += __shfl_xor(q0, 1, 64); q1 += __shfl_xor(q1, 1, 64); q2 += __shfl_xor(q2, 1, 64);
     q0 += __shfl_xor(q0, 2, 64); q1 += __shfl_xor(q1, 2, 64); q2 += __shfl_xor(q2, 2, 64);
