@@ -10,57 +10,35 @@
 #include "as_common.h"
 
 // ---- finalize: one workgroup, 1024 threads = 32 slices x 32 channels ---------------------
-// Exact merge of the per-partial (n, mean, M2) triples in fp64, in two division-free passes:
-//   mean = sum n_i*mean_i / N;   M2 = sum [ M2_i + n_i*(mean_i - mean)^2 ].
-// Reads are 128-byte rows in a fixed order (deterministic).
+// Exact merge of the per-partial (n, mean, M2) triples in fp64:  mean = sum n_i*mean_i / N;  M2 = sum [ M2_i + n_i*(mean_i - mean)^2 ]
+// in its ONE-PASS form (bn_merge.h: with a pivot K = the first partial's mean, S0 = sum n_i, S1 = sum n_i (mean_i - K),
+// S2 = sum [ M2_i + n_i (mean_i - K)^2 ] give mean = K + S1/S0 and M2 = S2 - S1^2/S0 — the two-pass result to ~1e-15 relative
+// in fp64).  This launch is a single workgroup on the critical path of a layer: the two-pass form it had until round 5 was
+// two dependent rounds of loads (7.6 us per launch; 8 launches per step).  Reads are 128-byte rows in a fixed order.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* __restrict__ stat_mean, const float* __restrict__ stat_m2, const float* __restrict__ stat_cnt,
     int nparts, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, float* save_mean, float* save_invstd, float* scale, float* shift) {
-  __shared__ double red[32][33];
-  __shared__ double smean[32], scount;
+  __shared__ double red[3][32][33];
   const int c = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const double K = (double)stat_mean[c];
   // branch-free and unrolled: the loads of 8 iterations are independent and in flight together
   // (empty partials carry count 0, mean 0, M2 0)
-  double s = 0.0, cn = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll 8
   for (int i = sl; i < nparts; i += 32) {
     const double nb = (double)stat_cnt[i];
-    cn += nb;
-    s += nb * (double)stat_mean[i * 32 + c];
+    const double dm = (double)stat_mean[i * 32 + c] - K;
+    s0 += nb; s1 += nb * dm; s2 += (double)stat_m2[i * 32 + c] + nb * dm * dm;
   }
-  red[sl][c] = s;
+  red[0][sl][c] = s0; red[1][sl][c] = s1; red[2][sl][c] = s2;
   __syncthreads();
   if (sl == 0) {
-    double t = 0.0;
-    for (int j = 0; j < 32; ++j) t += red[j][c];
-    smean[c] = t;
-  }
-  __syncthreads();
-  red[sl][c] = cn;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int j = 0; j < 32; ++j) t += red[j][0];
-    scount = t;
-  }
-  __syncthreads();
-  const double count = scount;
-  const double mean = smean[c] / count;
-  double q = 0.0;
-#pragma unroll 8
-  for (int i = sl; i < nparts; i += 32) {
-    const double nb = (double)stat_cnt[i];
-    const double dm = (double)stat_mean[i * 32 + c] - mean;
-    q += (double)stat_m2[i * 32 + c] + nb * dm * dm;
-  }
-  __syncthreads();
-  red[sl][c] = q;
-  __syncthreads();
-  if (sl == 0) {
-    double m2 = 0.0;
-    for (int j = 0; j < 32; ++j) m2 += red[j][c];
-    const double n = count;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int j = 0; j < 32; ++j) { t0 += red[0][j][c]; t1 += red[1][j][c]; t2 += red[2][j][c]; }
+    const double n = t0;
+    const double mean = K + t1 / n;
+    const double m2 = fmax(t2 - t1 * t1 / n, 0.0);
     const double var_b = m2 / n;
     const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
     const float meanf = (float)mean;
