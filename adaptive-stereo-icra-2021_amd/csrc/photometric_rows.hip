@@ -6,8 +6,9 @@
 // kernels reproduce bit for bit (tests/test_gpu_kernels.py: the chain in one node against the separate functions).
 //
 // Shape of the work.  A wave owns 64 adjacent columns and walks down a strip of rows, one row per step.  Everything a 3x3
-// window needs from the neighbouring columns comes from the neighbouring LANES by wave-wide DPP shifts folded into the
-// additions (v_add_f32_dpp wave_shr:1 / wave_shl:1: no LDS, no shuffles, no barriers), everything it needs from the rows above
+// window needs from the neighbouring columns comes from the neighbouring LANES by wave-wide DPP shifts (v_mov_b32_dpp
+// wave_shr:1 / wave_shl:1 — checked on the chip by tests/tools/scratch/dpp_probe.hip: no LDS, no shuffles, no barriers;
+// the compiler keeps each shifted value in a register for its three uses), everything it needs from the rows above
 // from registers: each input value is loaded ONCE per strip (the one-thread-per-pixel kernels loaded ~100 values per pixel
 // in the forward pass, ~190 in the backward pass, and wrote / re-read ten coefficient planes between the two backward passes).
 // The 3x3 sums keep the reference's order — row-major, one addition per tap, (((a00 + a01) + a02) + a10) ... — so the pooled
@@ -15,8 +16,11 @@
 // starts take three additions each.  The backward pass chains two such stencils (pooled moments -> coefficients, coefficients ->
 // gradient of the warped image) inside the same walk, two rows of delay and two columns / rows of halo, so the ten coefficient
 // planes never exist.
-// HBM-bound by design: forward reads pred, left, right (gathered) and writes warped + mask: 41 B per pixel; backward reads
-// pred, left, right and writes two planes (+ the 12 B per pixel of the pass that subtracts the per-image mean term).
+// Traffic: forward reads pred, left, right (gathered) and writes warped + mask: 41 B per pixel; backward reads pred, left,
+// right and writes two planes (+ the 12 B per pixel of the pass that subtracts the per-image mean term).  What bounds the
+// two kernels is their VECTOR work, not HBM: ~500 / ~700 instructions per pixel-row (24 window sums x 10, 9 IEEE divisions,
+// 2 expf): 40 / 59 us at 4 pairs of 375 x 1242, 0.24 / 0.14 of the 8 TB/s peak on their algorithmic bytes (0.29 / 0.17 at 32
+// pairs) — against 237 us for the launches they replace.
 #include "photometric_dev.h"
 #pragma clang fp contract(off)
 
