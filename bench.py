@@ -70,7 +70,7 @@ T0 = time.perf_counter()
 
 
 def csrc_digest():
-  """sha256 over the kernel sources (csrc/*.hip, *.h, sorted by name) — recorded in a PMC summary when its counters are taken
+  """sha256 over the kernel sources (csrc/*.hip, *.h, sorted by name; code lines only) — recorded in a PMC summary when its counters are taken
   (tests/tools/pmc_summarize.py) and compared here: HBM-counter figures of other kernels than the ones this run timed are not
   reported."""
   import glob
@@ -78,7 +78,11 @@ def csrc_digest():
   h = hashlib.sha256()
   d = os.path.join(REPO, "adaptive-stereo-icra-2021_amd", "csrc")
   for path in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
-    h.update(os.path.basename(path).encode()); h.update(b"\0"); h.update(open(path, "rb").read())
+    h.update(os.path.basename(path).encode()); h.update(b"\0")
+    for line in open(path, "rb").read().split(b"\n"):
+      t = line.strip()
+      if t and not t.startswith(b"//"):          # (whole-line comments and blank lines do not change a kernel)
+        h.update(t); h.update(b"\n")
   return h.hexdigest()[:16]
 
 
